@@ -1,0 +1,166 @@
+/*
+ * wtk_hip.h — C ABI of libwtk_hip.so, the MI355X (gfx950) implementation of WTracker's
+ * per-frame detection + prediction hot path.
+ *
+ * The reference (giladfrid009/WTracker) is pure Python and has no FFI; the interfaces this
+ * library stands in for are the Python methods cited at each entry point (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes binding a WTracker maintainer
+ * would add to call these from the reference's own controllers.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; wtk_last_error() returns a
+ *     thread-local, NUL-terminated description of the last failure on the calling thread;
+ *   - plain pointers and sizes only; `stream` arguments are a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - a handle owns its weights and workspace (device memory); callers own all I/O buffers;
+ *   - a handle is not re-entrant: use one handle per stream / thread;
+ *   - "no detection" is not an error: the bbox row is 4 x NaN (yolo_controller.py:84-85).
+ */
+#ifndef WTK_HIP_H
+#define WTK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WTK_ABI_VERSION 1
+
+typedef enum wtk_dtype {
+    WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
+    WTK_F16 = 1  /* fp16 storage, fp16 MFMA (v_mfma_f32_16x16x32_f16) with fp32 accumulate */
+} wtk_dtype;
+
+const char *wtk_last_error(void);
+int wtk_abi_version(void);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int wtk_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ResMLP trajectory predictor.
+ * Replaces: WormPredictor.forward -> RMLP.forward   wtracker/neural/mlp.py:47-48,176-188
+ *           (MLPLayer = Linear+BatchNorm1d(eval)+ReLU, mlp.py:67-71; MlpBlock, mlp.py:121-126)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wtk_mlp wtk_mlp;
+
+/* One folded affine layer  y = act(W x + b).  BatchNorm1d running statistics are folded into
+ * (W, b) by the caller (eval mode, mlp_controllers.py:29).  W is row-major [out_dim][in_dim]. */
+typedef struct wtk_mlp_layer {
+    int32_t in_dim;
+    int32_t out_dim;
+    int32_t relu;        /* 1: ReLU after the affine */
+    int32_t reserved;
+    const float *weight; /* host pointer, [out_dim][in_dim] */
+    const float *bias;   /* host pointer, [out_dim]         */
+} wtk_mlp_layer;
+
+typedef struct wtk_mlp_desc {
+    int32_t device;           /* HIP device ordinal */
+    int32_t n_layers;         /* total: 1 (input) + n_blocks*layers_per_block + 1 (output) */
+    int32_t n_blocks;         /* residual blocks: h <- h + block(h)   (mlp.py:185-187)      */
+    int32_t layers_per_block; /* 4 in both shipped models                                    */
+    const wtk_mlp_layer *layers; /* order: input, block0.l0..l3, block1..., output           */
+} wtk_mlp_desc;
+
+int wtk_mlp_create(wtk_mlp **out, const wtk_mlp_desc *desc);
+void wtk_mlp_destroy(wtk_mlp *h);
+/* y[B][out] = model(x[B][in]); x and y are DEVICE pointers, fp32 row-major. */
+int wtk_mlp_forward(wtk_mlp *h, const float *x_dev, int32_t batch, float *y_dev, void *stream);
+/* Same with HOST pointers (synchronous): what MLPController.provide_movement_vector needs for
+ * its single [1,28] sample (mlp_controllers.py:59). */
+int wtk_mlp_forward_host(wtk_mlp *h, const float *x_host, int32_t batch, float *y_host);
+
+/* Batched open-loop form of MLPController.provide_movement_vector (mlp_controllers.py:36-68)
+ * over a device-resident track: for every sample s with anchor frame t = anchor_frames[s]
+ * gather the boxes track[t + input_frames[j]] (j < n_in; out-of-range or non-finite -> the
+ * sample is flagged invalid, mlp_controllers.py:43-44), subtract box 0's x/y from every x/y
+ * (mlp_controllers.py:50-56), run the model.  pred[s] = raw model output (dx, dy) before the
+ * host-side clip/round; valid[s] = 1/0.  track is [n_frames][4] fp32 xywh (absolute coords). */
+int wtk_mlp_predict_track(wtk_mlp *h, const float *track_dev, int32_t n_frames,
+                          const int32_t *anchor_frames_dev, int32_t n_samples,
+                          const int32_t *input_frames_host, int32_t n_in,
+                          float *pred_dev /*[n_samples][2]*/, int32_t *valid_dev /*[n_samples]*/,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * YOLOv8 detector (single image size per handle).
+ * Replaces: YoloController.predict          wtracker/sim/sim_controllers/yolo_controller.py:64-90
+ *           i.e. ultralytics YOLO.predict(source=frames, max_det=1, imgsz=..., conf=...):
+ *           letterbox + BGR->RGB + /255, DetectionModel forward, DFL decode,
+ *           non_max_suppression, scale_boxes, xyxy -> xywh.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wtk_yolo wtk_yolo;
+
+/* One fused conv (Conv2d + folded BatchNorm2d [+ SiLU]).  Weight layout is O-H-W-I:
+ * [cout][kh][kw][cin] fp32 (cin fastest).  The conv list order is fixed; see
+ * wtk_yolo_conv_count / wtk_yolo_conv_info. */
+typedef struct wtk_conv_blob {
+    int32_t cout, cin, k, stride;
+    int32_t act; /* 1: SiLU, 0: linear (the Detect heads' last 1x1) */
+    int32_t reserved;
+    const float *weight; /* host pointer */
+    const float *bias;   /* host pointer, [cout] */
+} wtk_conv_blob;
+
+typedef struct wtk_yolo_desc {
+    int32_t device;
+    int32_t dtype;      /* wtk_dtype */
+    int32_t imgsz_h;    /* network input height (multiple of 32) */
+    int32_t imgsz_w;    /* network input width  (multiple of 32) */
+    int32_t max_batch;  /* frames per forward pass the workspace is sized for */
+    int32_t nc;         /* number of classes (1 for the worm detector, yolo_train_config.yaml:27) */
+    float width_mult;   /* 0.50 for YOLOv8s */
+    float depth_mult;   /* 0.33 for YOLOv8s */
+    int32_t max_channels; /* 1024 for YOLOv8s */
+    int32_t n_convs;    /* must equal wtk_yolo_conv_count(width, depth, maxch, nc) */
+    const wtk_conv_blob *convs;
+} wtk_yolo_desc;
+
+/* Number / description of the fused convs a model of this scale has, in the order the blob
+ * table must follow.  name_out receives e.g. "model.2.m.0.cv1" (ultralytics module path). */
+int wtk_yolo_conv_count(float width_mult, float depth_mult, int32_t max_channels, int32_t nc);
+int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t max_channels, int32_t nc,
+                       int32_t index, int32_t *cout, int32_t *cin, int32_t *k, int32_t *stride,
+                       int32_t *act, char *name_out, size_t name_cap);
+
+int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *desc);
+void wtk_yolo_destroy(wtk_yolo *h);
+
+/* frames: DEVICE pointer, uint8, [B][H][W][C] with C = 1 (gray; replicated to 3 channels as
+ * yolo_controller.py:68-69 does) or C = 3 (BGR).  H x W is letterboxed to imgsz_h x imgsz_w
+ * (identity when equal).  Outputs (DEVICE pointers, may be NULL except out_xywh):
+ *   out_xywh   [B][4] fp32: x_topleft, y_topleft, w, h in input-image pixels; 4 x NaN = none
+ *   out_conf   [B]    fp32: score of the kept detection (0 when none)
+ *   out_anchor [B]    int32: anchor index of the kept detection (-1 when none)
+ * conf/iou/max_det follow non_max_suppression; max_det must be 1 (yolo_controller.py:76). */
+int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W,
+                     int32_t C, float conf, float iou, int32_t max_det, float *out_xywh,
+                     float *out_conf, int32_t *out_anchor, void *stream);
+/* Same with HOST pointers for frames and outputs (synchronous; PCIe-inclusive). */
+int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, int32_t B, int32_t H,
+                          int32_t W, int32_t C, float conf, float iou, int32_t max_det,
+                          float *out_xywh, float *out_conf, int32_t *out_anchor);
+
+/* Test / profiling hooks: raw head outputs of the last forward pass, copied to HOST as fp32.
+ *   level 0..2 -> stride 8/16/32.  box: [B][h*w][64] DFL logits; cls: [B][h*w][nc] logits. */
+int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float *box_host, float *cls_host);
+/* Run ONLY decode + selection on caller-provided head logits (HOST fp32, same layout as
+ * wtk_yolo_debug_head, levels concatenated in anchor order) — isolates the NMS/argmax logic
+ * from conv rounding for bit-exact index tests. */
+int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host /*[B][A][64]*/,
+                         const float *cls_host /*[B][A][nc]*/, int32_t B, int32_t H, int32_t W,
+                         float conf, float *out_xywh, float *out_conf, int32_t *out_anchor);
+/* Algorithmic work of one forward pass: conv MACs per frame and the number of anchors. */
+int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors);
+/* Average device time (ms) per launch of each kernel class over the frames processed since
+ * the last reset, measured with HIP events on the caller's stream when profiling is enabled.
+ * kernel_class: 0 stem, 1 conv (implicit GEMM), 2 pool, 3 head (decode+select). */
+int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled);
+int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WTK_HIP_H */

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  Nothing of the reference's source is copied: the outputs are
+numeric data only (model parameters, input/output vectors, CSV logs).
+
+The reference imports `tkinter`, `cv2` and `ultralytics` at module import time
+(wtracker/utils/gui_utils.py:1, wtracker/utils/io_utils.py:1,
+wtracker/sim/sim_controllers/yolo_controller.py:6).  None of them is installed
+here and none of their functions is executed on the CSV/ResMLP path with all
+LogConfig.save_* flags off, so empty placeholder modules are registered in
+sys.modules before the import.
+
+Outputs
+  resmlp_100ms.npz / resmlp_200ms.npz   raw state-dict tensors, IOConfig, golden (x, y) pairs
+  sim_init_bboxes.csv                   seeded synthetic pre-detected track (input)
+  sim_mlp_bboxes.csv                    reference LoggingController(MLPController) log
+  sim_csv_bboxes.csv                    reference LoggingController(CsvController) log
+  sim_moves.json                        per-cycle (dx, dy) returned by provide_movement_vector
+  timing.json                           TimingConfig numbers for several (imaging, pred, moving) triples
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _register_placeholders():
+    tk = types.ModuleType("tkinter")
+    tk.Tk = object
+    fd = types.ModuleType("tkinter.filedialog")
+    tk.filedialog = fd
+    cv2 = types.ModuleType("cv2")
+    cv2.IMREAD_GRAYSCALE = 0
+    cv2.IMREAD_COLOR = 1
+    ul = types.ModuleType("ultralytics")
+    ul.YOLO = type("YOLO", (), {})
+    for name, mod in (("tkinter", tk), ("tkinter.filedialog", fd), ("cv2", cv2), ("ultralytics", ul)):
+        sys.modules.setdefault(name, mod)
+
+
+def synthetic_track(num_frames: int, seed: int, start=(1300.0, 1200.0), nan_rows=(57,)) -> np.ndarray:
+    """Seeded random-walk head track, SURVEY.md §8d: speed mean 0.54 px/frame, sigma 0.28,
+    head box ~13.8 x 14.6 px.  Returns [N,4] xywh float64 with NaN rows = missed detections."""
+    rng = np.random.default_rng(seed)
+    heading = rng.uniform(0, 2 * np.pi)
+    pos = np.array(start, dtype=np.float64)
+    out = np.empty((num_frames, 4), dtype=np.float64)
+    for i in range(num_frames):
+        speed = max(0.0, rng.normal(0.54, 0.28))
+        heading += rng.normal(0.0, 0.15)
+        pos = pos + speed * np.array([np.cos(heading), np.sin(heading)])
+        w = 13.8 + rng.normal(0, 0.6)
+        h = 14.6 + rng.normal(0, 0.6)
+        out[i] = (pos[0] - w / 2, pos[1] - h / 2, w, h)
+    for r in nan_rows:
+        if 0 <= r < num_frames:
+            out[r] = np.nan
+    return out
+
+
+def model_inputs(io_config, n: int, seed: int) -> np.ndarray:
+    """Inputs shaped like MLPController builds them (mlp_controllers.py:50-56): 7 xywh boxes,
+    x/y relative to the first box's corner."""
+    rng = np.random.default_rng(seed)
+    k = len(io_config.input_frames)
+    x = np.zeros((n, k, 4), dtype=np.float64)
+    for i in range(n):
+        v = rng.normal(0, 0.8, size=2)
+        for j, f in enumerate(io_config.input_frames):
+            x[i, j, 0:2] = v * f + rng.normal(0, 0.3, size=2)
+            x[i, j, 2] = 13.8 + rng.normal(0, 0.8)
+            x[i, j, 3] = 14.6 + rng.normal(0, 0.8)
+        x[i, :, 0] -= x[i, 0, 0]
+        x[i, :, 1] -= x[i, 0, 1]
+    return x.reshape(n, k * 4).astype(np.float32)
+
+
+def main():
+    _register_placeholders()
+    sys.path.insert(0, REF)
+    import torch
+
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+
+    from wtracker.sim.config import TimingConfig, ExperimentConfig
+    from wtracker.sim.simulator import Simulator
+    from wtracker.sim.sim_controllers.csv_controller import CsvController
+    from wtracker.sim.sim_controllers.mlp_controllers import MLPController
+    from wtracker.sim.sim_controllers.logging_controller import LoggingController, LogConfig
+
+    models = {
+        "100ms": "ResMLP(imaging-100ms_pred-40ms_moving-50ms).pt",
+        "200ms": "ResMLP(imaging-200ms_pred-40ms_moving-50ms).pt",
+    }
+    loaded = {}
+    for tag, fname in models.items():
+        m = torch.load(os.path.join(REF, "models", fname), weights_only=False, map_location="cpu")
+        m.eval()
+        loaded[tag] = m
+        sd = m.state_dict()
+        arrays = {"sd::" + k: v.detach().cpu().numpy() for k, v in sd.items()}
+        digest = hashlib.sha256(b"".join(np.ascontiguousarray(v).tobytes() for v in arrays.values())).hexdigest()
+        x = model_inputs(m.io_config, 256, seed=1234)
+        with torch.no_grad():
+            y_batch = m.forward(torch.from_numpy(x)).numpy()
+            y_single = np.concatenate([m.forward(torch.from_numpy(x[i : i + 1])).numpy() for i in range(x.shape[0])])
+            y_zero = m.forward(torch.zeros(1, x.shape[1])).numpy()
+        np.savez(
+            os.path.join(HERE, f"resmlp_{tag}.npz"),
+            input_frames=np.asarray(m.io_config.input_frames, dtype=np.int64),
+            pred_frames=np.asarray(m.io_config.pred_frames, dtype=np.int64),
+            x=x,
+            y_batch=y_batch,
+            y_single=y_single,
+            y_zero=y_zero,
+            sha256=np.frombuffer(digest.encode(), dtype=np.uint8),
+            **arrays,
+        )
+        print(tag, "params", sum(v.size for k, v in arrays.items() if "num_batches" not in k), "f(0)=", y_zero, digest[:16])
+
+    # ---- timing arithmetic fixtures (sim/config.py:41-67)
+    exp_cfg_json = json.load(open(os.path.join(REF, "experiments/exp0/exp_config.json")))
+    timing_rows = []
+    for fps, ppm in ((60, 90), (60, 88), (30, 92), (50, 91.5)):
+        for trip in ((100, 40, 50), (200, 40, 50), (250, 60, 70), (16, 16, 17), (83.4, 33.3, 50.1)):
+            ec = ExperimentConfig(name="t", num_frames=10, frames_per_sec=fps, orig_resolution=(1600, 1400), px_per_mm=ppm, init_position=(10, 10))
+            tc = TimingConfig(ec, trip[0], trip[1], trip[2], (4, 4), (0.32, 0.32))
+            timing_rows.append(
+                dict(fps=fps, px_per_mm=ppm, imaging_ms=trip[0], pred_ms=trip[1], moving_ms=trip[2],
+                     imaging_frame_num=tc.imaging_frame_num, pred_frame_num=tc.pred_frame_num,
+                     moving_frame_num=tc.moving_frame_num, cycle_frame_num=tc.cycle_frame_num,
+                     camera_size_px=list(tc.camera_size_px), micro_size_px=list(tc.micro_size_px),
+                     ms_per_frame=tc.ms_per_frame))
+    json.dump(timing_rows, open(os.path.join(HERE, "timing.json"), "w"), indent=1)
+
+    # ---- golden sim loop (SURVEY.md §3.2, §8d "Synthetic tracks for C1")
+    num_frames = 200
+    track = synthetic_track(num_frames, seed=0)
+    init_csv = os.path.join(HERE, "sim_init_bboxes.csv")
+    with open(init_csv, "w") as f:
+        f.write("frame,wrm_x,wrm_y,wrm_w,wrm_h\n")
+        for i, r in enumerate(track):
+            f.write(f"{i}," + ",".join("" if not np.isfinite(v) else repr(float(v)) for v in r) + "\n")
+
+    moves = {}
+
+    def run(kind: str, out_name: str, timing=(100, 40, 50), model_tag="100ms"):
+        ec = ExperimentConfig(
+            name="exp0", num_frames=num_frames, frames_per_sec=exp_cfg_json["frames_per_sec"],
+            orig_resolution=tuple(exp_cfg_json["orig_resolution"]), px_per_mm=exp_cfg_json["px_per_mm"],
+            init_position=tuple(exp_cfg_json["init_position"]))
+        tc = TimingConfig(ec, timing[0], timing[1], timing[2], (4, 4), (0.32, 0.32))
+        if kind == "mlp":
+            ctrl = MLPController(tc, init_csv, loaded[model_tag], max_speed=0.9)
+        else:
+            ctrl = CsvController(tc, init_csv)
+        rec = []
+        orig = ctrl.provide_movement_vector
+
+        def wrapped(sim):
+            dx, dy = orig(sim)
+            rec.append([int(sim.frame_number), int(dx), int(dy)])
+            return dx, dy
+
+        ctrl.provide_movement_vector = wrapped
+        tmp = tempfile.mkdtemp(prefix="wtk_golden_")
+        try:
+            lc = LogConfig(root_folder=tmp, save_mic_view=False, save_cam_view=False, save_err_view=False, save_wrm_view=False)
+            sim = Simulator(tc, ec, LoggingController(ctrl, lc))
+            sim.run()
+            shutil.copy(lc.bbox_file_path, os.path.join(HERE, out_name))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        moves[out_name] = rec
+
+    run("mlp", "sim_mlp_bboxes.csv")
+    run("csv", "sim_csv_bboxes.csv")
+    run("mlp", "sim_mlp200_bboxes.csv", timing=(200, 40, 50), model_tag="200ms")
+    json.dump(moves, open(os.path.join(HERE, "sim_moves.json"), "w"))
+    for k, v in moves.items():
+        print(k, "cycles", len(v), "last", v[-1])
+
+
+if __name__ == "__main__":
+    main()

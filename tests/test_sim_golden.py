@@ -1,0 +1,97 @@
+"""The harness (wtracker_amd/sim.py), CsvController and the oracle MLP controller reproduce the logs
+the REAL reference wrote for the same seeded input (tests/golden/*.csv, sim_moves.json).  CPU only."""
+import csv
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import resmlp_oracle
+from oracle.controllers_oracle import OracleMLPController
+from wtracker_amd.controllers import CsvController
+from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger, discretize
+
+EXP0 = dict(name="exp0", num_frames=200, frames_per_sec=60, orig_resolution=(1600, 1400), px_per_mm=90, init_position=(1300, 1200))
+
+
+def read_log(path):
+    with open(path, newline="") as f:
+        return list(csv.DictReader(f))
+
+
+def assert_rows_equal(rows, golden):
+    assert len(rows) == len(golden)
+    for r, g in zip(rows, golden):
+        for k, gv in g.items():
+            v = r[k]
+            if k == "phase":
+                assert v == gv
+            elif gv in ("", "nan"):
+                assert not np.isfinite(float(v))
+            else:
+                assert float(v) == float(gv), (k, r["frame"], v, gv)
+
+
+def test_timing_arithmetic(golden_dir):
+    for t in json.load(open(os.path.join(golden_dir, "timing.json"))):
+        ec = ExperimentConfig("t", 10, t["fps"], (1600, 1400), t["px_per_mm"], (10, 10))
+        tc = TimingConfig(ec, t["imaging_ms"], t["pred_ms"], t["moving_ms"], (4, 4), (0.32, 0.32))
+        assert (tc.imaging_frame_num, tc.pred_frame_num, tc.moving_frame_num, tc.cycle_frame_num) == (
+            t["imaging_frame_num"], t["pred_frame_num"], t["moving_frame_num"], t["cycle_frame_num"])
+        assert list(tc.camera_size_px) == t["camera_size_px"] and list(tc.micro_size_px) == t["micro_size_px"]
+        assert tc.ms_per_frame == t["ms_per_frame"]
+
+
+def run(ctrl_factory, timing=(100, 40, 50)):
+    ec = ExperimentConfig(**EXP0)
+    tc = TimingConfig(ec, *timing, (4, 4), (0.32, 0.32))
+    ctrl = ctrl_factory(tc)
+    moves = []
+    inner = ctrl.provide_movement_vector
+
+    def wrapped(sim):
+        dx, dy = inner(sim)
+        moves.append([int(sim.frame_number), int(dx), int(dy)])
+        return dx, dy
+
+    ctrl.provide_movement_vector = wrapped
+    log = TrackLogger(ctrl)
+    Simulator(tc, ec, log).run()
+    return log.rows, moves
+
+
+def test_csv_controller_loop_matches_reference_log(golden_dir):
+    init = os.path.join(golden_dir, "sim_init_bboxes.csv")
+    rows, moves = run(lambda tc: CsvController(tc, init))
+    assert_rows_equal(rows, read_log(os.path.join(golden_dir, "sim_csv_bboxes.csv")))
+    assert moves == json.load(open(os.path.join(golden_dir, "sim_moves.json")))["sim_csv_bboxes.csv"]
+    assert len(rows) == 198  # the last cycle is never logged
+
+
+@pytest.mark.parametrize("tag,timing,name", [("100ms", (100, 40, 50), "sim_mlp_bboxes.csv"), ("200ms", (200, 40, 50), "sim_mlp200_bboxes.csv")])
+def test_oracle_mlp_controller_loop_matches_reference_log(golden_dir, tag, timing, name):
+    init = os.path.join(golden_dir, "sim_init_bboxes.csv")
+    st = resmlp_oracle.load_state(os.path.join(golden_dir, f"resmlp_{tag}.npz"))
+    rows, moves = run(lambda tc: OracleMLPController(tc, init, st), timing)
+    assert moves == json.load(open(os.path.join(golden_dir, "sim_moves.json")))[name]
+    assert_rows_equal(rows, read_log(os.path.join(golden_dir, name)))
+
+
+def test_csv_predict_edge_cases(golden_dir):
+    ec = ExperimentConfig(**EXP0)
+    tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.32, 0.32))
+    c = CsvController(tc, os.path.join(golden_dir, "sim_init_bboxes.csv"))
+    out = c.predict([-3, 0, 57, 199, 200], relative=False)
+    assert np.isnan(out[0]).all() and np.isnan(out[2]).all() and np.isnan(out[4]).all()  # OOB, missed detection, OOB
+    assert np.isfinite(out[1]).all() and np.isfinite(out[3]).all()
+    with pytest.raises(AssertionError):
+        c.predict([])
+
+
+def test_discretize():
+    b = np.array([[10.2, 5.7, 3.1, 4.0], [np.nan, 1, 1, 1], [-5.0, -5.0, 3.0, 3.0], [1395.5, 1590.0, 20.0, 20.0]])
+    d, ok = discretize(b, (1600, 1400))
+    assert d.dtype == np.int32
+    assert d.tolist() == [[10, 5, 4, 5], [0, 0, 0, 0], [0, 0, 0, 0], [1395, 1590, 5, 10]]
+    assert ok.tolist() == [True, False, False, True]

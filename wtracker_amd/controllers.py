@@ -1,0 +1,215 @@
+"""Drop-in controllers: the reference's `SimController` implementations for the hot path, with the
+arithmetic executed by libwtk_hip.so on the MI355X.
+
+Mirrors (same constructor arguments, method names, return conventions, error behaviour):
+  CsvController      wtracker/sim/sim_controllers/csv_controller.py:11-73
+  HipMLPController   <- MLPController   wtracker/sim/sim_controllers/mlp_controllers.py:14-71
+  YoloConfig         wtracker/sim/sim_controllers/yolo_controller.py:15-45
+  HipYoloController  <- YoloController  wtracker/sim/sim_controllers/yolo_controller.py:48-109
+"""
+from __future__ import annotations
+
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Any, Collection, Optional
+
+import numpy as np
+
+from . import hip, yolo_spec
+from .resmlp import FoldedResMLP, from_torch_module
+from .sim import SimController, TimingConfig
+
+
+def _read_track_csv(path: str) -> np.ndarray:
+    """Columns wrm_x, wrm_y, wrm_w, wrm_h as float64 [N,4]; empty cells -> NaN.  Parsed with pandas'
+    default C float parser on purpose: it is what the reference uses (csv_controller.py:16) and it is
+    not round-trip exact, so any other parser differs from the reference's table in the last ulp."""
+    import pandas as pd
+
+    return pd.read_csv(path, usecols=["wrm_x", "wrm_y", "wrm_w", "wrm_h"]).to_numpy(dtype=float)
+
+
+class CsvController(SimController):
+    """Replays pre-detected boxes (the record/replay feeder under MLPController)."""
+
+    def __init__(self, timing_config: TimingConfig, csv_path: str):
+        super().__init__(timing_config)
+        self.csv_path = csv_path
+        self._csv_data = _read_track_csv(csv_path)
+        self._camera_bboxes = deque(maxlen=timing_config.cycle_frame_num)
+
+    def on_sim_start(self, sim):
+        self._camera_bboxes.clear()
+
+    def on_camera_frame(self, sim):
+        self._camera_bboxes.append(sim.view.camera_position)
+
+    def predict(self, frame_nums: Collection[int], relative: bool = True) -> np.ndarray:
+        assert len(frame_nums) > 0
+        frame_nums = np.asanyarray(frame_nums, dtype=int)
+        valid = (frame_nums >= 0) & (frame_nums < self._csv_data.shape[0])
+        boxes = np.full((frame_nums.shape[0], 4), np.nan)
+        boxes[valid] = self._csv_data[frame_nums[valid], :]
+        if not relative:
+            return boxes
+        n = self.timing_config.cycle_frame_num
+        cams = np.asanyarray([self._camera_bboxes[f % n] for f in frame_nums], dtype=float)
+        boxes[:, 0] -= cams[:, 0]
+        boxes[:, 1] -= cams[:, 1]
+        return boxes
+
+    def begin_movement_prediction(self, sim) -> None:
+        pass
+
+    def provide_movement_vector(self, sim) -> tuple:
+        box = self.predict([sim.frame_number - self.timing_config.pred_frame_num])[0, :]
+        if not np.isfinite(box).all():
+            return 0, 0
+        cx, cy = box[0] + box[2] / 2, box[1] + box[3] / 2
+        return round(cx - sim.view.camera_size[0] / 2), round(cy - sim.view.camera_size[1] / 2)
+
+    def _cycle_predict_all(self, sim) -> np.ndarray:
+        start = (sim.cycle_number - 1) * self.timing_config.cycle_frame_num
+        end = min(start + self.timing_config.cycle_frame_num, len(self._csv_data))
+        return self.predict(np.arange(start, end))
+
+
+class HipMLPController(CsvController):
+    """MLPController with the ResMLP forward on the GPU (wtk_mlp_forward_host).
+
+    `model` may be a `FoldedResMLP` (see wtracker_amd.resmlp) or a live reference `WormPredictor`
+    (anything with `state_dict()` and `io_config`), as simulate.ipynb cell 9 passes."""
+
+    def __init__(self, timing_config: TimingConfig, csv_path: str, model, max_speed: float = 0.9, device: int = 0):
+        super().__init__(timing_config, csv_path)
+        folded: FoldedResMLP = model if isinstance(model, FoldedResMLP) else from_torch_module(model)
+        self.model = folded
+        self.input_frames = list(folded.input_frames)
+        self.pred_frames = list(folded.pred_frames)
+        self._mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=device)
+        max_speed_px_frame = max_speed * (timing_config.px_per_mm / timing_config.frames_per_sec)
+        self.max_dist_per_pred = max_speed_px_frame * self.pred_frames[0]
+
+    def provide_movement_vector(self, sim) -> tuple:
+        frames = np.asanyarray(self.input_frames, dtype=int) + (sim.frame_number - self.timing_config.pred_frame_num)
+        cam = np.asanyarray(sim.view.camera_position)
+        cam_center = (cam[0] + cam[2] / 2, cam[1] + cam[3] / 2)
+        boxes = self.predict(frames, relative=False).reshape(1, -1)  # float64, NaN when out of range
+        if not np.isfinite(boxes).all():
+            return 0, 0
+        # the model is fed the box CORNER (not centre) of frame 0 as origin (mlp_controllers.py:46-56)
+        x0, y0 = boxes[0, 0], boxes[0, 1]
+        rel_x, rel_y = x0 - cam_center[0], y0 - cam_center[1]
+        boxes[:, 0::4] -= x0
+        boxes[:, 1::4] -= y0
+        pred = self._mlp.forward_host(boxes.astype(np.float32))[0]  # float64 -> float32 as torch.Tensor(ndarray) does
+        pred = np.clip(pred, -self.max_dist_per_pred, self.max_dist_per_pred)
+        # float64 add + Python banker's rounding stay on the host, exactly as written in the reference
+        return round(pred[0].item() + rel_x), round(pred[1].item() + rel_y)
+
+
+@dataclass
+class YoloConfig:
+    """Same fields as the reference's YoloConfig.  `model_path` is a WTKYOLO1 weight file
+    (wtracker_amd.yolo_spec.save_weights); `device` 'cuda' / 'cuda:N' selects the MI355X."""
+
+    model_path: str
+    device: str = "cuda"
+    verbose: bool = False
+    pred_kwargs: dict = field(default_factory=lambda: {"imgsz": 384, "conf": 0.1})
+    # extensions (not in the reference): arithmetic type and model scale
+    dtype: str = "fp16"
+    scale: str = "s"
+    max_batch: int = 64
+    model: Any = field(default=None, init=False, repr=False)
+
+    def __getstate__(self) -> dict:
+        state = self.__dict__.copy()
+        del state["model"]  # like the reference, never serialise the model (yolo_controller.py:37-40)
+        return state
+
+    def device_index(self) -> int:
+        if self.device == "cpu":
+            raise hip.WtkError("HipYoloController has no CPU path: use device='cuda' (the MI355X)")
+        return int(self.device.split(":")[1]) if ":" in self.device else 0
+
+    def load_model(self) -> "_YoloModel":
+        if self.model is None:
+            self.model = _YoloModel(self)
+        return self.model
+
+
+class _YoloModel:
+    """Weights + one device detector per network input shape (created on first use)."""
+
+    def __init__(self, cfg: YoloConfig):
+        self.cfg = cfg
+        self.weights, self.nc = yolo_spec.load_weights(cfg.model_path)
+        self._dets: dict = {}
+
+    def detector(self, net_hw: tuple, batch: int) -> hip.HipYolo:
+        det = self._dets.get(net_hw)
+        if det is None or det.max_batch < batch:
+            if det is not None:
+                det.close()
+            width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
+            det = hip.HipYolo(self.weights, net_hw, max(batch, self.cfg.max_batch), dtype=self.cfg.dtype, nc=self.nc,
+                              width=width, depth=depth, max_channels=maxch, device=self.cfg.device_index())
+            self._dets[net_hw] = det
+        return det
+
+
+class HipYoloController(SimController):
+    def __init__(self, timing_config: TimingConfig, yolo_config: YoloConfig):
+        super().__init__(timing_config)
+        self.yolo_config = yolo_config
+        self._camera_frames = deque(maxlen=timing_config.cycle_frame_num)
+        self._model = yolo_config.load_model()
+
+    def on_sim_start(self, sim):
+        self._camera_frames.clear()
+
+    def on_camera_frame(self, sim):
+        self._camera_frames.append(sim.camera_view())
+
+    def on_cycle_end(self, sim):
+        self._camera_frames.clear()
+
+    def predict(self, frames: Collection[np.ndarray]) -> np.ndarray:
+        """frames: HxW (gray) or HxWx3 (BGR) uint8 arrays of one shape -> [N,4] (x, y, w, h) in frame
+        pixels; a frame without a detection above `conf` yields a NaN row.  float32, or float64 when
+        any row is NaN (np.stack of float32 boxes and float64 NaN rows, yolo_controller.py:85-90)."""
+        assert len(frames) > 0
+        batch = np.stack([np.asarray(f) for f in frames], axis=0)
+        if batch.dtype != np.uint8:
+            raise hip.WtkError("frames must be uint8")
+        kw = dict(self.yolo_config.pred_kwargs)
+        imgsz = int(kw.pop("imgsz", 640))
+        conf = float(kw.pop("conf", 0.25))
+        iou = float(kw.pop("iou", 0.7))
+        if "max_det" in kw:
+            raise TypeError("predict() got multiple values for keyword argument 'max_det'")  # as the reference would
+        H, W = batch.shape[1], batch.shape[2]
+        net_hw = yolo_spec.letterbox_shape(H, W, imgsz)
+        det = self._model.detector(net_hw, batch.shape[0])
+        xywh, _, anchor = det.predict_host(batch, conf=conf, iou=iou, max_det=1)
+        if (anchor < 0).any():
+            out = xywh.astype(np.float64)
+            out[anchor < 0] = np.nan
+            return out
+        return xywh
+
+    def begin_movement_prediction(self, sim) -> None:
+        pass
+
+    def provide_movement_vector(self, sim) -> tuple:
+        frame = self._camera_frames[-self.timing_config.pred_frame_num]
+        bbox = self.predict([frame])[0]
+        if not np.isfinite(bbox).all():
+            return 0, 0
+        mid = bbox[0] + bbox[2] / 2, bbox[1] + bbox[3] / 2
+        cam_mid = sim.view.camera_size[0] / 2, sim.view.camera_size[1] / 2
+        return round(mid[0] - cam_mid[0]), round(mid[1] - cam_mid[1])
+
+    def _cycle_predict_all(self, sim) -> np.ndarray:
+        return self.predict(self._camera_frames)

@@ -1,0 +1,935 @@
+// C ABI of libwtk_hip.so (see include/wtk_hip.h): handle management, YOLOv8 graph planning
+// (channel-slice views instead of concat/upsample tensors), weight packing and kernel launches.
+#include "../../include/wtk_hip.h"
+#include "wtk_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace wtk;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+static int fail_hip(const char *what, hipError_t e) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+}
+#define HIP_TRY(expr)                                                                                                          \
+    do {                                                                                                                       \
+        hipError_t _e = (expr);                                                                                                \
+        if (_e != hipSuccess) return fail_hip(#expr, _e);                                                                      \
+    } while (0)
+
+extern "C" const char *wtk_last_error(void) { return g_err.c_str(); }
+extern "C" int wtk_abi_version(void) { return WTK_ABI_VERSION; }
+extern "C" int wtk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static bool g_attr_done = false;
+static int ensure_attributes() {
+    if (g_attr_done) return 0;
+    HIP_TRY(conv_init_attributes());
+    HIP_TRY(pool_init_attributes());
+    g_attr_done = true;
+    return 0;
+}
+
+static uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f; // round-to-nearest-even, host compiler builtin
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+
+// =============================================================================================
+// ResMLP
+// =============================================================================================
+struct wtk_mlp {
+    int device = 0;
+    int n_layers = 0, n_blocks = 0, layers_per_block = 0;
+    int in_dim = 0, out_dim = 0;
+    float *params = nullptr;
+    MlpLayerDev *layers = nullptr;
+    // scratch for the host-pointer entry point
+    float *x_dev = nullptr, *y_dev = nullptr;
+    int scratch_cap = 0;
+};
+
+extern "C" int wtk_mlp_create(wtk_mlp **out, const wtk_mlp_desc *d) {
+    if (!out || !d || !d->layers) return fail("wtk_mlp_create: null argument");
+    if (d->n_layers != 2 + d->n_blocks * d->layers_per_block) return fail("wtk_mlp_create: n_layers != 2 + n_blocks*layers_per_block");
+    if (d->n_layers > kMlpMaxLayers) return fail("wtk_mlp_create: too many layers");
+    if (wtk_device_count() <= d->device) return fail("wtk_mlp_create: no such HIP device (is a GPU visible?)");
+    HIP_TRY(hipSetDevice(d->device));
+    std::vector<MlpLayerDev> L(d->n_layers);
+    std::vector<float> blob;
+    for (int i = 0; i < d->n_layers; ++i) {
+        const wtk_mlp_layer &s = d->layers[i];
+        if (s.in_dim <= 0 || s.out_dim <= 0 || s.in_dim > kMlpMaxDim || s.out_dim > kMlpMaxDim) return fail("wtk_mlp_create: layer dim out of range");
+        if (i > 0) {
+            const bool block_first = (i - 1) % std::max(d->layers_per_block, 1) == 0 && i < d->n_layers - 1;
+            const int prev_out = (block_first || i == d->n_layers - 1) ? L[0].out_dim : L[i - 1].out_dim;
+            if (s.in_dim != prev_out) return fail("wtk_mlp_create: layer dims do not chain");
+        }
+        MlpLayerDev &l = L[i];
+        l.in_dim = s.in_dim;
+        l.out_dim = s.out_dim;
+        l.in_pad = (s.in_dim + 3) / 4 * 4;
+        l.out_pad = (s.out_dim + 15) / 16 * 16;
+        l.relu = s.relu;
+        l.w_off = (int)blob.size();
+        blob.resize(blob.size() + (size_t)l.out_pad * l.in_pad, 0.f);
+        for (int o = 0; o < s.out_dim; ++o)
+            for (int k = 0; k < s.in_dim; ++k) blob[l.w_off + (size_t)o * l.in_pad + k] = s.weight[(size_t)o * s.in_dim + k];
+        l.b_off = (int)blob.size();
+        blob.resize(blob.size() + l.out_pad, 0.f);
+        for (int o = 0; o < s.out_dim; ++o) blob[l.b_off + o] = s.bias[o];
+        l.pad_ = 0;
+    }
+    // every block must return to the residual width
+    for (int b = 0; b < d->n_blocks; ++b)
+        if (L[d->layers_per_block * (b + 1)].out_dim != L[0].out_dim) return fail("wtk_mlp_create: block output dim != residual dim");
+    wtk_mlp *h = new wtk_mlp();
+    h->device = d->device;
+    h->n_layers = d->n_layers;
+    h->n_blocks = d->n_blocks;
+    h->layers_per_block = d->layers_per_block;
+    h->in_dim = L[0].in_dim;
+    h->out_dim = L.back().out_dim;
+    hipError_t e;
+    if ((e = hipMalloc(&h->params, blob.size() * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(&h->layers, L.size() * sizeof(MlpLayerDev))) != hipSuccess ||
+        (e = hipMemcpy(h->params, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->layers, L.data(), L.size() * sizeof(MlpLayerDev), hipMemcpyHostToDevice)) != hipSuccess) {
+        wtk_mlp_destroy(h);
+        return fail_hip("wtk_mlp_create", e);
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void wtk_mlp_destroy(wtk_mlp *h) {
+    if (!h) return;
+    (void)hipFree(h->params);
+    (void)hipFree(h->layers);
+    (void)hipFree(h->x_dev);
+    (void)hipFree(h->y_dev);
+    delete h;
+}
+
+static MlpArgs mlp_base_args(wtk_mlp *h) {
+    MlpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.params = h->params;
+    a.layers = h->layers;
+    a.n_layers = h->n_layers;
+    a.n_blocks = h->n_blocks;
+    a.layers_per_block = h->layers_per_block;
+    a.in_dim = h->in_dim;
+    a.out_dim = h->out_dim;
+    return a;
+}
+
+extern "C" int wtk_mlp_forward(wtk_mlp *h, const float *x_dev, int32_t batch, float *y_dev, void *stream) {
+    if (!h || !x_dev || !y_dev) return fail("wtk_mlp_forward: null argument");
+    if (batch < 0) return fail("wtk_mlp_forward: negative batch");
+    if (batch == 0) return 0;
+    MlpArgs a = mlp_base_args(h);
+    a.x = x_dev;
+    a.y = y_dev;
+    a.B = batch;
+    HIP_TRY(launch_mlp(a, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int wtk_mlp_forward_host(wtk_mlp *h, const float *x_host, int32_t batch, float *y_host) {
+    if (!h || !x_host || !y_host) return fail("wtk_mlp_forward_host: null argument");
+    if (batch <= 0) return batch == 0 ? 0 : fail("wtk_mlp_forward_host: negative batch");
+    HIP_TRY(hipSetDevice(h->device));
+    if (batch > h->scratch_cap) {
+        (void)hipFree(h->x_dev);
+        (void)hipFree(h->y_dev);
+        h->x_dev = h->y_dev = nullptr;
+        h->scratch_cap = 0;
+        const int cap = std::max(batch, 256);
+        HIP_TRY(hipMalloc(&h->x_dev, (size_t)cap * h->in_dim * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->y_dev, (size_t)cap * h->out_dim * sizeof(float)));
+        h->scratch_cap = cap;
+    }
+    HIP_TRY(hipMemcpy(h->x_dev, x_host, (size_t)batch * h->in_dim * sizeof(float), hipMemcpyHostToDevice));
+    if (wtk_mlp_forward(h, h->x_dev, batch, h->y_dev, nullptr)) return 1;
+    HIP_TRY(hipMemcpy(y_host, h->y_dev, (size_t)batch * h->out_dim * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int wtk_mlp_predict_track(wtk_mlp *h, const float *track_dev, int32_t n_frames, const int32_t *anchor_frames_dev,
+                                     int32_t n_samples, const int32_t *input_frames_host, int32_t n_in, float *pred_dev,
+                                     int32_t *valid_dev, void *stream) {
+    if (!h || !track_dev || !anchor_frames_dev || !input_frames_host || !pred_dev) return fail("wtk_mlp_predict_track: null argument");
+    if (n_in <= 0 || n_in > kMlpMaxInputFrames || n_in * 4 != h->in_dim) return fail("wtk_mlp_predict_track: n_in*4 must equal the model's input dim");
+    if (n_samples < 0 || n_frames < 0) return fail("wtk_mlp_predict_track: negative size");
+    if (n_samples == 0) return 0;
+    MlpArgs a = mlp_base_args(h);
+    a.x = nullptr;
+    a.track = track_dev;
+    a.n_frames = n_frames;
+    a.anchor_frames = anchor_frames_dev;
+    for (int i = 0; i < n_in; ++i) a.input_frames[i] = input_frames_host[i];
+    a.n_in = n_in;
+    a.valid = valid_dev;
+    a.y = pred_dev;
+    a.B = n_samples;
+    HIP_TRY(launch_mlp(a, (hipStream_t)stream));
+    return 0;
+}
+
+// =============================================================================================
+// YOLOv8
+// =============================================================================================
+namespace {
+
+struct ConvSpec {
+    std::string name;
+    int cout, cin, k, stride, act;
+};
+
+struct ModelDims {
+    int c[5];  // channel widths of P1..P5
+    int n[4];  // C2f repeats of layers 2,4,6,8
+    int hb, hc; // Detect hidden widths (box tower, cls tower)
+    int nc;
+};
+
+static int make_divisible8(double x) { return (int)(std::ceil(x / 8.0) * 8.0); }
+
+static ModelDims model_dims(float width, float depth, int max_ch, int nc) {
+    ModelDims d;
+    const int base[5] = {64, 128, 256, 512, 1024};
+    for (int i = 0; i < 5; ++i) d.c[i] = make_divisible8(std::min(base[i], max_ch) * (double)width);
+    const int nb[4] = {3, 6, 6, 3};
+    for (int i = 0; i < 4; ++i) d.n[i] = std::max((int)std::lround(nb[i] * (double)depth), 1);
+    d.hb = std::max(std::max(16, d.c[2] / 4), 64);
+    d.hc = std::max(d.c[2], std::min(nc, 100));
+    d.nc = nc;
+    return d;
+}
+
+static void c2f_specs(std::vector<ConvSpec> &v, const std::string &p, int c1, int c2, int n) {
+    const int c = c2 / 2;
+    v.push_back({p + ".cv1", 2 * c, c1, 1, 1, 1});
+    v.push_back({p + ".cv2", c2, (2 + n) * c, 1, 1, 1});
+    for (int i = 0; i < n; ++i) {
+        v.push_back({p + ".m." + std::to_string(i) + ".cv1", c, c, 3, 1, 1});
+        v.push_back({p + ".m." + std::to_string(i) + ".cv2", c, c, 3, 1, 1});
+    }
+}
+
+// Fused convs in ultralytics module order
+static std::vector<ConvSpec> conv_specs(const ModelDims &d) {
+    std::vector<ConvSpec> v;
+    const int *c = d.c;
+    v.push_back({"model.0", c[0], 3, 3, 2, 1});
+    v.push_back({"model.1", c[1], c[0], 3, 2, 1});
+    c2f_specs(v, "model.2", c[1], c[1], d.n[0]);
+    v.push_back({"model.3", c[2], c[1], 3, 2, 1});
+    c2f_specs(v, "model.4", c[2], c[2], d.n[1]);
+    v.push_back({"model.5", c[3], c[2], 3, 2, 1});
+    c2f_specs(v, "model.6", c[3], c[3], d.n[2]);
+    v.push_back({"model.7", c[4], c[3], 3, 2, 1});
+    c2f_specs(v, "model.8", c[4], c[4], d.n[3]);
+    v.push_back({"model.9.cv1", c[4] / 2, c[4], 1, 1, 1});
+    v.push_back({"model.9.cv2", c[4], c[4] * 2, 1, 1, 1});
+    c2f_specs(v, "model.12", c[4] + c[3], c[3], d.n[3]);
+    c2f_specs(v, "model.15", c[3] + c[2], c[2], d.n[3]);
+    v.push_back({"model.16", c[2], c[2], 3, 2, 1});
+    c2f_specs(v, "model.18", c[2] + c[3], c[3], d.n[3]);
+    v.push_back({"model.19", c[3], c[3], 3, 2, 1});
+    c2f_specs(v, "model.21", c[3] + c[4], c[4], d.n[3]);
+    const int ch[3] = {c[2], c[3], c[4]};
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "model.22.cv2." + std::to_string(i);
+        v.push_back({p + ".0", d.hb, ch[i], 3, 1, 1});
+        v.push_back({p + ".1", d.hb, d.hb, 3, 1, 1});
+        v.push_back({p + ".2", 64, d.hb, 1, 1, 0});
+    }
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "model.22.cv3." + std::to_string(i);
+        v.push_back({p + ".0", d.hc, ch[i], 3, 1, 1});
+        v.push_back({p + ".1", d.hc, d.hc, 3, 1, 1});
+        v.push_back({p + ".2", d.nc, d.hc, 1, 1, 0});
+    }
+    return v;
+}
+
+static int find_spec(const std::vector<ConvSpec> &v, const std::string &name) {
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].name == name) return (int)i;
+    return -1;
+}
+
+struct Buf {
+    size_t elems_per_image = 0; // h*w*C
+    int h = 0, w = 0, C = 0;
+    void *ptr = nullptr;
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_POOL };
+
+struct Op {
+    OpKind kind;
+    // conv
+    int in_buf = -1, in_coff = 0, cin = 0;
+    int out_buf = -1, out_coff = 0;
+    int out2_buf = -1, out2_coff = 0;
+    int res_buf = -1, res_coff = 0;
+    int cout = 0, cout_pad = 0, k = 1, stride = 1, act = 1;
+    int cfg = 0;
+    int K = 0, Kpad = 0;
+    int tile_w = 0;
+    void *w = nullptr; // packed device weights
+    float *bias = nullptr;
+    double macs_per_image = 0;
+};
+
+} // namespace
+
+struct wtk_yolo {
+    int device = 0;
+    int is_f16 = 1;
+    int esize = 2;
+    int S_h = 0, S_w = 0, max_batch = 0;
+    ModelDims dims;
+    std::vector<Buf> bufs;
+    std::vector<Op> ops;
+    std::vector<void *> dev_allocs;
+    int box_buf[3] = {-1, -1, -1}, cls_buf[3] = {-1, -1, -1};
+    int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
+    int cls_ld = 32;
+    double macs_per_frame = 0;
+    int anchors = 0;
+    // staging for the host entry points and for letterboxing
+    uint8_t *frames_dev = nullptr;
+    size_t frames_cap = 0;
+    uint8_t *lb_dev = nullptr;
+    size_t lb_cap = 0;
+    float *o_xywh = nullptr, *o_conf = nullptr;
+    int *o_anchor = nullptr;
+    // profiling
+    int profiling = 0;
+    hipEvent_t ev[16];
+    int ev_created = 0;
+    double prof_ms[4] = {0, 0, 0, 0};
+    long long prof_launches[4] = {0, 0, 0, 0};
+};
+
+extern "C" int wtk_yolo_conv_count(float width_mult, float depth_mult, int32_t max_channels, int32_t nc) {
+    if (nc < 1 || width_mult <= 0 || depth_mult <= 0 || max_channels < 8) return -1;
+    return (int)conv_specs(model_dims(width_mult, depth_mult, max_channels, nc)).size();
+}
+
+extern "C" int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t max_channels, int32_t nc, int32_t index, int32_t *cout,
+                                  int32_t *cin, int32_t *k, int32_t *stride, int32_t *act, char *name_out, size_t name_cap) {
+    if (nc < 1 || width_mult <= 0 || depth_mult <= 0 || max_channels < 8) return fail("wtk_yolo_conv_info: bad model scale");
+    const auto v = conv_specs(model_dims(width_mult, depth_mult, max_channels, nc));
+    if (index < 0 || index >= (int)v.size()) return fail("wtk_yolo_conv_info: index out of range");
+    const ConvSpec &s = v[index];
+    if (cout) *cout = s.cout;
+    if (cin) *cin = s.cin;
+    if (k) *k = s.k;
+    if (stride) *stride = s.stride;
+    if (act) *act = s.act;
+    if (name_out && name_cap) {
+        std::snprintf(name_out, name_cap, "%s", s.name.c_str());
+    }
+    return 0;
+}
+
+static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes));
+    h->dev_allocs.push_back(*p);
+    return 0;
+}
+
+static int pick_cfg(int cout) {
+    if (cout % 128 == 0) return CFG_128x128;
+    if (cout % 64 == 0) return CFG_256x64;
+    return CFG_256x32;
+}
+
+// pack [cout][k][k][cin] fp32 -> [cout_pad][Kpad] storage dtype (zero padded) on the device
+static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_parts, const std::vector<const float *> &b_parts,
+                     const std::vector<int> &couts) {
+    const int ce = h->is_f16 ? 8 : 4;
+    op.K = op.k * op.k * op.cin;
+    op.Kpad = (op.K + 8 * ce - 1) / (8 * ce) * (8 * ce);
+    const int bn = conv_cfg_bn(op.cfg);
+    op.cout_pad = (op.cout + bn - 1) / bn * bn;
+    std::vector<float> wf((size_t)op.cout_pad * op.Kpad, 0.f), bf(op.cout_pad, 0.f);
+    int row = 0;
+    for (size_t p = 0; p < w_parts.size(); ++p) {
+        for (int o = 0; o < couts[p]; ++o, ++row) {
+            std::memcpy(&wf[(size_t)row * op.Kpad], w_parts[p] + (size_t)o * op.K, sizeof(float) * op.K);
+            bf[row] = b_parts[p][o];
+        }
+    }
+    if (dev_alloc(h, (void **)&op.bias, bf.size() * sizeof(float))) return 1;
+    HIP_TRY(hipMemcpy(op.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (h->is_f16) {
+        std::vector<uint16_t> wh(wf.size());
+        for (size_t i = 0; i < wf.size(); ++i) wh[i] = f32_to_f16_bits(wf[i]);
+        if (dev_alloc(h, &op.w, wh.size() * 2)) return 1;
+        HIP_TRY(hipMemcpy(op.w, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        if (dev_alloc(h, &op.w, wf.size() * 4)) return 1;
+        HIP_TRY(hipMemcpy(op.w, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+namespace {
+struct Planner {
+    wtk_yolo *h;
+    const std::vector<ConvSpec> &specs;
+    const wtk_conv_blob *blobs;
+    bool failed = false;
+
+    int new_buf(int hh, int ww, int C) {
+        Buf b;
+        b.h = hh;
+        b.w = ww;
+        b.C = C;
+        b.elems_per_image = (size_t)hh * ww * C;
+        h->bufs.push_back(b);
+        return (int)h->bufs.size() - 1;
+    }
+    // generic conv op from one or more blobs (concatenated along cout)
+    void conv(const std::vector<std::string> &names, int in_buf, int in_coff, int out_buf, int out_coff, int out2_buf = -1,
+              int out2_coff = 0, int res_buf = -1, int res_coff = 0, int cout_store_pad = 0) {
+        if (failed) return;
+        Op op;
+        op.kind = OP_CONV;
+        std::vector<const float *> wp, bp;
+        std::vector<int> couts;
+        int cout = 0;
+        for (auto &nm : names) {
+            const int i = find_spec(specs, nm);
+            if (i < 0) {
+                failed = true;
+                fail("internal: unknown conv " + nm);
+                return;
+            }
+            const ConvSpec &s = specs[i];
+            op.cin = s.cin;
+            op.k = s.k;
+            op.stride = s.stride;
+            op.act = s.act;
+            wp.push_back(blobs[i].weight);
+            bp.push_back(blobs[i].bias);
+            couts.push_back(s.cout);
+            cout += s.cout;
+        }
+        op.cout = std::max(cout, cout_store_pad); // channels actually stored (>= real cout, zero rows beyond)
+        op.cfg = pick_cfg(op.cout);
+        op.in_buf = in_buf;
+        op.in_coff = in_coff;
+        op.out_buf = out_buf;
+        op.out_coff = out_coff;
+        op.out2_buf = out2_buf;
+        op.out2_coff = out2_coff;
+        op.res_buf = res_buf;
+        op.res_coff = res_coff;
+        const Buf &ib = h->bufs[in_buf];
+        const Buf &ob = h->bufs[out_buf];
+        const int pad = op.k / 2;
+        const int ho = (ib.h + 2 * pad - op.k) / op.stride + 1, wo = (ib.w + 2 * pad - op.k) / op.stride + 1;
+        if (ho != ob.h || wo != ob.w || in_coff + op.cin > ib.C || out_coff + op.cout > ob.C) {
+            failed = true;
+            fail("internal: shape mismatch planning conv " + names[0]);
+            return;
+        }
+        // 2-D pixel tiles where the map is large enough that a linear tile would be a thin strip
+        const int bm = conv_cfg_bm(op.cfg);
+        op.tile_w = 0;
+        if (op.k == 3 && wo >= 64 && wo % 16 == 0 && ho % (bm / 16) == 0) op.tile_w = 16;
+        op.macs_per_image = (double)ho * wo * cout * op.k * op.k * op.cin;
+        if (pack_conv(h, op, wp, bp, couts)) {
+            failed = true;
+            return;
+        }
+        h->ops.push_back(op);
+    }
+    // C2f block: input view -> output view.  Returns nothing; allocates its concat + temp buffers.
+    void c2f(const std::string &p, int in_buf, int in_coff, int c2, int n, bool shortcut, int out_buf, int out_coff, int out2_buf = -1,
+             int out2_coff = 0) {
+        if (failed) return;
+        const Buf ib = h->bufs[in_buf];
+        const int c = c2 / 2;
+        const int cat = new_buf(ib.h, ib.w, (2 + n) * c);
+        const int tmp = new_buf(ib.h, ib.w, c);
+        conv({p + ".cv1"}, in_buf, in_coff, cat, 0);
+        for (int i = 0; i < n; ++i) {
+            const std::string m = p + ".m." + std::to_string(i);
+            conv({m + ".cv1"}, cat, (1 + i) * c, tmp, 0);
+            conv({m + ".cv2"}, tmp, 0, cat, (2 + i) * c, -1, 0, shortcut ? cat : -1, (1 + i) * c);
+        }
+        conv({p + ".cv2"}, cat, 0, out_buf, out_coff, out2_buf, out2_coff);
+    }
+};
+} // namespace
+
+extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
+    if (!h) return;
+    for (void *p : h->dev_allocs) (void)hipFree(p);
+    (void)hipFree(h->frames_dev);
+    (void)hipFree(h->lb_dev);
+    for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
+    delete h;
+}
+
+extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
+    if (!out || !d || !d->convs) return fail("wtk_yolo_create: null argument");
+    if (d->dtype != WTK_F32 && d->dtype != WTK_F16) return fail("wtk_yolo_create: dtype must be WTK_F32 or WTK_F16");
+    if (d->imgsz_h <= 0 || d->imgsz_w <= 0 || d->imgsz_h % 32 || d->imgsz_w % 32) return fail("wtk_yolo_create: imgsz must be a positive multiple of 32");
+    if (d->max_batch <= 0) return fail("wtk_yolo_create: max_batch must be positive");
+    if (d->nc < 1 || d->nc > 32) return fail("wtk_yolo_create: nc must be in [1, 32]");
+    if (wtk_device_count() <= d->device) return fail("wtk_yolo_create: no such HIP device (is a GPU visible?)");
+    const ModelDims dims = model_dims(d->width_mult, d->depth_mult, d->max_channels, d->nc);
+    const std::vector<ConvSpec> specs = conv_specs(dims);
+    if ((int)specs.size() != d->n_convs) return fail("wtk_yolo_create: n_convs does not match the model scale");
+    for (size_t i = 0; i < specs.size(); ++i) {
+        const wtk_conv_blob &b = d->convs[i];
+        const ConvSpec &s = specs[i];
+        if (b.cout != s.cout || b.cin != s.cin || b.k != s.k || b.stride != s.stride || b.act != s.act || !b.weight || !b.bias)
+            return fail("wtk_yolo_create: conv blob " + std::to_string(i) + " (" + s.name + ") does not match the expected shape");
+    }
+    for (int i = 0; i < 5; ++i)
+        if (dims.c[i] % 16 != 0) return fail("wtk_yolo_create: channel widths must be multiples of 16 for this build");
+    if (dims.hb % 16 || dims.hc % 16) return fail("wtk_yolo_create: head widths must be multiples of 16");
+    HIP_TRY(hipSetDevice(d->device));
+    if (ensure_attributes()) return 1;
+
+    wtk_yolo *h = new wtk_yolo();
+    h->device = d->device;
+    h->is_f16 = d->dtype == WTK_F16;
+    h->esize = h->is_f16 ? 2 : 4;
+    h->S_h = d->imgsz_h;
+    h->S_w = d->imgsz_w;
+    h->max_batch = d->max_batch;
+    h->dims = dims;
+
+    Planner P{h, specs, d->convs};
+    const int *c = dims.c;
+    const int H = h->S_h, W = h->S_w;
+    auto hw = [&](int s, int &hh, int &ww) { hh = H / s, ww = W / s; };
+    int h2, w2, h4, w4, h8, w8, h16, w16, h32, w32;
+    hw(2, h2, w2), hw(4, h4, w4), hw(8, h8, w8), hw(16, h16, w16), hw(32, h32, w32);
+
+    // ---- buffers that hold more than one logical tensor (concat-free FPN/PAN)
+    const int t0 = P.new_buf(h2, w2, c[0]);
+    const int t1 = P.new_buf(h4, w4, c[1]);
+    const int t2 = P.new_buf(h4, w4, c[1]);
+    const int t3 = P.new_buf(h8, w8, c[2]);
+    const int cat14 = P.new_buf(h8, w8, c[3] + c[2]);   // [up(t12) | t4]
+    const int t5 = P.new_buf(h16, w16, c[3]);
+    const int cat11 = P.new_buf(h16, w16, c[4] + c[3]); // [up(t9) | t6]
+    const int t7 = P.new_buf(h32, w32, c[4]);
+    const int t8 = P.new_buf(h32, w32, c[4]);
+    const int sppcat = P.new_buf(h32, w32, 2 * c[4]);   // [x | y1 | y2 | y3], each c4/2
+    const int cat20 = P.new_buf(h32, w32, c[3] + c[4]); // [t19 | t9]
+    const int cat17 = P.new_buf(h16, w16, c[2] + c[3]); // [t16 | t12]
+    const int t15 = P.new_buf(h8, w8, c[2]);
+    const int t18 = P.new_buf(h16, w16, c[3]);
+    const int t21 = P.new_buf(h32, w32, c[4]);
+
+    // ---- backbone
+    {
+        Op op;
+        op.kind = OP_STEM;
+        op.out_buf = t0;
+        op.cout = c[0];
+        op.macs_per_image = (double)h2 * w2 * c[0] * 27;
+        const int i0 = find_spec(specs, "model.0");
+        float *wdev, *bdev;
+        if (dev_alloc(h, (void **)&wdev, sizeof(float) * c[0] * 27) || dev_alloc(h, (void **)&bdev, sizeof(float) * c[0])) {
+            wtk_yolo_destroy(h);
+            return 1;
+        }
+        if (hipMemcpy(wdev, d->convs[i0].weight, sizeof(float) * c[0] * 27, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(bdev, d->convs[i0].bias, sizeof(float) * c[0], hipMemcpyHostToDevice) != hipSuccess) {
+            wtk_yolo_destroy(h);
+            return fail("wtk_yolo_create: stem weight upload failed");
+        }
+        op.w = wdev;
+        op.bias = bdev;
+        h->ops.push_back(op);
+    }
+    P.conv({"model.1"}, t0, 0, t1, 0);
+    P.c2f("model.2", t1, 0, c[1], dims.n[0], true, t2, 0);
+    P.conv({"model.3"}, t2, 0, t3, 0);
+    P.c2f("model.4", t3, 0, c[2], dims.n[1], true, cat14, c[3]);
+    P.conv({"model.5"}, cat14, c[3], t5, 0);
+    P.c2f("model.6", t5, 0, c[3], dims.n[2], true, cat11, c[4]);
+    P.conv({"model.7"}, cat11, c[4], t7, 0);
+    P.c2f("model.8", t7, 0, c[4], dims.n[3], true, t8, 0);
+    // SPPF
+    P.conv({"model.9.cv1"}, t8, 0, sppcat, 0);
+    if (!P.failed) {
+        Op op;
+        op.kind = OP_POOL;
+        op.in_buf = sppcat;
+        op.cin = c[4] / 2;
+        h->ops.push_back(op);
+    }
+    P.conv({"model.9.cv2"}, sppcat, 0, cat20, c[3], cat11, 0); // t9 -> cat20 slice, upsampled copy -> cat11
+    // ---- neck
+    P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], cat14, 0); // t12 -> cat17 slice, up -> cat14
+    P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0);
+    P.conv({"model.16"}, t15, 0, cat17, 0);
+    P.c2f("model.18", cat17, 0, c[3], dims.n[3], false, t18, 0);
+    P.conv({"model.19"}, t18, 0, cat20, 0);
+    P.c2f("model.21", cat20, 0, c[4], dims.n[3], false, t21, 0);
+    // ---- Detect: both towers' first 3x3 share one conv (weights concatenated along cout)
+    const int feat[3] = {t15, t18, t21};
+    const int fh[3] = {h8, h16, h32}, fw[3] = {w8, w16, w32};
+    h->cls_ld = 32;
+    for (int i = 0; i < 3 && !P.failed; ++i) {
+        const std::string b = "model.22.cv2." + std::to_string(i), cl = "model.22.cv3." + std::to_string(i);
+        const int d1 = P.new_buf(fh[i], fw[i], dims.hb + dims.hc);
+        const int d2b = P.new_buf(fh[i], fw[i], dims.hb);
+        const int d2c = P.new_buf(fh[i], fw[i], dims.hc);
+        h->box_buf[i] = P.new_buf(fh[i], fw[i], 64);
+        h->cls_buf[i] = P.new_buf(fh[i], fw[i], h->cls_ld);
+        h->lh[i] = fh[i];
+        h->lw[i] = fw[i];
+        P.conv({b + ".0", cl + ".0"}, feat[i], 0, d1, 0);
+        P.conv({b + ".1"}, d1, 0, d2b, 0);
+        P.conv({cl + ".1"}, d1, dims.hb, d2c, 0);
+        P.conv({b + ".2"}, d2b, 0, h->box_buf[i], 0);
+        P.conv({cl + ".2"}, d2c, 0, h->cls_buf[i], 0, -1, 0, -1, 0, h->cls_ld);
+    }
+    if (P.failed) {
+        wtk_yolo_destroy(h);
+        return 1;
+    }
+    h->anchors = h8 * w8 + h16 * w16 + h32 * w32;
+    for (const Op &op : h->ops) h->macs_per_frame += op.macs_per_image;
+
+    // ---- activation workspace: every tensor gets its own allocation (288 GB HBM: no liveness reuse needed)
+    for (Buf &b : h->bufs) {
+        if (dev_alloc(h, &b.ptr, b.elems_per_image * (size_t)h->max_batch * h->esize)) {
+            wtk_yolo_destroy(h);
+            return 1;
+        }
+    }
+    if (dev_alloc(h, (void **)&h->o_xywh, sizeof(float) * 4 * h->max_batch) || dev_alloc(h, (void **)&h->o_conf, sizeof(float) * h->max_batch) ||
+        dev_alloc(h, (void **)&h->o_anchor, sizeof(int) * h->max_batch)) {
+        wtk_yolo_destroy(h);
+        return 1;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors) {
+    if (!h) return fail("wtk_yolo_workload: null handle");
+    if (macs_per_frame) *macs_per_frame = h->macs_per_frame;
+    if (anchors) *anchors = h->anchors;
+    return 0;
+}
+
+extern "C" int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled) {
+    if (!h) return fail("wtk_yolo_set_profiling: null handle");
+    if (enabled && !h->ev_created) {
+        for (int i = 0; i < 16; ++i) {
+            HIP_TRY(hipEventCreate(&h->ev[i]));
+            h->ev_created = i + 1;
+        }
+    }
+    h->profiling = enabled ? 1 : 0;
+    for (int i = 0; i < 4; ++i) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
+    return 0;
+}
+
+extern "C" int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches) {
+    if (!h || kernel_class < 0 || kernel_class > 3) return fail("wtk_yolo_get_profile: bad argument");
+    if (total_ms) *total_ms = h->prof_ms[kernel_class];
+    if (launches) *launches = h->prof_launches[kernel_class];
+    return 0;
+}
+
+// ultralytics LetterBox geometry (auto=False: pad to exactly imgsz) + scale_boxes inverse
+static void letterbox_geom(int H, int W, int Sh, int Sw, int &new_h, int &new_w, int &top, int &left, float &gain, float &pad_x, float &pad_y) {
+    const double r = std::min((double)Sh / H, (double)Sw / W);
+    new_w = (int)std::nearbyint(W * r);
+    new_h = (int)std::nearbyint(H * r);
+    const double dw = (Sw - new_w) / 2.0, dh = (Sh - new_h) / 2.0;
+    top = (int)std::nearbyint(dh - 0.1);
+    left = (int)std::nearbyint(dw - 0.1);
+    // scale_boxes recomputes gain/pad from the two shapes
+    gain = (float)std::min((double)Sh / H, (double)Sw / W);
+    pad_x = (float)std::nearbyint((Sw - W * (double)gain) / 2.0 - 0.1);
+    pad_y = (float)std::nearbyint((Sh - H * (double)gain) / 2.0 - 0.1);
+}
+
+static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xywh, float *out_conf, int *out_anchor, hipStream_t st) {
+    HeadArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 3; ++i) {
+        a.box[i] = h->bufs[h->box_buf[i]].ptr;
+        a.cls[i] = h->bufs[h->cls_buf[i]].ptr;
+        a.lh[i] = h->lh[i];
+        a.lw[i] = h->lw[i];
+    }
+    a.cls_ld = h->cls_ld;
+    a.nc = h->dims.nc;
+    a.N = B;
+    a.conf = conf;
+    int nh, nw, top, left;
+    letterbox_geom(H, W, h->S_h, h->S_w, nh, nw, top, left, a.gain, a.pad_x, a.pad_y);
+    a.img_w = (float)W;
+    a.img_h = (float)H;
+    a.out_xywh = out_xywh;
+    a.out_conf = out_conf;
+    a.out_anchor = out_anchor;
+    HIP_TRY(launch_head(a, h->is_f16, st));
+    return 0;
+}
+
+extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
+                                int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
+    (void)iou; // with max_det == 1 the IoU threshold cannot change the survivor
+    if (!h || !frames_dev || !out_xywh) return fail("wtk_yolo_predict: null argument");
+    if (B <= 0) return fail("wtk_yolo_predict: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
+    if (B > h->max_batch) return fail("wtk_yolo_predict: batch exceeds max_batch");
+    if (C != 1 && C != 3) return fail("wtk_yolo_predict: frames must have 1 (gray) or 3 (BGR) channels");
+    if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
+    if (H <= 0 || W <= 0) return fail("wtk_yolo_predict: bad frame size");
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *net_in = frames_dev;
+    if (H != h->S_h || W != h->S_w) {
+        // letterbox into the handle's staging image
+        const size_t need = (size_t)B * h->S_h * h->S_w * C;
+        if (need > h->lb_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipFree(h->lb_dev);
+            h->lb_dev = nullptr;
+            h->lb_cap = 0;
+            HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
+            h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
+        }
+        LetterboxArgs la;
+        la.src = frames_dev;
+        la.dst = h->lb_dev;
+        la.N = B, la.H = H, la.W = W, la.C = C;
+        la.Sh = h->S_h, la.Sw = h->S_w;
+        float g, px, py;
+        letterbox_geom(H, W, h->S_h, h->S_w, la.new_h, la.new_w, la.top, la.left, g, px, py);
+        HIP_TRY(launch_letterbox(la, st));
+        net_in = h->lb_dev;
+    }
+
+    int cur_class = -1, nev = 0;
+    int ev_class[16];
+    auto mark = [&](int cls) -> int {
+        if (!h->profiling || cls == cur_class) return 0;
+        if (nev >= 16) return 0;
+        HIP_TRY(hipEventRecord(h->ev[nev], st));
+        ev_class[nev] = cls;
+        ++nev;
+        cur_class = cls;
+        return 0;
+    };
+    long long launches[4] = {0, 0, 0, 0};
+
+    for (const Op &op : h->ops) {
+        if (op.kind == OP_STEM) {
+            if (mark(0)) return 1;
+            StemArgs a;
+            a.frames = net_in;
+            a.N = B, a.H = h->S_h, a.W = h->S_w, a.C = C;
+            a.w = (const float *)op.w;
+            a.bias = op.bias;
+            a.out = h->bufs[op.out_buf].ptr;
+            a.Cout = op.cout;
+            a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
+            HIP_TRY(launch_stem(a, h->is_f16, st));
+            ++launches[0];
+        } else if (op.kind == OP_POOL) {
+            if (mark(2)) return 1;
+            const Buf &b = h->bufs[op.in_buf];
+            PoolArgs a;
+            a.buf = b.ptr;
+            a.N = B, a.H = b.h, a.W = b.w, a.c = op.cin;
+            HIP_TRY(launch_sppf_pool(a, h->is_f16, st));
+            ++launches[2];
+        } else {
+            if (mark(1)) return 1;
+            const Buf &ib = h->bufs[op.in_buf];
+            const Buf &ob = h->bufs[op.out_buf];
+            ConvArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.in = ib.ptr;
+            a.in_ld = ib.C;
+            a.in_coff = op.in_coff;
+            a.N = B, a.H = ib.h, a.W = ib.w, a.Cin = op.cin;
+            a.Ho = ob.h, a.Wo = ob.w, a.Cout = op.cout;
+            a.CoutPad = op.cout_pad;
+            a.KH = a.KW = op.k;
+            a.stride = op.stride;
+            a.pad = op.k / 2;
+            a.w = op.w;
+            a.bias = op.bias;
+            a.out = ob.ptr;
+            a.out_ld = ob.C;
+            a.out_coff = op.out_coff;
+            if (op.out2_buf >= 0) {
+                a.out2 = h->bufs[op.out2_buf].ptr;
+                a.out2_ld = h->bufs[op.out2_buf].C;
+                a.out2_coff = op.out2_coff;
+            }
+            if (op.res_buf >= 0) {
+                a.res = h->bufs[op.res_buf].ptr;
+                a.res_ld = h->bufs[op.res_buf].C;
+                a.res_coff = op.res_coff;
+            }
+            a.act = op.act;
+            a.K = op.K;
+            a.Kpad = op.Kpad;
+            a.M = (long long)B * ob.h * ob.w;
+            a.tile_w = op.tile_w;
+            if (op.tile_w) {
+                const int th = conv_cfg_bm(op.cfg) / op.tile_w;
+                a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;
+                a.tiles_y = (ob.h + th - 1) / th;
+            }
+            HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
+            ++launches[1];
+        }
+    }
+    if (mark(3)) return 1;
+    if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st)) return 1;
+    ++launches[3];
+    if (h->profiling) {
+        if (nev < 16) {
+            HIP_TRY(hipEventRecord(h->ev[nev], st));
+            ev_class[nev] = -1;
+            ++nev;
+        }
+        HIP_TRY(hipEventSynchronize(h->ev[nev - 1]));
+        for (int i = 0; i + 1 < nev; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+            h->prof_ms[ev_class[i]] += ms;
+        }
+        for (int i = 0; i < 4; ++i) h->prof_launches[i] += launches[i];
+    }
+    return 0;
+}
+
+extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, int32_t B, int32_t H, int32_t W, int32_t C, float conf,
+                                     float iou, int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor) {
+    if (!h || !frames_host || !out_xywh) return fail("wtk_yolo_predict_host: null argument");
+    if (B <= 0) return fail("wtk_yolo_predict_host: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
+    if (B > h->max_batch) return fail("wtk_yolo_predict_host: batch exceeds max_batch");
+    if (H <= 0 || W <= 0 || (C != 1 && C != 3)) return fail("wtk_yolo_predict_host: bad frame shape");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t need = (size_t)B * H * W * C;
+    if (need > h->frames_cap) {
+        (void)hipFree(h->frames_dev);
+        h->frames_dev = nullptr;
+        h->frames_cap = 0;
+        const size_t cap = std::max(need, (size_t)h->max_batch * H * W * C);
+        HIP_TRY(hipMalloc(&h->frames_dev, cap));
+        h->frames_cap = cap;
+    }
+    HIP_TRY(hipMemcpy(h->frames_dev, frames_host, need, hipMemcpyHostToDevice));
+    if (wtk_yolo_predict(h, h->frames_dev, B, H, W, C, conf, iou, max_det, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;
+    HIP_TRY(hipMemcpy(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost));
+    if (out_conf) HIP_TRY(hipMemcpy(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost));
+    if (out_anchor) HIP_TRY(hipMemcpy(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static void to_f32(const void *src, float *dst, size_t n, int is_f16) {
+    if (!is_f16) {
+        std::memcpy(dst, src, n * 4);
+        return;
+    }
+    const _Float16 *s = reinterpret_cast<const _Float16 *>(src);
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)s[i];
+}
+
+extern "C" int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float *box_host, float *cls_host) {
+    if (!h || level < 0 || level > 2 || B <= 0 || B > h->max_batch) return fail("wtk_yolo_debug_head: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t A = (size_t)h->lh[level] * h->lw[level];
+    std::vector<char> tmp;
+    if (box_host) {
+        const size_t n = (size_t)B * A * 64;
+        tmp.resize(n * h->esize);
+        HIP_TRY(hipMemcpy(tmp.data(), h->bufs[h->box_buf[level]].ptr, tmp.size(), hipMemcpyDeviceToHost));
+        to_f32(tmp.data(), box_host, n, h->is_f16);
+    }
+    if (cls_host) {
+        const size_t n = (size_t)B * A * h->cls_ld;
+        tmp.resize(n * h->esize);
+        HIP_TRY(hipMemcpy(tmp.data(), h->bufs[h->cls_buf[level]].ptr, tmp.size(), hipMemcpyDeviceToHost));
+        std::vector<float> full(n);
+        to_f32(tmp.data(), full.data(), n, h->is_f16);
+        for (size_t i = 0; i < (size_t)B * A; ++i)
+            for (int k = 0; k < h->dims.nc; ++k) cls_host[i * h->dims.nc + k] = full[i * h->cls_ld + k];
+    }
+    return 0;
+}
+
+extern "C" int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf,
+                                    float *out_xywh, float *out_conf, int32_t *out_anchor) {
+    if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch) return fail("wtk_yolo_decode_host: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    // scatter the concatenated [B][A][.] logits into the per-level head buffers (storage dtype)
+    const int A = h->anchors;
+    size_t a0 = 0;
+    for (int l = 0; l < 3; ++l) {
+        const size_t Al = (size_t)h->lh[l] * h->lw[l];
+        std::vector<float> bx((size_t)B * Al * 64), cl((size_t)B * Al * h->cls_ld, 0.f);
+        for (int n = 0; n < B; ++n)
+            for (size_t j = 0; j < Al; ++j) {
+                std::memcpy(&bx[((size_t)n * Al + j) * 64], &box_host[((size_t)n * A + a0 + j) * 64], 64 * sizeof(float));
+                for (int k = 0; k < h->dims.nc; ++k) cl[((size_t)n * Al + j) * h->cls_ld + k] = cls_host[((size_t)n * A + a0 + j) * h->dims.nc + k];
+            }
+        if (h->is_f16) {
+            std::vector<uint16_t> hb(bx.size()), hc(cl.size());
+            for (size_t i = 0; i < bx.size(); ++i) hb[i] = f32_to_f16_bits(bx[i]);
+            for (size_t i = 0; i < cl.size(); ++i) hc[i] = f32_to_f16_bits(cl[i]);
+            HIP_TRY(hipMemcpy(h->bufs[h->box_buf[l]].ptr, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->bufs[h->cls_buf[l]].ptr, hc.data(), hc.size() * 2, hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy(h->bufs[h->box_buf[l]].ptr, bx.data(), bx.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->bufs[h->cls_buf[l]].ptr, cl.data(), cl.size() * 4, hipMemcpyHostToDevice));
+        }
+        a0 += Al;
+    }
+    if (run_head(h, B, H, W, conf, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;
+    HIP_TRY(hipMemcpy(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost));
+    if (out_conf) HIP_TRY(hipMemcpy(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost));
+    if (out_anchor) HIP_TRY(hipMemcpy(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,137 @@
+// Internal declarations shared by the HIP translation units of libwtk_hip.so.
+// Everything here is gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, MFMA, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wtk {
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (conv_igemm.hip).  Activations are NHWC; a tensor argument is a
+// *channel-slice view* (base pointer, pixel stride `ld` in elements, first channel `coff`), so
+// C2f / SPPF / FPN concatenations are never materialised: producers write into the slice of
+// the consumer's buffer.
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const void *in;
+    int in_ld, in_coff;
+    int N, H, W, Cin;
+    int Ho, Wo, Cout;
+    int CoutPad; // Cout rounded up to the tile's BN; rows [Cout, CoutPad) of w/bias are zero
+    int KH, KW, stride, pad;
+    const void *w;     // packed weights [CoutPad][Kpad], K = (kh, kw, cin), cin fastest
+    const float *bias; // [CoutPad]
+    void *out;
+    int out_ld, out_coff;
+    void *out2; // optional second destination: 2x nearest-neighbour upsampled copy [N,2Ho,2Wo]
+    int out2_ld, out2_coff;
+    const void *res; // optional residual added after the activation (Bottleneck shortcut)
+    int res_ld, res_coff;
+    int act; // 1: SiLU
+    int K, Kpad;
+    int tile_w; // 0: linear pixel order over N*Ho*Wo; >0: 2-D pixel tiles tile_w x (BM/tile_w)
+    int tiles_x, tiles_y;
+    long long M; // N*Ho*Wo
+};
+
+// Tile configurations (block = 256 threads = 4 waves)
+enum ConvCfg { CFG_128x128 = 0, CFG_256x64 = 1, CFG_256x32 = 2 };
+int conv_cfg_bm(int cfg);
+int conv_cfg_bn(int cfg);
+// is_f16: 1 -> _Float16 storage + v_mfma_f32_16x16x32_f16; 0 -> fp32 + v_mfma_f32_16x16x4_f32
+hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t stream);
+hipError_t conv_init_attributes();
+
+// ---------------------------------------------------------------------------------------------
+// Stem: uint8 frame -> (BGR->RGB, /255) -> 3x3 stride-2 conv (Cin=3) + bias + SiLU -> NHWC.
+// Fuses ultralytics' preprocess with model.0 so the fp tensor [B,3,S,S] never exists.
+// ---------------------------------------------------------------------------------------------
+struct StemArgs {
+    const uint8_t *frames; // [N][H][W][C], C = 1 or 3 (BGR)
+    int N, H, W, C;
+    const float *w; // [Cout][3][3][3] fp32, O-H-W-I with I in RGB order
+    const float *bias;
+    void *out; // [N][H/2][W/2][Cout]
+    int Cout;
+    int Ho, Wo;
+};
+hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream);
+
+// Letterbox (ultralytics LetterBox, cv2.INTER_LINEAR fixed-point bilinear + pad 114) of uint8
+// frames [N][H][W][C] into [N][S_h][S_w][C].
+struct LetterboxArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int N, H, W, C;
+    int Sh, Sw;       // destination size
+    int new_h, new_w; // resized (unpadded) size
+    int top, left;    // padding offsets
+};
+hipError_t launch_letterbox(const LetterboxArgs &a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2) on a
+// channel slice of the SPPF concat buffer; x at channels [0,c), y_k at [k*c,(k+1)*c).
+// ---------------------------------------------------------------------------------------------
+struct PoolArgs {
+    void *buf; // [N][H][W][4c]
+    int N, H, W, c;
+};
+hipError_t launch_sppf_pool(const PoolArgs &a, int is_f16, hipStream_t stream);
+hipError_t pool_init_attributes();
+
+// ---------------------------------------------------------------------------------------------
+// Head: DFL decode + thresholded arg-max selection (max_det = 1) + scale_boxes + xyxy->xywh.
+// ---------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const void *box[3]; // per level [N][h*w][64] DFL logits (storage dtype)
+    const void *cls[3]; // per level [N][h*w][cls_ld] class logits (storage dtype)
+    int cls_ld;
+    int nc;
+    int lh[3], lw[3]; // level map sizes
+    int N;
+    float conf;
+    // inverse letterbox (ultralytics scale_boxes): x = (x - pad_x) / gain, clipped to [0, W0]
+    float gain, pad_x, pad_y;
+    float img_w, img_h;
+    float *out_xywh; // [N][4]
+    float *out_conf; // [N] or null
+    int *out_anchor; // [N] or null
+};
+hipError_t launch_head(const HeadArgs &a, int is_f16, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// ResMLP (mlp.hip)
+// ---------------------------------------------------------------------------------------------
+struct MlpLayerDev {
+    int in_dim, out_dim;
+    int in_pad;  // in_dim rounded up to 4
+    int out_pad; // out_dim rounded up to 16
+    int relu;
+    int w_off; // float offset of W[out_pad][in_pad] in the parameter blob
+    int b_off; // float offset of b[out_pad]
+    int pad_;
+};
+constexpr int kMlpMaxLayers = 64;
+constexpr int kMlpMaxDim = 128; // widest activation the kernel supports
+constexpr int kMlpMaxInputFrames = 16;
+struct MlpArgs {
+    const float *params;
+    const MlpLayerDev *layers; // device array
+    int n_layers, n_blocks, layers_per_block;
+    int in_dim, out_dim;
+    // direct mode
+    const float *x; // [B][in_dim]
+    // gather mode (x == nullptr)
+    const float *track; // [n_frames][4]
+    int n_frames;
+    const int *anchor_frames; // [B]
+    int input_frames[kMlpMaxInputFrames];
+    int n_in;
+    int *valid; // [B]
+    float *y;   // [B][out_dim]
+    int B;
+};
+hipError_t launch_mlp(const MlpArgs &a, hipStream_t stream);
+
+} // namespace wtk

@@ -1,0 +1,290 @@
+"""ctypes binding of libwtk_hip.so — the C ABI declared in include/wtk_hip.h.
+
+There is NO CPU fallback: if the shared library is missing or a GPU is not visible the calls
+raise.  (The oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwtk_hip.so")
+_lib: Optional[C.CDLL] = None
+
+WTK_F32 = 0
+WTK_F16 = 1
+DTYPES = {"fp32": WTK_F32, "f32": WTK_F32, "float32": WTK_F32, "fp16": WTK_F16, "f16": WTK_F16, "float16": WTK_F16}
+
+
+class WtkError(RuntimeError):
+    pass
+
+
+class _MlpLayer(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("relu", C.c_int32), ("reserved", C.c_int32),
+                ("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float))]
+
+
+class _MlpDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_layers", C.c_int32), ("n_blocks", C.c_int32), ("layers_per_block", C.c_int32),
+                ("layers", C.POINTER(_MlpLayer))]
+
+
+class _ConvBlob(C.Structure):
+    _fields_ = [("cout", C.c_int32), ("cin", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
+                ("reserved", C.c_int32), ("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float))]
+
+
+class _YoloDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("imgsz_h", C.c_int32), ("imgsz_w", C.c_int32),
+                ("max_batch", C.c_int32), ("nc", C.c_int32), ("width_mult", C.c_float), ("depth_mult", C.c_float),
+                ("max_channels", C.c_int32), ("n_convs", C.c_int32), ("convs", C.POINTER(_ConvBlob))]
+
+
+# every symbol include/wtk_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "wtk_last_error", "wtk_abi_version", "wtk_device_count",
+    "wtk_mlp_create", "wtk_mlp_destroy", "wtk_mlp_forward", "wtk_mlp_forward_host", "wtk_mlp_predict_track",
+    "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
+    "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
+    "wtk_yolo_set_profiling", "wtk_yolo_get_profile",
+]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libwtk_hip.so (built in-tree by `python -m wtracker_amd._build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise WtkError(f"{_LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                       "there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.wtk_last_error.restype = C.c_char_p
+    lib.wtk_abi_version.restype = C.c_int
+    lib.wtk_device_count.restype = C.c_int
+    lib.wtk_mlp_create.argtypes = [C.POINTER(vp), C.POINTER(_MlpDesc)]
+    lib.wtk_mlp_destroy.argtypes = [vp]
+    lib.wtk_mlp_destroy.restype = None
+    lib.wtk_mlp_forward.argtypes = [vp, vp, i32, vp, vp]
+    lib.wtk_mlp_forward_host.argtypes = [vp, vp, i32, vp]
+    lib.wtk_mlp_predict_track.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp, vp]
+    lib.wtk_yolo_conv_count.argtypes = [f32, f32, i32, i32]
+    lib.wtk_yolo_conv_info.argtypes = [f32, f32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                                       C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+    lib.wtk_yolo_create.argtypes = [C.POINTER(vp), C.POINTER(_YoloDesc)]
+    lib.wtk_yolo_destroy.argtypes = [vp]
+    lib.wtk_yolo_destroy.restype = None
+    lib.wtk_yolo_predict.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
+    lib.wtk_yolo_predict_host.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp]
+    lib.wtk_yolo_debug_head.argtypes = [vp, i32, i32, vp, vp]
+    lib.wtk_yolo_decode_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
+    lib.wtk_yolo_workload.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.wtk_yolo_set_profiling.argtypes = [vp, i32]
+    lib.wtk_yolo_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise WtkError(f"{what}: {load().wtk_last_error().decode(errors='replace')}")
+
+
+def device_count() -> int:
+    return int(load().wtk_device_count())
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ptr(x) -> C.c_void_p:
+    """Device pointer from a torch tensor / int, host pointer from a numpy array; None -> NULL."""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"cannot take a pointer of {type(x)}")
+
+
+# -------------------------------------------------------------------------------------------------
+class HipMLP:
+    """Device ResMLP (wtk_mlp).  `layers` = list of (W[out,in] fp32, b[out] fp32, relu: bool), BN folded,
+    in the order input, block0.l0.., ..., output."""
+
+    def __init__(self, layers: Sequence[tuple], n_blocks: int, layers_per_block: int, device: int = 0):
+        lib = load()
+        self._keep = []
+        arr = (_MlpLayer * len(layers))()
+        for i, (w, b, relu) in enumerate(layers):
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            assert w.ndim == 2 and b.shape == (w.shape[0],)
+            self._keep += [w, b]
+            arr[i] = _MlpLayer(w.shape[1], w.shape[0], int(bool(relu)), 0, _fptr(w), _fptr(b))
+        desc = _MlpDesc(device, len(layers), n_blocks, layers_per_block, arr)
+        self._h = C.c_void_p()
+        _check(lib.wtk_mlp_create(C.byref(self._h), C.byref(desc)), "wtk_mlp_create")
+        self.in_dim = int(layers[0][0].shape[1])
+        self.out_dim = int(layers[-1][0].shape[0])
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().wtk_mlp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def forward_host(self, x: np.ndarray) -> np.ndarray:
+        """x: [B, in_dim] float32 (host) -> [B, out_dim] float32 (host)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[1] == self.in_dim
+        y = np.empty((x.shape[0], self.out_dim), dtype=np.float32)
+        if x.shape[0] == 0:
+            return y
+        _check(load().wtk_mlp_forward_host(self._h, _ptr(x), x.shape[0], _ptr(y)), "wtk_mlp_forward_host")
+        return y
+
+    def forward(self, x_dev, y_dev, batch: int, stream: int = 0):
+        """Device tensors (torch) / raw device pointers; asynchronous on `stream` (hipStream_t as int)."""
+        _check(load().wtk_mlp_forward(self._h, _ptr(x_dev), batch, _ptr(y_dev), C.c_void_p(stream)), "wtk_mlp_forward")
+
+    def predict_track(self, track_dev, n_frames: int, anchor_frames_dev, n_samples: int, input_frames: Sequence[int],
+                      pred_dev, valid_dev=None, stream: int = 0):
+        inf = np.ascontiguousarray(input_frames, dtype=np.int32)
+        _check(load().wtk_mlp_predict_track(self._h, _ptr(track_dev), n_frames, _ptr(anchor_frames_dev), n_samples,
+                                            _ptr(inf), len(inf), _ptr(pred_dev), _ptr(valid_dev), C.c_void_p(stream)),
+               "wtk_mlp_predict_track")
+
+
+# -------------------------------------------------------------------------------------------------
+def yolo_conv_table(width: float, depth: float, max_channels: int, nc: int) -> list[dict]:
+    """The library's own conv list (name, cout, cin, k, stride, act) — needs no GPU."""
+    lib = load()
+    n = lib.wtk_yolo_conv_count(width, depth, max_channels, nc)
+    if n <= 0:
+        raise WtkError("wtk_yolo_conv_count: bad model scale")
+    out = []
+    for i in range(n):
+        co, ci, k, s, a = (C.c_int32() for _ in range(5))
+        name = C.create_string_buffer(96)
+        _check(lib.wtk_yolo_conv_info(width, depth, max_channels, nc, i, C.byref(co), C.byref(ci), C.byref(k), C.byref(s),
+                                      C.byref(a), name, 96), "wtk_yolo_conv_info")
+        out.append(dict(name=name.value.decode(), cout=co.value, cin=ci.value, k=k.value, stride=s.value, act=a.value))
+    return out
+
+
+class HipYolo:
+    """Device YOLOv8 detector (wtk_yolo) for one network input size.
+
+    weights: dict name -> (W[cout,k,k,cin] fp32 O-H-W-I, b[cout] fp32) for every conv of
+    wtracker_amd.yolo_spec.conv_table(scale, nc)."""
+
+    def __init__(self, weights: dict, imgsz: tuple[int, int], max_batch: int, dtype: str = "fp16", nc: int = 1,
+                 width: float = 0.5, depth: float = 0.33, max_channels: int = 1024, device: int = 0):
+        lib = load()
+        table = yolo_conv_table(width, depth, max_channels, nc)
+        arr = (_ConvBlob * len(table))()
+        self._keep = []
+        for i, t in enumerate(table):
+            if t["name"] not in weights:
+                raise WtkError(f"missing weights for conv {t['name']}")
+            w, b = weights[t["name"]]
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            if w.shape != (t["cout"], t["k"], t["k"], t["cin"]) or b.shape != (t["cout"],):
+                raise WtkError(f"conv {t['name']}: expected weight {(t['cout'], t['k'], t['k'], t['cin'])}, got {w.shape}")
+            self._keep += [w, b]
+            arr[i] = _ConvBlob(t["cout"], t["cin"], t["k"], t["stride"], t["act"], 0, _fptr(w), _fptr(b))
+        desc = _YoloDesc(device, DTYPES[dtype], int(imgsz[0]), int(imgsz[1]), int(max_batch), nc, width, depth, max_channels,
+                         len(table), arr)
+        self._h = C.c_void_p()
+        _check(lib.wtk_yolo_create(C.byref(self._h), C.byref(desc)), "wtk_yolo_create")
+        self._keep = []  # the library copied everything to the device
+        self.imgsz = (int(imgsz[0]), int(imgsz[1]))
+        self.max_batch = int(max_batch)
+        self.dtype = dtype
+        self.nc = nc
+        self.device = device
+        macs, anchors = C.c_double(), C.c_int32()
+        _check(lib.wtk_yolo_workload(self._h, C.byref(macs), C.byref(anchors)), "wtk_yolo_workload")
+        self.macs_per_frame = macs.value
+        self.anchors = anchors.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().wtk_yolo_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def predict_host(self, frames: np.ndarray, conf: float = 0.1, iou: float = 0.7, max_det: int = 1):
+        """frames: uint8 [B,H,W] or [B,H,W,C] (host).  Returns (xywh [B,4] f32 with NaN rows, conf [B], anchor [B])."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim == 3:
+            frames = frames[..., None]
+        B, H, W, Cc = frames.shape
+        xywh = np.empty((B, 4), dtype=np.float32)
+        cf = np.empty((B,), dtype=np.float32)
+        an = np.empty((B,), dtype=np.int32)
+        _check(load().wtk_yolo_predict_host(self._h, _ptr(frames), B, H, W, Cc, conf, iou, max_det, _ptr(xywh), _ptr(cf),
+                                            _ptr(an)), "wtk_yolo_predict_host")
+        return xywh, cf, an
+
+    def predict(self, frames_dev, B: int, H: int, W: int, Cc: int, out_xywh, out_conf=None, out_anchor=None,
+                conf: float = 0.1, iou: float = 0.7, max_det: int = 1, stream: int = 0):
+        """Device pointers / torch CUDA tensors; asynchronous on `stream`."""
+        _check(load().wtk_yolo_predict(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh),
+                                       _ptr(out_conf), _ptr(out_anchor), C.c_void_p(stream)), "wtk_yolo_predict")
+
+    def debug_head(self, B: int):
+        """Raw head logits of the last forward: (box [B,A,64], cls [B,A,nc]) fp32, levels concatenated."""
+        lib = load()
+        boxes, clss = [], []
+        S_h, S_w = self.imgsz
+        for lvl, s in enumerate((8, 16, 32)):
+            A = (S_h // s) * (S_w // s)
+            bx = np.empty((B, A, 64), dtype=np.float32)
+            cl = np.empty((B, A, self.nc), dtype=np.float32)
+            _check(lib.wtk_yolo_debug_head(self._h, lvl, B, _ptr(bx), _ptr(cl)), "wtk_yolo_debug_head")
+            boxes.append(bx)
+            clss.append(cl)
+        return np.concatenate(boxes, 1), np.concatenate(clss, 1)
+
+    def decode_host(self, box: np.ndarray, cls: np.ndarray, H: int, W: int, conf: float = 0.1):
+        box = np.ascontiguousarray(box, dtype=np.float32)
+        cls = np.ascontiguousarray(cls, dtype=np.float32)
+        B = box.shape[0]
+        assert box.shape == (B, self.anchors, 64) and cls.shape == (B, self.anchors, self.nc)
+        xywh = np.empty((B, 4), dtype=np.float32)
+        cf = np.empty((B,), dtype=np.float32)
+        an = np.empty((B,), dtype=np.int32)
+        _check(load().wtk_yolo_decode_host(self._h, _ptr(box), _ptr(cls), B, H, W, conf, _ptr(xywh), _ptr(cf), _ptr(an)),
+               "wtk_yolo_decode_host")
+        return xywh, cf, an
+
+    def set_profiling(self, enabled: bool):
+        _check(load().wtk_yolo_set_profiling(self._h, int(enabled)), "wtk_yolo_set_profiling")
+
+    def get_profile(self) -> dict:
+        names = ["stem", "conv", "pool", "head"]
+        out = {}
+        for i, nme in enumerate(names):
+            ms, n = C.c_double(), C.c_int64()
+            _check(load().wtk_yolo_get_profile(self._h, i, C.byref(ms), C.byref(n)), "wtk_yolo_get_profile")
+            out[nme] = dict(total_ms=ms.value, launches=n.value)
+        return out
