@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the YOLOv8s + ResMLP sim-loop hot path on MI355X (BASELINE.json metric).
+
+One "step" = one super-batch: every rank runs the detector (stem, 61 implicit-GEMM convs, SPPF pool,
+head select) on its `--batch` synthetic 640x640 frames that are already resident in HBM, the [B,4]
+track slices are all-gathered (N > 1 only), and the ResMLP movement vectors of the cycles that became
+computable are produced (wtracker_amd/pipeline.py).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(weights, dims, size: int, n_frames: int, folded_path: str) -> dict:
+    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload, all host cores."""
+    from oracle import resmlp_oracle
+    from oracle import yolo_oracle as yo
+    from wtracker_amd import frames as fr
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = yo.YoloOracle(weights, dims)
+    frames, _ = fr.synthetic_frames(n_frames, size, seed=1)
+    st = resmlp_oracle.load_state(folded_path)
+    yo.predict(model, list(frames[:2]), imgsz=size)  # warm-up
+    t0 = time.perf_counter()
+    xywh, _, _ = yo.predict(model, list(frames), imgsz=size)
+    # ResMLP over the sample's cycles (one sample per 9 frames)
+    x = np.zeros((max(n_frames // 9, 1), 28), dtype=np.float32)
+    resmlp_oracle.forward(st, x)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_frames} synthetic {size}x{size} frames, one batch, torch-CPU fp32 restatement (oracle/yolo_oracle.py) + numpy ResMLP, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config 3: 64)")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel-class HIP-event timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
+
+    from wtracker_amd import _build, hip, resmlp
+    from wtracker_amd import frames as fr
+    from wtracker_amd import yolo_spec as ys
+    from wtracker_amd.pipeline import TrackPipeline
+
+    if _build.needs_build() and rank == 0:
+        _build.build(verbose=False)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
+    if hip.device_count() <= local_rank:
+        raise SystemExit("no HIP device visible: the product path has no CPU fallback")
+
+    scale, nc = "s", 1
+    weights = ys.synthetic_weights(scale, nc, seed=0)
+    depth, width, maxch = ys.SCALES[scale]
+    det = hip.HipYolo(weights, (args.size, args.size), args.batch, dtype=args.dtype, nc=nc, width=width, depth=depth,
+                      max_channels=maxch, device=local_rank)
+    golden = os.path.join(ROOT, "tests", "golden", "resmlp_100ms.npz")
+    folded = resmlp.load_npz(golden)  # ResMLP(imaging-100ms_pred-40ms_moving-50ms): the reference's shipped weights
+    mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
+
+    # synthetic frames, resident in HBM before the timed region; every rank draws its own seed
+    pool = max(args.pool // args.batch, 1) * args.batch
+    frames_np, _ = fr.synthetic_frames(pool, args.size, seed=1 + rank)
+    frames = torch.from_numpy(frames_np).to(dev)
+    n_pool_batches = pool // args.batch
+
+    total_steps = args.warmup + args.steps
+    total_frames = total_steps * args.batch * world
+    # 60 fps, 100/40/50 ms timing (BASELINE config 3): imaging 6, pred 3, moving 3 frames
+    pipe = TrackPipeline(det, mlp, folded, args.batch, total_frames, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9,
+                         conf=0.1, rank=rank, world=world, group=group, device=dev)
+
+    def run(s: int):
+        b = s % n_pool_batches
+        pipe.step(s, frames[b * args.batch : (b + 1) * args.batch])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for s in range(args.warmup):
+        run(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        run(s)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel-class device time with HIP events on the launch stream (same workload, rank 0)
+    roofline = None
+    if not args.no_profile:
+        det.set_profiling(True)
+        prof_steps = max(min(args.steps, 10), 1)
+        for s in range(prof_steps):
+            run(args.warmup + s)
+        torch.cuda.synchronize(dev)
+        prof = det.get_profile()
+        det.set_profiling(False)
+        conv = prof["conv"]
+        stem_macs = (args.size // 2) ** 2 * ys.conv_table(scale, nc)[0]["cout"] * 27
+        conv_flops_per_forward = 2.0 * (det.macs_per_frame - stem_macs) * args.batch
+        launches_per_forward = conv["launches"] / prof_steps
+        avg_launch_ms = conv["total_ms"] / max(conv["launches"], 1)
+        achieved = conv_flops_per_forward / launches_per_forward / (avg_launch_ms * 1e-3) / 1e12
+        roofline = {"kernel": "conv_igemm_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype],
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": None,
+                    "launches_per_step": launches_per_forward, "avg_launch_ms": avg_launch_ms,
+                    "flop_per_launch_avg": conv_flops_per_forward / launches_per_forward,
+                    "class_ms_per_step": {k: v["total_ms"] / prof_steps for k, v in prof.items()}}
+
+    frames_done = args.steps * args.batch * world
+    out = {
+        "metric": "frames/sec YOLOv8s+ResMLP sim loop @640x640",
+        "value": frames_done / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: full sim loop, YOLOv8s (nc=1, seeded synthetic weights) + ResMLP(imaging-100ms_pred-40ms_moving-50ms, reference weights)",
+                   "frame": f"{args.size}x{args.size} uint8 gray, resident in HBM", "batch_per_gpu": args.batch,
+                   "global_batch": args.batch * world, "timing_ms": [100, 40, 50], "conf": 0.1,
+                   "parallelism": f"frame-sharded x{world}, one RCCL all-gather of [B,4] tracks per step" if world > 1 else "single GPU"},
+        "roofline": roofline,
+    }
+    if rank == 0 and args.cpu_frames > 0:
+        out["cpu_baseline"] = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, args.cpu_frames, golden)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

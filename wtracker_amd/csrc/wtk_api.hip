@@ -328,6 +328,7 @@ struct wtk_yolo {
     size_t frames_cap = 0;
     uint8_t *lb_dev = nullptr;
     size_t lb_cap = 0;
+    void *zero_page = nullptr;
     float *o_xywh = nullptr, *o_conf = nullptr;
     int *o_anchor = nullptr;
     // profiling
@@ -642,6 +643,14 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         wtk_yolo_destroy(h);
         return 1;
     }
+    if (dev_alloc(h, &h->zero_page, 256)) {
+        wtk_yolo_destroy(h);
+        return 1;
+    }
+    if (hipMemset(h->zero_page, 0, 256) != hipSuccess) {
+        wtk_yolo_destroy(h);
+        return fail("wtk_yolo_create: hipMemset failed");
+    }
     *out = h;
     return 0;
 }
@@ -813,6 +822,7 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
             a.Kpad = op.Kpad;
             a.M = (long long)B * ob.h * ob.w;
             a.tile_w = op.tile_w;
+            a.zeros = h->zero_page;
             if (op.tile_w) {
                 const int th = conv_cfg_bm(op.cfg) / op.tile_w;
                 a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;

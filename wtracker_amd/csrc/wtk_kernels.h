@@ -32,6 +32,7 @@ struct ConvArgs {
     int tile_w; // 0: linear pixel order over N*Ho*Wo; >0: 2-D pixel tiles tile_w x (BM/tile_w)
     int tiles_x, tiles_y;
     long long M; // N*Ho*Wo
+    const void *zeros; // >= 16 zero bytes in device memory (source of padded / out-of-range chunks)
 };
 
 // Tile configurations (block = 256 threads = 4 waves)

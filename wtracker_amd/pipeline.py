@@ -1,0 +1,103 @@
+"""Open-loop batched form of the sim loop's hot path (BASELINE configs 3-5): frames that are
+already camera views are detected in batches (the `_cycle_predict_all` batch call,
+yolo_controller.py:108-109, widened from a 9/15-frame cycle to a 64/256-frame super-batch), the
+resulting bbox track is exchanged between ranks, and the ResMLP movement prediction of every
+imaging/moving cycle whose prediction frame falls in the super-batch is computed from the track
+(`MLPController.provide_movement_vector`, mlp_controllers.py:36-68).
+
+Multi-GPU: frames are sharded over ranks in interleaved super-batches — step s covers frames
+[s*B*N, (s+1)*B*N), rank r detects [s*B*N + r*B, +B) — so after ONE all-gather per step (RCCL over
+xGMI, payload B*16 bytes per rank: latency-bound) every rank holds the whole track up to the end of
+the super-batch, which is what ResMLP's 27..45-frame look-back needs.  No other
+collective exists on the path.
+
+torch is used for device memory, streams and torch.distributed only; all arithmetic is in
+libwtk_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import hip
+from .resmlp import FoldedResMLP
+
+
+class ShardPlan:
+    """Pure index arithmetic of the interleaved super-batch sharding (no device work): which frames a
+    rank detects at step s, and which cycles' predictions become computable after that step."""
+
+    def __init__(self, batch: int, world: int, total_frames: int, imaging_frame_num: int, pred_frame_num: int, cycle_frame_num: int):
+        self.B, self.world = batch, world
+        self.super_batch = batch * world
+        self.total_frames = total_frames
+        self.img, self.pred, self.cyc = imaging_frame_num, pred_frame_num, cycle_frame_num
+        n_cycles = max(0, (total_frames - imaging_frame_num) // cycle_frame_num + 1)
+        anchors = np.arange(n_cycles, dtype=np.int64) * cycle_frame_num + (imaging_frame_num - pred_frame_num)
+        self.anchors = anchors[anchors + pred_frame_num < total_frames].astype(np.int32)
+
+    @property
+    def steps(self) -> int:
+        return self.total_frames // self.super_batch
+
+    def local_range(self, s: int, rank: int) -> tuple:
+        f0 = s * self.super_batch + rank * self.B
+        return f0, f0 + self.B
+
+    def super_range(self, s: int) -> tuple:
+        return s * self.super_batch, (s + 1) * self.super_batch
+
+    def cycles(self, s: int) -> tuple:
+        """[lo, hi) into self.anchors: cycles whose provide_movement_vector frame lies in super-batch s."""
+        f0, f1 = self.super_range(s)
+        key = self.anchors.astype(np.int64) + self.pred
+        return int(np.searchsorted(key, f0, side="left")), int(np.searchsorted(key, f1, side="left"))
+
+
+def exchange_tracks(track: torch.Tensor, local_xywh: torch.Tensor, plan: ShardPlan, s: int, group=None):
+    """The path's only collective: all-gather the ranks' [B,4] slices into the track rows of super-batch s
+    (rank order == frame order, so the gathered block is contiguous).  Backend-agnostic: RCCL on the GPUs,
+    gloo in the CPU tests."""
+    import torch.distributed as dist
+
+    f0, f1 = plan.super_range(s)
+    dist.all_gather_into_tensor(track[f0:f1].view(-1), local_xywh.contiguous().view(-1), group=group)
+
+
+class TrackPipeline:
+    def __init__(self, det: hip.HipYolo, mlp: hip.HipMLP, folded: FoldedResMLP, batch: int, total_frames: int,
+                 imaging_frame_num: int, pred_frame_num: int, cycle_frame_num: int, conf: float = 0.1,
+                 rank: int = 0, world: int = 1, group=None, device: Optional[torch.device] = None):
+        self.det, self.mlp, self.folded = det, mlp, folded
+        self.rank, self.world, self.group = rank, world, group
+        self.conf = conf
+        self.device = device or torch.device("cuda", det.device)
+        self.plan = ShardPlan(batch, world, total_frames, imaging_frame_num, pred_frame_num, cycle_frame_num)
+        # device-resident track of the whole run: xywh per frame (NaN = no detection yet / none found)
+        self.track = torch.full((total_frames, 4), float("nan"), dtype=torch.float32, device=self.device)
+        self.local_xywh = torch.empty((batch, 4), dtype=torch.float32, device=self.device)
+        self.local_conf = torch.empty((batch,), dtype=torch.float32, device=self.device)
+        self.local_anchor = torch.empty((batch,), dtype=torch.int32, device=self.device)
+        n = max(len(self.plan.anchors), 1)
+        self.anchors = torch.from_numpy(self.plan.anchors).to(self.device)
+        self.moves = torch.zeros((n, 2), dtype=torch.float32, device=self.device)  # raw ResMLP (dx, dy) per cycle
+        self.valid = torch.zeros((n,), dtype=torch.int32, device=self.device)
+
+    def step(self, s: int, frames_dev: torch.Tensor) -> int:
+        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles."""
+        B, H, W = frames_dev.shape[0], frames_dev.shape[1], frames_dev.shape[2]
+        C = frames_dev.shape[3] if frames_dev.dim() == 4 else 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if self.world == 1:
+            f0, f1 = self.plan.local_range(s, 0)
+            self.det.predict(frames_dev, B, H, W, C, self.track[f0:f1], self.local_conf, self.local_anchor, conf=self.conf, stream=st)
+        else:
+            self.det.predict(frames_dev, B, H, W, C, self.local_xywh, self.local_conf, self.local_anchor, conf=self.conf, stream=st)
+            exchange_tracks(self.track, self.local_xywh, self.plan, s, self.group)
+        lo, hi = self.plan.cycles(s)
+        if hi > lo:
+            self.mlp.predict_track(self.track, self.plan.total_frames, self.anchors[lo:hi], hi - lo, self.folded.input_frames,
+                                   self.moves[lo:hi], self.valid[lo:hi], stream=st)
+        return hi - lo
