@@ -7,6 +7,7 @@ plan order of wtk_yolo_create) and print per-op time, TFLOP/s and algorithmic HB
 import argparse
 import csv
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -100,7 +101,11 @@ def main():
             fl = 2.0 * px * cout * cin * k * k
             by = px * stride_in * stride_in * cin * es + px * cout * es * (1 + extra) + cout * cin * k * k * es
         kname = mine[args.skip * per + i]["Kernel_Name"]
-        short = "128x128" if "Li128ELi128" in kname else ("256x64" if "Li256ELi64" in kname else ("256x32" if "Li256ELi32" in kname else kind))
+        if "halo" in kname:
+            m = re.search(r"Li(\d+)ELi(\d)ELi(\d)E", kname)
+            short = f"halo{m.group(1)}/{m.group(2)}" if m else "halo"
+        else:
+            short = "128x128" if "Li128ELi128" in kname else ("256x64" if "Li256ELi64" in kname else ("256x32" if "Li256ELi32" in kname else kind))
         print(f"{name:28s} {short:10s} {us:9.1f} {fl / 1e9:8.2f} {fl / us / 1e6 if us else 0:8.1f} {by / 1e6:9.1f} {by / us / 1e3 if us else 0:8.0f}")
         tot_us += us
         tot_fl += fl

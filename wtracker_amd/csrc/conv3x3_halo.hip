@@ -1,0 +1,311 @@
+// 3x3 / stride-1 convolution with an LDS-resident input window ("halo") on CDNA4 matrix cores.
+//
+// The generic implicit-GEMM kernel (conv_igemm.hip) re-stages the im2col pixel operand for each of the
+// 9 taps: 9x the L2->LDS traffic and 9x the LDS-DMA instructions of the input it actually needs, and
+// on MI355X the DMA issue cost (~60-180 cycles per 1-KiB piece) then rivals the MFMA time.  Here the
+// block's input window is staged ONCE per 64-channel chunk and the 9 taps read it at shifted offsets:
+//
+//   * the image is walked in column strips of S <= 85 px; inside a strip, pixels of the zero-padded
+//     window (pitch = S + 2 columns) are numbered flat, o = y*pitch + x, so the input of output o for
+//     tap (kh, kw) is simply window[o + kh*pitch + kw]: a 1-D shift.  A block owns 256 consecutive flat
+//     outputs (2 of every `pitch` are border junk and are dropped in the epilogue); its window is the
+//     contiguous run of 256 + 2*pitch + 2 window pixels, each 128 bytes (64 fp16 / 32 fp32 channels);
+//   * an MFMA pixel tile is 16 consecutive flat outputs = 16 consecutive window rows, so with the
+//     row&7 XOR swizzle every ds_read_b128 fragment read is conflict-free for ANY tap offset;
+//   * per tap only the [BN][64ch] weight slab is streamed (double buffered, LDS-DMA); the next channel
+//     chunk's window is prefetched one 1-KiB piece per wave per tap underneath the MFMAs;
+//   * 8 waves / block (2 per SIMD); wave tile 64 px x 64 cout (BN = 128) or 32 px x 64 cout (BN = 64);
+//   * all four LDS buffers are distinct objects so hipcc's waitcnt pass does not drain the in-flight
+//     LDS-DMA before each fragment read (see conv_igemm.hip).
+#include "wtk_kernels.h"
+
+#include <type_traits>
+
+namespace wtk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <typename T> struct ElemH;
+template <> struct ElemH<_Float16> {
+    static constexpr int CE = 8;
+};
+template <> struct ElemH<float> {
+    static constexpr int CE = 4;
+};
+
+__device__ __forceinline__ float silu_h(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 &acc, _Float16 *) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wf), __builtin_bit_cast(half8, pf), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 &acc, float *) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.x), __builtin_bit_cast(float, pf.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.y), __builtin_bit_cast(float, pf.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.z), __builtin_bit_cast(float, pf.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, pf.w), acc, 0, 0, 0);
+}
+
+template <int NV> __device__ __forceinline__ void load_run_h(const _Float16 *p, float (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 8) {
+        half8 h = *reinterpret_cast<const half8 *>(p + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i + j] = (float)h[j];
+    }
+}
+template <int NV> __device__ __forceinline__ void load_run_h(const float *p, float (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) {
+        float4 f = *reinterpret_cast<const float4 *>(p + i);
+        v[i] = f.x, v[i + 1] = f.y, v[i + 2] = f.z, v[i + 3] = f.w;
+    }
+}
+template <int NV> __device__ __forceinline__ void store_run_h(_Float16 *p, const float (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 8) {
+        half8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[i + j];
+        *reinterpret_cast<half8 *>(p + i) = h;
+    }
+}
+template <int NV> __device__ __forceinline__ void store_run_h(float *p, const float (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) *reinterpret_cast<float4 *>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+}
+
+constexpr int kBM = 256;
+constexpr int kHaloBytes = kHaloRowsMax * 128;
+
+template <typename T, int BN, int NHALO, int MINW>
+__global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
+    constexpr int CE = ElemH<T>::CE;
+    constexpr int CCH = 8 * CE; // channels per 128-byte chunk
+    constexpr int WAVES_C = BN / 64, WAVES_P = 8 / WAVES_C;
+    constexpr int WP = kBM / WAVES_P, TP = WP / 16, TC = 4, NV = 16;
+    constexpr int WR = BN / 64; // weight rows staged per thread per tap
+
+    __shared__ __attribute__((aligned(16))) char halo0[kHaloBytes];
+    __shared__ __attribute__((aligned(16))) char halo1[NHALO == 2 ? kHaloBytes : 16];
+    __shared__ __attribute__((aligned(16))) char wbuf0[BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf1[BN * 128];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_p = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // ---- block -> (cout tile, row block, strip, image); XCD-aware bijective remap
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int nct = a.CoutPad / BN;
+    const int n0 = (L % nct) * BN;
+    int t = L / nct;
+    const int rb = t % a.blocks_per_strip;
+    t /= a.blocks_per_strip;
+    const int strip = t % a.strips;
+    const int n = t / a.strips;
+    const int o0 = rb * kBM;
+    const int xs = strip * a.S;
+    const int pitch = a.pitch;
+    const int halo_rows = kBM + 2 * pitch + 2;
+    const int halo_pieces = (halo_rows + 7) >> 3;
+
+    const T *in = reinterpret_cast<const T *>(a.in) + (long long)n * a.H * a.W * a.in_ld + a.in_coff;
+    const T *wgt = reinterpret_cast<const T *>(a.w);
+    const char *zero_page = reinterpret_cast<const char *>(a.zeros);
+
+    // one 1-KiB piece (8 window rows) of channel chunk `c` into `buf`
+    auto issue_halo_piece = [&](char *buf, int piece, int c) {
+        const int hr = piece * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ (hr & 7); // logical chunk landing on this lane's physical slot
+        const int flat = o0 + hr;
+        const int r = flat / pitch;
+        const int cc = flat - r * pitch;
+        const int iy = r - 1, ix = xs + cc - 1;
+        const bool ok = hr < halo_rows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const char *src = ok ? reinterpret_cast<const char *>(in + ((long long)iy * a.W + ix) * a.in_ld + c * CCH + lc * CE) : zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(buf + piece * 1024), 16, 0, 0);
+    };
+    // weight slab of (tap, chunk c): rows = couts n0 .. n0+BN, 128 bytes each
+    const int wrow0 = tid >> 3, wp = tid & 7;
+    auto issue_weights = [&](char *buf, int tap, int c) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int row = wrow0 + 64 * i;
+            const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+            const T *src = wgt + (long long)(n0 + row) * a.Kpad + tap * a.Cin + c * CCH + ((wp ^ key) * CE);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(buf + (64 * i + 8 * wave) * 128), 16, 0, 0);
+        }
+    };
+
+    floatx4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    int woff[TC], wkey[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int row = wave_c * 64 + (lr >> 2) * NV + i * 4 + (lr & 3);
+        woff[i] = row * 128;
+        wkey[i] = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+    }
+    const int prow0 = wave_p * WP + lr; // window row of this lane's pixel in tile 0 at tap (0,0)
+
+    auto compute_tap = [&](const char *halo, const char *wb, int tapoff) {
+#pragma unroll
+        for (int kh2 = 0; kh2 < 2; ++kh2) {
+            const int chunk = lg + 4 * kh2;
+            uint4 pf[TP], wf[TC];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int hr = prow0 + j * 16 + tapoff;
+                pf[j] = *reinterpret_cast<const uint4 *>(halo + hr * 128 + ((chunk ^ (hr & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + woff[i] + ((chunk ^ wkey[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(wf[i], pf[j], acc[i][j], (T *)nullptr);
+        }
+    };
+
+    const int nchunks = a.Cin / CCH;
+
+    // ---- prologue: whole window of chunk 0 + weights of (tap 0, chunk 0)
+    for (int piece = wave; piece < halo_pieces; piece += 8) issue_halo_piece(halo0, piece, 0);
+    issue_weights(wbuf0, 0, 0);
+    __syncthreads();
+
+    // one channel chunk = 9 taps.  CP = parity of the chunk: window in halo[CP], tap t's weights in wbuf[(CP+t)&1]
+    auto chunk_body = [&](auto cp_tag, int c) {
+        constexpr int CP = decltype(cp_tag)::value;
+        const char *hcur = (NHALO == 2 && CP == 1) ? halo1 : halo0;
+        char *hnext = (NHALO == 2 && CP == 0) ? halo1 : halo0;
+        const bool more = c + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            char *wnext = ((CP + tap) & 1) ? wbuf0 : wbuf1;
+            const char *wcur = ((CP + tap) & 1) ? wbuf1 : wbuf0;
+            if (tap < 8)
+                issue_weights(wnext, tap + 1, c);
+            else if (more)
+                issue_weights(wnext, 0, c + 1);
+            if (NHALO == 2 && more) { // next chunk's window, one piece per wave per tap, under the MFMAs
+                const int piece = wave + 8 * tap;
+                if (piece < halo_pieces) issue_halo_piece(hnext, piece, c + 1);
+            }
+            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+            __syncthreads(); // vmcnt(0): everything issued above has landed; everyone is done reading wcur
+        }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < nchunks) chunk_body(std::integral_constant<int, 1>{}, c + 1);
+    }
+
+    // ---- epilogue
+    const int cb = n0 + wave_c * 64 + lg * NV;
+    if (cb + NV > a.Cout) return;
+    float bias[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
+    T *out = reinterpret_cast<T *>(a.out);
+    T *out2 = reinterpret_cast<T *>(a.out2);
+    const T *res = reinterpret_cast<const T *>(a.res);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int o = o0 + wave_p * WP + j * 16 + lr;
+        const int y = o / pitch;
+        const int x = o - y * pitch;
+        if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+        if (a.act) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = silu_h(v[i]);
+        }
+        const long long pix = ((long long)n * a.H + y) * a.W + xs + x;
+        if (res) {
+            float rv[NV];
+            load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] += rv[i];
+        }
+        store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
+        if (out2) {
+            const int H2 = a.H * 2, W2 = a.W * 2;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const long long pix2 = ((long long)n * H2 + (2 * y + dy)) * W2 + (2 * (xs + x) + dx);
+                    store_run_h<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
+                }
+        }
+    }
+}
+
+template <typename T, int BN, int NHALO, int MINW> hipError_t launch_h(const HaloArgs &a, hipStream_t stream) {
+    const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+bool halo_eligible(int k, int stride, int cin, int is_f16) {
+    const int cch = is_f16 ? 64 : 32;
+    return k == 3 && stride == 1 && cin % cch == 0;
+}
+
+void halo_geometry(int H, int W, int *S, int *pitch, int *strips, int *blocks_per_strip) {
+    const int smax = (kHaloRowsMax - kBM - 2) / 2 - 2; // BM + 2*(S+2) + 2 <= kHaloRowsMax
+    *strips = (W + smax - 1) / smax;
+    *S = (W + *strips - 1) / *strips;
+    *pitch = *S + 2;
+    *blocks_per_strip = (H * *pitch + kBM - 1) / kBM;
+}
+
+int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : 64; }
+
+hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream) {
+    const int ce = is_f16 ? 8 : 4;
+    const int cch = 8 * ce;
+    const int bn = halo_cout_tile(a.Cout);
+    if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % 16 != 0) return hipErrorInvalidValue;
+    if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
+    if (a.pitch != a.S + 2 || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W) return hipErrorInvalidValue;
+    if (a.blocks_per_strip * kBM < a.H * a.pitch) return hipErrorInvalidValue;
+    if (a.res && (a.res_ld % ce || a.res_coff % ce)) return hipErrorInvalidValue;
+    if (a.out2 && (a.out2_ld % ce || a.out2_coff % ce)) return hipErrorInvalidValue;
+    const int nchunks = a.Cin / cch;
+    if (is_f16) {
+        if (bn == 128) return launch_h<_Float16, 128, 2, 2>(a, stream);
+        if (nchunks == 1) return launch_h<_Float16, 64, 1, 4>(a, stream);
+        return launch_h<_Float16, 64, 2, 2>(a, stream);
+    }
+    if (bn == 128) return launch_h<float, 128, 2, 2>(a, stream);
+    if (nchunks == 1) return launch_h<float, 64, 1, 4>(a, stream);
+    return launch_h<float, 64, 2, 2>(a, stream);
+}
+
+} // namespace wtk

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -302,6 +303,7 @@ struct Op {
     int cfg = 0;
     int K = 0, Kpad = 0;
     int tile_w = 0;
+    int halo = 0; // 1: conv3x3_halo kernel
     void *w = nullptr; // packed device weights
     float *bias = nullptr;
     double macs_per_image = 0;
@@ -332,6 +334,7 @@ struct wtk_yolo {
     float *o_xywh = nullptr, *o_conf = nullptr;
     int *o_anchor = nullptr;
     // profiling
+    int use_halo = 1;
     int profiling = 0;
     hipEvent_t ev[16];
     int ev_created = 0;
@@ -379,7 +382,7 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
     const int ce = h->is_f16 ? 8 : 4;
     op.K = op.k * op.k * op.cin;
     op.Kpad = (op.K + 8 * ce - 1) / (8 * ce) * (8 * ce);
-    const int bn = conv_cfg_bn(op.cfg);
+    const int bn = op.halo ? halo_cout_tile(op.cout) : conv_cfg_bn(op.cfg);
     op.cout_pad = (op.cout + bn - 1) / bn * bn;
     std::vector<float> wf((size_t)op.cout_pad * op.Kpad, 0.f), bf(op.cout_pad, 0.f);
     int row = 0;
@@ -468,6 +471,7 @@ struct Planner {
         const int bm = conv_cfg_bm(op.cfg);
         op.tile_w = 0;
         if (op.k == 3 && wo >= 64 && wo % 16 == 0 && ho % (bm / 16) == 0) op.tile_w = 16;
+        op.halo = halo_eligible(op.k, op.stride, op.cin, h->is_f16) && h->use_halo ? 1 : 0;
         op.macs_per_image = (double)ho * wo * cout * op.k * op.k * op.cin;
         if (pack_conv(h, op, wp, bp, couts)) {
             failed = true;
@@ -533,6 +537,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     h->S_w = d->imgsz_w;
     h->max_batch = d->max_batch;
     h->dims = dims;
+    if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
 
     Planner P{h, specs, d->convs};
     const int *c = dims.c;
@@ -828,7 +833,23 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
                 a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;
                 a.tiles_y = (ob.h + th - 1) / th;
             }
-            HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
+            if (op.halo) {
+                HaloArgs g;
+                std::memset(&g, 0, sizeof(g));
+                g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
+                g.N = B, g.H = ib.h, g.W = ib.w, g.Cin = op.cin;
+                g.Cout = op.cout, g.CoutPad = op.cout_pad;
+                g.w = op.w, g.bias = op.bias;
+                g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
+                g.out2 = a.out2, g.out2_ld = a.out2_ld, g.out2_coff = a.out2_coff;
+                g.res = a.res, g.res_ld = a.res_ld, g.res_coff = a.res_coff;
+                g.act = op.act, g.Kpad = op.Kpad;
+                halo_geometry(ib.h, ib.w, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
+                g.zeros = h->zero_page;
+                HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
+            } else {
+                HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
+            }
             ++launches[1];
         }
     }

@@ -44,6 +44,33 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
 hipError_t conv_init_attributes();
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with an LDS-resident input window (conv3x3_halo.hip).
+// ---------------------------------------------------------------------------------------------
+constexpr int kHaloRowsMax = 432; // window rows (128 B each) one LDS buffer holds: 54 KiB
+struct HaloArgs {
+    const void *in;
+    int in_ld, in_coff;
+    int N, H, W, Cin;
+    int Cout, CoutPad;
+    const void *w;     // packed [CoutPad][Kpad], K = (tap, cin)
+    const float *bias; // [CoutPad]
+    void *out;
+    int out_ld, out_coff;
+    void *out2;
+    int out2_ld, out2_coff;
+    const void *res;
+    int res_ld, res_coff;
+    int act;
+    int Kpad;
+    int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
+    const void *zeros;
+};
+bool halo_eligible(int k, int stride, int cin, int is_f16);
+void halo_geometry(int H, int W, int *S, int *pitch, int *strips, int *blocks_per_strip);
+int halo_cout_tile(int cout_stored);
+hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
 // Stem: uint8 frame -> (BGR->RGB, /255) -> 3x3 stride-2 conv (Cin=3) + bias + SiLU -> NHWC.
 // Fuses ultralytics' preprocess with model.0 so the fp tensor [B,3,S,S] never exists.
 // ---------------------------------------------------------------------------------------------
