@@ -36,7 +36,13 @@ template <> struct ElemH<float> {
     static constexpr int CE = 4;
 };
 
-__device__ __forceinline__ float silu_h(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU with two transcendentals and three plain VALU ops (v_mul, v_exp, v_add, v_rcp, v_mul).  The obvious
+// x / (1 + __expf(-x)) expands to ~35 instructions (IEEE division + range-checked exp) and made the
+// epilogue, not the MFMA loop, the longest part of every conv.  v_exp/v_rcp are 1-ulp approximations.
+__device__ __forceinline__ float silu_h(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 __device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 &acc, _Float16 *) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wf), __builtin_bit_cast(half8, pf), acc, 0, 0, 0);
@@ -124,8 +130,17 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     const T *wgt = reinterpret_cast<const T *>(a.w);
     const char *zero_page = reinterpret_cast<const char *>(a.zeros);
 
-    // one 1-KiB piece (8 window rows) of channel chunk `c` into `buf`
-    auto issue_halo_piece = [&](char *buf, int piece, int c) {
+    // ---- loop-invariant per-lane addressing (the inner loop must stay almost VALU-free: a wave64 VALU op
+    // costs ~4 issue cycles against 16 per MFMA, so a few dozen address instructions per tap starve the
+    // matrix pipe).
+    // Window pieces: wave w stages pieces w, w+8, ... (<= kMaxPiecesPerWave); the window geometry does not
+    // depend on the channel chunk, so each piece's per-lane byte offset inside the image is computed once.
+    constexpr int kMaxPiecesPerWave = (kHaloRowsMax / 8 + 7) / 8;
+    unsigned hoff[kMaxPiecesPerWave];
+    unsigned hvalid = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxPiecesPerWave; ++q) {
+        const int piece = wave + 8 * q;
         const int hr = piece * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ (hr & 7); // logical chunk landing on this lane's physical slot
         const int flat = o0 + hr;
@@ -133,21 +148,34 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         const int cc = flat - r * pitch;
         const int iy = r - 1, ix = xs + cc - 1;
         const bool ok = hr < halo_rows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const char *src = ok ? reinterpret_cast<const char *>(in + ((long long)iy * a.W + ix) * a.in_ld + c * CCH + lc * CE) : zero_page;
+        hoff[q] = ok ? (unsigned)((((long long)iy * a.W + ix) * a.in_ld + lc * CE) * (long long)sizeof(T)) : 0u;
+        hvalid |= ok ? (1u << q) : 0u;
+    }
+    const char *img = reinterpret_cast<const char *>(in);
+    auto issue_halo_piece = [&](char *buf, int q, int c) { // q static after unrolling
+        const int piece = wave + 8 * q;
+        if (piece >= halo_pieces) return; // wave-uniform
+        const char *src = ((hvalid >> q) & 1u) ? img + (size_t)c * (CCH * sizeof(T)) + hoff[q] : zero_page;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(buf + piece * 1024), 16, 0, 0);
     };
-    // weight slab of (tap, chunk c): rows = couts n0 .. n0+BN, 128 bytes each
+    // Weight slab of (tap, chunk c): rows = couts n0 .. n0+BN, 128 bytes each.  Uniform base + invariant
+    // per-lane 32-bit offset (lets the compiler use the SGPR-base form of global_load_lds).
     const int wrow0 = tid >> 3, wp = tid & 7;
-    auto issue_weights = [&](char *buf, int tap, int c) {
+    unsigned wvoff[WR];
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int row = wrow0 + 64 * i;
-            const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
-            const T *src = wgt + (long long)(n0 + row) * a.Kpad + tap * a.Cin + c * CCH + ((wp ^ key) * CE);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+    for (int i = 0; i < WR; ++i) {
+        const int row = wrow0 + 64 * i;
+        const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+        wvoff[i] = (unsigned)(((long long)row * a.Kpad + (wp ^ key) * CE) * (long long)sizeof(T));
+    }
+    const char *wtile = reinterpret_cast<const char *>(wgt + (long long)n0 * a.Kpad);
+    auto issue_weights = [&](char *buf, int tap, int c) {
+        const char *ub = wtile + ((size_t)tap * a.Cin + (size_t)c * CCH) * sizeof(T); // wave-uniform
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + wvoff[i]),
                                              (__attribute__((address_space(3))) void *)(buf + (64 * i + 8 * wave) * 128), 16, 0, 0);
-        }
     };
 
     floatx4 acc[TC][TP];
@@ -156,27 +184,25 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    int woff[TC], wkey[TC];
-#pragma unroll
-    for (int i = 0; i < TC; ++i) {
-        const int row = wave_c * 64 + (lr >> 2) * NV + i * 4 + (lr & 3);
-        woff[i] = row * 128;
-        wkey[i] = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
-    }
+    // weight fragments: row(i) = wave_c*64 + (lr>>2)*16 + 4*i + (lr&3); the swizzle key does not depend on
+    // i, so the four tiles are one base + immediates (i*512), and the second k-half is base ^ 64.
+    const int wrow_l = wave_c * 64 + (lr >> 2) * NV + (lr & 3);
+    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
+    const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
     const int prow0 = wave_p * WP + lr; // window row of this lane's pixel in tile 0 at tap (0,0)
 
     auto compute_tap = [&](const char *halo, const char *wb, int tapoff) {
+        const int base = prow0 + tapoff;
+        const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4); // tiles j: + j*2048 (key unchanged)
 #pragma unroll
         for (int kh2 = 0; kh2 < 2; ++kh2) {
-            const int chunk = lg + 4 * kh2;
+            const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
+            const unsigned wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
             uint4 pf[TP], wf[TC];
 #pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const int hr = prow0 + j * 16 + tapoff;
-                pf[j] = *reinterpret_cast<const uint4 *>(halo + hr * 128 + ((chunk ^ (hr & 7)) << 4));
-            }
+            for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
 #pragma unroll
-            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + woff[i] + ((chunk ^ wkey[i]) << 4));
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -187,7 +213,8 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     const int nchunks = a.Cin / CCH;
 
     // ---- prologue: whole window of chunk 0 + weights of (tap 0, chunk 0)
-    for (int piece = wave; piece < halo_pieces; piece += 8) issue_halo_piece(halo0, piece, 0);
+#pragma unroll
+    for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_halo_piece(halo0, q, 0);
     issue_weights(wbuf0, 0, 0);
     __syncthreads();
 
@@ -205,10 +232,8 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
                 issue_weights(wnext, tap + 1, c);
             else if (more)
                 issue_weights(wnext, 0, c + 1);
-            if (NHALO == 2 && more) { // next chunk's window, one piece per wave per tap, under the MFMAs
-                const int piece = wave + 8 * tap;
-                if (piece < halo_pieces) issue_halo_piece(hnext, piece, c + 1);
-            }
+            if (NHALO == 2 && more && tap < kMaxPiecesPerWave) // next chunk's window, one piece per wave per
+                issue_halo_piece(hnext, tap, c + 1);           // tap, underneath the MFMAs
             compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
             __syncthreads(); // vmcnt(0): everything issued above has landed; everyone is done reading wcur
         }

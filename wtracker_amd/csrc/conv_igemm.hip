@@ -34,7 +34,13 @@ template <> struct Elem<float> {
     static constexpr int CE = 4;
 };
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU with two transcendentals and three plain VALU ops (v_mul, v_exp, v_add, v_rcp, v_mul).  The obvious
+// x / (1 + __expf(-x)) expands to ~35 instructions (IEEE division + range-checked exp) and made the
+// epilogue, not the MFMA loop, the longest part of every conv.  v_exp/v_rcp are 1-ulp approximations.
+__device__ __forceinline__ float silu_f(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // one 16-byte operand fragment pair -> MFMA(s)
 __device__ __forceinline__ void mma_frag(const uint4 &wf, const uint4 &pf, floatx4 &acc, _Float16 *) {

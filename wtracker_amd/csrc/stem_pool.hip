@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
 #pragma unroll
             for (int k = 0; k < 27; ++k) s = fmaf(w[k], x[k], s);
             s += b_s[c8 + j];
-            v[j] = s / (1.0f + __expf(-s));
+            v[j] = s * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s * -1.4426950408889634f));
         }
         if constexpr (sizeof(T) == 2) {
             half8 h;
