@@ -8,84 +8,180 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------
 // Stem: fuses ultralytics' predictor preprocess (BGR->RGB, HWC uint8 -> float /255)
-// with model.0 = Conv(3, c0, k=3, s=2, p=1)+BN+SiLU (a5).  One thread = one output pixel x CO couts.
-// Weights [Cout][3][3][3] (O-H-W-I, I = RGB) live in LDS and are read as wave-uniform broadcasts.
+// with model.0 = Conv(3, c0, k=3, s=2, p=1)+BN+SiLU (a5) on the matrix cores.
+//
+// One block = one 16x16 tile of output pixels x all c0 couts.  The 33x33 input patch is normalised
+// once into LDS as [pixel][R,G,B,0]; K is laid out as k = tap*4 + channel (36 of 64 / 36 slots used),
+// so an MFMA B-fragment is two 8-byte LDS reads (two taps) in fp16 mode and one 4-byte read per tap in
+// fp32 mode — no im2col buffer.  Weights are pre-packed to the same K layout and live in registers.
+// Output lanes own 8 consecutive couts of one pixel (16-byte NHWC stores).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CO>
-__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
-    __shared__ float w_s[CO * 27];
-    __shared__ float b_s[CO];
-    const int co0 = blockIdx.y * CO;
-    for (int i = threadIdx.x; i < CO * 27; i += 256) w_s[i] = a.w[co0 * 27 + i];
-    for (int i = threadIdx.x; i < CO; i += 256) b_s[i] = a.bias[co0 + i];
+typedef float floatx4_s __attribute__((ext_vector_type(4)));
+typedef _Float16 half4_s __attribute__((ext_vector_type(4)));
+
+constexpr int kStemPatch = 33;
+
+template <typename T> struct StemElem;
+template <> struct StemElem<_Float16> {
+    using px_t = half4_s; // [R,G,B,0]
+};
+template <> struct StemElem<float> {
+    using px_t = float4;
+};
+
+template <typename T, int TC>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
+    using px_t = typename StemElem<T>::px_t;
+    __shared__ __attribute__((aligned(16))) px_t patch[kStemPatch * kStemPatch + 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int tiles_x = (a.Wo + 15) >> 4, tiles_y = (a.Ho + 15) >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+
+    // ---- patch: uint8 (gray or BGR) -> RGB/255 in LDS, zero outside the image
+    const uint8_t *img = a.frames + (long long)n * a.H * a.W * a.C;
+    for (int i = tid; i < kStemPatch * kStemPatch; i += 256) {
+        const int py = i / kStemPatch, px = i - py * kStemPatch;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float r = 0.f, g = 0.f, b = 0.f;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            const uint8_t *p = img + ((long long)iy * a.W + ix) * a.C;
+            if (a.C == 1) {
+                r = g = b = (float)p[0] / 255.0f; // gray -> 3 identical channels (yolo_controller.py:68-69)
+            } else {
+                b = (float)p[0] / 255.0f, g = (float)p[1] / 255.0f, r = (float)p[2] / 255.0f;
+            }
+        }
+        px_t v;
+        v.x = (T)r, v.y = (T)g, v.z = (T)b, v.w = (T)0.f;
+        patch[i] = v;
+    }
+
+    // ---- weights -> registers.  cout of (tile tc, MFMA row r): (r>>2)*4*TC + tc*4 + (r&3)
+    floatx4_s acc[TC][4];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (floatx4_s){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long M = (long long)a.N * a.Ho * a.Wo;
-    if (m >= M) return;
-    const int HoWo = a.Ho * a.Wo;
-    const int n = (int)(m / HoWo);
-    const int rem = (int)(m - (long long)n * HoWo);
-    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-
-    float x[27]; // (kh, kw, rgb)
-    const uint8_t *img = a.frames + (long long)n * a.H * a.W * a.C;
+    if constexpr (sizeof(T) == 2) {
+        typedef _Float16 half8_s __attribute__((ext_vector_type(8)));
+        // packed weights: [cout][16 taps][4] fp16, taps 9..15 zero; lane holds k = 8*lg .. 8*lg+7 = taps 2lg, 2lg+1
+        const _Float16 *w = reinterpret_cast<const _Float16 *>(a.w);
+        half8_s wf[TC][2];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho * 2 - 1 + kh;
+        for (int i = 0; i < TC; ++i) {
+            const int co = (lr >> 2) * 4 * TC + i * 4 + (lr & 3);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int wi = wo * 2 - 1 + kw;
-            float r = 0.f, g = 0.f, b = 0.f;
-            if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
-                const uint8_t *p = img + ((long long)hi * a.W + wi) * a.C;
-                if (a.C == 1) {
-                    r = g = b = (float)p[0] / 255.0f; // gray -> 3 identical channels (yolo_controller.py:68-69)
-                } else {
-                    b = (float)p[0] / 255.0f;
-                    g = (float)p[1] / 255.0f;
-                    r = (float)p[2] / 255.0f;
+            for (int ks = 0; ks < 2; ++ks) wf[i][ks] = *reinterpret_cast<const half8_s *>(w + (co * 16 + ks * 8 + 2 * lg) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { // pixel tile j = output row 4*wave + j of the block tile, 16 px wide
+            const int py = (wave * 4 + j) * 2, px = lr * 2;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8_s pf;
+                const int tap0 = ks * 8 + 2 * lg;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tap = tap0 + h;
+                    half4_s v = (half4_s){0, 0, 0, 0};
+                    if (tap < 9) v = patch[(py + tap / 3) * kStemPatch + px + tap % 3];
+                    pf[4 * h + 0] = v.x, pf[4 * h + 1] = v.y, pf[4 * h + 2] = v.z, pf[4 * h + 3] = v.w;
                 }
+#pragma unroll
+                for (int i = 0; i < TC; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i][ks], pf, acc[i][j], 0, 0, 0);
             }
-            x[(kh * 3 + kw) * 3 + 0] = r;
-            x[(kh * 3 + kw) * 3 + 1] = g;
-            x[(kh * 3 + kw) * 3 + 2] = b;
+        }
+    } else {
+        // packed weights: [cout][9 taps][4] fp32; MFMA 16x16x4: lane holds k = lg (channel lg of the tap)
+        const float *w = reinterpret_cast<const float *>(a.w);
+        float wf[TC][9];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co = (lr >> 2) * 4 * TC + i * 4 + (lr & 3);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wf[i][tap] = w[(co * 9 + tap) * 4 + lg];
+        }
+        const float *pl = reinterpret_cast<const float *>(patch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = (wave * 4 + j) * 2, px = lr * 2;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float pv = pl[((py + tap / 3) * kStemPatch + px + tap % 3) * 4 + lg];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][tap], pv, acc[i][j], 0, 0, 0);
+            }
         }
     }
-    T *out = reinterpret_cast<T *>(a.out) + m * a.Cout + co0;
+
+    // ---- epilogue: lane (pixel lr of row j, group lg) owns couts lg*4*TC .. +4*TC-1
+    constexpr int NV = 4 * TC;
+    const int cb = lg * NV;
+    float bias[NV];
 #pragma unroll
-    for (int c8 = 0; c8 < CO; c8 += 8) {
-        float v[8];
+    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
+    T *out = reinterpret_cast<T *>(a.out);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float s = 0.f;
-            const float *w = &w_s[(c8 + j) * 27];
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + wave * 4 + j, ox = ox0 + lr;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        float v[NV];
 #pragma unroll
-            for (int k = 0; k < 27; ++k) s = fmaf(w[k], x[k], s);
-            s += b_s[c8 + j];
-            v[j] = s * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s * -1.4426950408889634f));
-        }
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = acc[i][j][r] + bias[i * 4 + r];
+                v[i * 4 + r] = s * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s * -1.4426950408889634f));
+            }
+        T *o = out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout + cb;
         if constexpr (sizeof(T) == 2) {
-            half8 h;
+            typedef _Float16 half8_o __attribute__((ext_vector_type(8)));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
-            *reinterpret_cast<half8 *>(out + c8) = h;
+            for (int i = 0; i < NV; i += 8) {
+                half8_o h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = (_Float16)v[i + q];
+                *reinterpret_cast<half8_o *>(o + i) = h;
+            }
         } else {
-            *reinterpret_cast<float4 *>(out + c8) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4 *>(out + c8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int i = 0; i < NV; i += 4) *reinterpret_cast<float4 *>(o + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
         }
     }
 }
 
 hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream) {
-    if (a.Cout % 16 != 0 || (a.C != 1 && a.C != 3)) return hipErrorInvalidValue;
+    if ((a.Cout != 16 && a.Cout != 32 && a.Cout != 48 && a.Cout != 64) || (a.C != 1 && a.C != 3)) return hipErrorInvalidValue;
     if (a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2) return hipErrorInvalidValue;
-    const long long M = (long long)a.N * a.Ho * a.Wo;
-    dim3 grid((unsigned)((M + 255) / 256), a.Cout / 16);
-    if (is_f16)
-        hipLaunchKernelGGL((stem_kernel<_Float16, 16>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((stem_kernel<float, 16>), grid, dim3(256), 0, stream, a);
+    const long long blocks = (long long)a.N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks);
+#define WTK_STEM(T, TC) hipLaunchKernelGGL((stem_mfma_kernel<T, TC>), grid, dim3(256), 0, stream, a)
+    if (is_f16) {
+        switch (a.Cout / 16) {
+        case 1: WTK_STEM(_Float16, 1); break;
+        case 2: WTK_STEM(_Float16, 2); break;
+        case 3: WTK_STEM(_Float16, 3); break;
+        default: WTK_STEM(_Float16, 4); break;
+        }
+    } else {
+        switch (a.Cout / 16) {
+        case 1: WTK_STEM(float, 1); break;
+        case 2: WTK_STEM(float, 2); break;
+        case 3: WTK_STEM(float, 3); break;
+        default: WTK_STEM(float, 4); break;
+        }
+    }
+#undef WTK_STEM
     return hipGetLastError();
 }
 

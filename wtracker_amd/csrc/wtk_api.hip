@@ -571,12 +571,29 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         op.cout = c[0];
         op.macs_per_image = (double)h2 * w2 * c[0] * 27;
         const int i0 = find_spec(specs, "model.0");
-        float *wdev, *bdev;
-        if (dev_alloc(h, (void **)&wdev, sizeof(float) * c[0] * 27) || dev_alloc(h, (void **)&bdev, sizeof(float) * c[0])) {
+        // repack [cout][3][3][3(RGB)] -> K = tap*4 + channel (see stem_mfma_kernel)
+        const float *w0 = d->convs[i0].weight;
+        const int taps = h->is_f16 ? 16 : 9;
+        std::vector<float> wp((size_t)c[0] * taps * 4, 0.f);
+        for (int co = 0; co < c[0]; ++co)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ch = 0; ch < 3; ++ch) wp[((size_t)co * taps + tap) * 4 + ch] = w0[((size_t)co * 9 + tap) * 3 + ch];
+        void *wdev;
+        float *bdev;
+        std::vector<uint16_t> wh;
+        const void *src = wp.data();
+        size_t bytes = wp.size() * 4;
+        if (h->is_f16) {
+            wh.resize(wp.size());
+            for (size_t i = 0; i < wp.size(); ++i) wh[i] = f32_to_f16_bits(wp[i]);
+            src = wh.data();
+            bytes = wh.size() * 2;
+        }
+        if (dev_alloc(h, &wdev, bytes) || dev_alloc(h, (void **)&bdev, sizeof(float) * c[0])) {
             wtk_yolo_destroy(h);
             return 1;
         }
-        if (hipMemcpy(wdev, d->convs[i0].weight, sizeof(float) * c[0] * 27, hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMemcpy(wdev, src, bytes, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(bdev, d->convs[i0].bias, sizeof(float) * c[0], hipMemcpyHostToDevice) != hipSuccess) {
             wtk_yolo_destroy(h);
             return fail("wtk_yolo_create: stem weight upload failed");
@@ -777,7 +794,7 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
             StemArgs a;
             a.frames = net_in;
             a.N = B, a.H = h->S_h, a.W = h->S_w, a.C = C;
-            a.w = (const float *)op.w;
+            a.w = op.w;
             a.bias = op.bias;
             a.out = h->bufs[op.out_buf].ptr;
             a.Cout = op.cout;

@@ -77,7 +77,7 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
 struct StemArgs {
     const uint8_t *frames; // [N][H][W][C], C = 1 or 3 (BGR)
     int N, H, W, C;
-    const float *w; // [Cout][3][3][3] fp32, O-H-W-I with I in RGB order
+    const void *w; // packed: fp16 [Cout][16 taps][4] (taps 9..15 and channel 3 zero), fp32 [Cout][9][4]
     const float *bias;
     void *out; // [N][H/2][W/2][Cout]
     int Cout;
