@@ -86,7 +86,7 @@ template <int NV> __device__ __forceinline__ void store_run(float *p, const floa
     for (int i = 0; i < NV; i += 4) *reinterpret_cast<float4 *>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
 }
 
-template <typename T, int BM, int BN, int WAVES_P, int WAVES_C>
+template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int CE = Elem<T>::CE;
     constexpr int BKE = 8 * CE; // K elements per step = one 128-byte row
@@ -106,153 +106,182 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_p = wave / WAVES_C;
     const int wave_c = wave % WAVES_C;
+    const int lr = lane & 15, lg = lane >> 4;
 
-    // ---- XCD-aware bijective remap: consecutive logical tiles share an XCD (and its L2)
-    const int nwg = gridDim.x;
-    int L;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+    // ---- persistent tile schedule.  Tiles (pixel tile major, cout tile minor) are cut into 8 contiguous
+    // ranges, one per XCD label (blockIdx % 8 names the blocks that share an XCD and its L2 — a speed
+    // heuristic only); the blocks of a label walk their range with stride = #blocks of that label, so at
+    // any moment an XCD works on neighbouring tiles (shared 3x3 halos, shared weights).
     const int nct = a.CoutPad / BN;
-    const int ptile = L / nct;
-    const int n0 = (L % nct) * BN;
+    const int total_tiles = a.ptiles * nct;
+    int t_begin, my_tiles, t_stride;
+    {
+        const int G = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int nbx = (G - xcd + 7) >> 3;
+        const int q = total_tiles >> 3, r = total_tiles & 7;
+        const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int count = xcd < r ? q + 1 : q;
+        t_begin = first + slot;
+        t_stride = nbx;
+        my_tiles = slot < count ? (count - slot + nbx - 1) / nbx : 0;
+    }
+    if (my_tiles == 0) return;
 
     const int HoWo = a.Ho * a.Wo;
     const int tile_h = a.tile_w > 0 ? BM / a.tile_w : 0;
     const int tpi = a.tiles_x * a.tiles_y;
 
-    auto pixel_coords = [&](int p, int &n, int &ho, int &wo) -> bool {
+    auto pixel_coords = [&](int ptile, int p, int &n, int &ho, int &wo) __attribute__((always_inline)) -> bool {
         if (a.tile_w == 0) {
-            long long m = (long long)ptile * BM + p;
-            if (m >= a.M) return false;
-            n = (int)(m / HoWo);
-            int rem = (int)(m - (long long)n * HoWo);
-            ho = rem / a.Wo;
-            wo = rem - ho * a.Wo;
+            const long long m64 = (long long)ptile * BM + p;
+            if (m64 >= a.M) return false;
+            const unsigned m = (unsigned)m64;
+            n = (int)fdiv(m, a.d_howo);
+            const unsigned rem = m - (unsigned)n * (unsigned)HoWo;
+            ho = (int)fdiv(rem, a.d_wo);
+            wo = (int)(rem - (unsigned)ho * (unsigned)a.Wo);
             return true;
         } else {
-            n = ptile / tpi;
-            int t = ptile - n * tpi;
-            int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-            int py = p / a.tile_w, px = p - py * a.tile_w;
-            ho = ty * tile_h + py;
-            wo = tx * a.tile_w + px;
+            n = (int)fdiv((unsigned)ptile, a.d_tpi);
+            const unsigned t = (unsigned)ptile - (unsigned)n * (unsigned)tpi;
+            const unsigned ty = fdiv(t, a.d_tilesx), tx = t - ty * (unsigned)a.tiles_x;
+            const unsigned py = fdiv((unsigned)p, a.d_tilew), px = (unsigned)p - py * (unsigned)a.tile_w;
+            ho = (int)(ty * tile_h + py);
+            wo = (int)(tx * a.tile_w + px);
             return ho < a.Ho && wo < a.Wo;
         }
     };
 
-    // ---- staging assignment: thread -> 16-byte chunk `ch` of rows r0 + 32*i
+    // ---- staging assignment: thread -> 16-byte physical chunk `ch` of rows r0 + 32*i.
+    // LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 8 rows x 128 B of the LDS image
+    // linearly (dest = wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
+    // chunk: the lane that lands on physical chunk p of row r fetches logical chunk p ^ key(r).  Rows
+    // r0 + 32*i of one thread share key(r) for the pixel tile (key = r & 7), so the thread's logical K
+    // chunk — and with it its (tap, channel) walk — is the same for all its rows.  Out-of-image taps /
+    // ragged rows fetch from a zero page instead of being predicated (an inactive lane would leave stale
+    // LDS bytes behind).
     const int ch = tid & 7;
     const int r0 = tid >> 3;
+    const int lchunk = ch ^ (r0 & 7);
     const T *in = reinterpret_cast<const T *>(a.in);
-    const T *wgt = reinterpret_cast<const T *>(a.w);
+    const char *zero_page = reinterpret_cast<const char *>(a.zeros);
+    const int ntaps = a.KH * a.KW;
+    const int nk = a.Kpad / BKE;
 
-    long long pbase[PR]; // element offset of the (hi0, wi0) input pixel of each staged row
-    int phi0[PR], pwi0[PR];
-#pragma unroll
-    for (int i = 0; i < PR; ++i) {
-        int n, ho, wo;
-        bool ok = pixel_coords(r0 + 32 * i, n, ho, wo);
-        if (ok) {
-            phi0[i] = ho * a.stride - a.pad;
-            pwi0[i] = wo * a.stride - a.pad;
-            pbase[i] = (((long long)n * a.H + phi0[i]) * a.W + pwi0[i]) * a.in_ld + a.in_coff;
-        } else {
-            phi0[i] = -(1 << 28); // fails every bounds test below
-            pwi0[i] = -(1 << 28);
-            pbase[i] = 0;
-        }
-    }
-    const T *wrow[WR];
+    unsigned wvoff[WR]; // per-lane byte offset inside a [BN][Kpad] weight slab, loop invariant
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
         const int row = r0 + 32 * i;
         const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
-        wrow[i] = wgt + (long long)(n0 + row) * a.Kpad + (ch ^ key) * CE;
+        wvoff[i] = (unsigned)(((long long)row * a.Kpad + (ch ^ key) * CE) * (long long)sizeof(T));
     }
 
-    // running (tap, c) of this thread's logical pixel chunk
-    int kc = (ch ^ (r0 & 7)) * CE; // channel within the tap
-    int tap = 0;
-    while (kc >= a.Cin) {
-        kc -= a.Cin;
-        ++tap;
-    }
-    const int ntaps = a.KH * a.KW;
-
-    // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction fills 8 rows x 128 B of the LDS
-    // image linearly (dest = wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane
-    // SOURCE chunk instead: the lane that lands on physical chunk p of row r fetches logical chunk
-    // p ^ key(r).  Rows r0 + 32*i of one thread share key(r) for the pixel tile (key = r & 7), so the
-    // thread's logical K chunk — and with it its (tap, channel) walk — is the same for all its rows.
-    // Out-of-image taps / ragged rows fetch from a zero page instead of being predicated (an inactive
-    // lane would leave stale LDS bytes behind).
-    const char *zero_page = reinterpret_cast<const char *>(a.zeros);
-    auto issue_stage = [&](int ks, char *pt) {
+    // loader state: the tile / K step being staged runs one stage ahead of the tile being computed
+    long long pbase[PR]; // element offset of the (hi0, wi0) input pixel of each staged row (-1: no pixel)
+    int phi0[PR], pwi0[PR];
+    const char *wslab = nullptr; // wave-uniform
+    int kc = 0, tap = 0, ld_ks = 0, ld_i = 0;
+    auto setup_loader = [&](int i) __attribute__((always_inline)) {
+        const int tile = t_begin + i * t_stride;
+        const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
+        const int n0 = (tile - ptile * nct) * BN;
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            int n, ho, wo;
+            const bool ok = pixel_coords(ptile, r0 + 32 * r, n, ho, wo);
+            if (K1) {
+                pbase[r] = ok ? (((long long)n * a.H + ho) * a.W + wo) * a.in_ld + a.in_coff + lchunk * CE : -1;
+            } else if (ok) {
+                phi0[r] = ho * a.stride - a.pad;
+                pwi0[r] = wo * a.stride - a.pad;
+                pbase[r] = (((long long)n * a.H + phi0[r]) * a.W + pwi0[r]) * a.in_ld + a.in_coff;
+            } else {
+                phi0[r] = -(1 << 28); // fails every bounds test below
+                pwi0[r] = -(1 << 28);
+                pbase[r] = 0;
+            }
+        }
+        wslab = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.w) + (long long)n0 * a.Kpad);
+        kc = lchunk * CE;
+        tap = 0;
+        if (!K1)
+            while (kc >= a.Cin) {
+                kc -= a.Cin;
+                ++tap;
+            }
+        ld_ks = 0;
+    };
+    auto issue_stage = [&](char *pt) __attribute__((always_inline)) {
         char *wt = pt + BM * 128;
-        int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const bool tap_ok = tap < ntaps;
-        const long long delta = ((long long)kh * a.W + kw) * a.in_ld + kc;
+        if (K1) {
+            const bool k_ok = kc < a.Cin; // K tail of the last step is zero
 #pragma unroll
-        for (int i = 0; i < PR; ++i) {
-            const int hi = phi0[i] + kh, wi = pwi0[i] + kw;
-            const bool ok = tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const char *src = ok ? reinterpret_cast<const char *>(in + pbase[i] + delta) : zero_page;
-            char *dst = pt + (32 * i + 8 * wave) * 128; // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
+            for (int r = 0; r < PR; ++r) {
+                const char *src = (k_ok && pbase[r] >= 0) ? reinterpret_cast<const char *>(in + pbase[r] + ld_ks * BKE) : zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(pt + (32 * r + 8 * wave) * 128), 16, 0, 0);
+            }
+        } else {
+            const int kh = a.KW == 3 ? (tap * 11) >> 5 : tap / a.KW, kw = tap - kh * a.KW; // tap/3 for tap < 32
+            const bool tap_ok = tap < ntaps;
+            const long long delta = ((long long)kh * a.W + kw) * a.in_ld + kc;
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const char *src = reinterpret_cast<const char *>(wrow[i] + (long long)ks * BKE);
-            char *dst = wt + (32 * i + 8 * wave) * 128;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            for (int r = 0; r < PR; ++r) {
+                const int hi = phi0[r] + kh, wi = pwi0[r] + kw;
+                const bool ok = tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const char *src = ok ? reinterpret_cast<const char *>(in + pbase[r] + delta) : zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(pt + (32 * r + 8 * wave) * 128), 16, 0, 0);
+            }
         }
+        const char *ub = wslab + (size_t)ld_ks * (BKE * sizeof(T));
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + wvoff[i]),
+                                             (__attribute__((address_space(3))) void *)(wt + (32 * i + 8 * wave) * 128), 16, 0, 0);
+        // advance the loader; crossing into the next tile recomputes the row table
         kc += BKE;
-        while (kc >= a.Cin) {
-            kc -= a.Cin;
-            ++tap;
+        if (!K1)
+            while (kc >= a.Cin) {
+                kc -= a.Cin;
+                ++tap;
+            }
+        if (++ld_ks == nk) {
+            if (++ld_i < my_tiles) setup_loader(ld_i);
         }
     };
 
     floatx4 acc[TC][TP];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
 
-    const int lr = lane & 15, lg = lane >> 4;
-    // fragment row addresses (bytes within a tile), constant over K
-    int poff[TP], pkey[TP], woff[TC], wkey[TC];
-#pragma unroll
-    for (int t = 0; t < TP; ++t) {
-        const int row = wave_p * WP + t * 16 + lr;
-        poff[t] = row * 128;
-        pkey[t] = row & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < TC; ++t) {
-        const int row = wave_c * WC + (lr >> 2) * NV + t * 4 + (lr & 3);
-        woff[t] = row * 128;
-        wkey[t] = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
-    }
+    // fragment addresses: pixel tiles j are base + j*2048 (same swizzle key), cout tiles i are
+    // base + i*512 (key independent of i); the second k-half is base ^ 64.
+    const int prow_l = wave_p * WP + lr;
+    const unsigned pfrag0 = prow_l * 128 + ((lg ^ (prow_l & 7)) << 4);
+    const int wrow_l = wave_c * WC + (lr >> 2) * NV + (lr & 3);
+    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
+    const unsigned wfrag0 = BM * 128 + wrow_l * 128 + ((lg ^ wkey_l) << 4);
 
-    auto compute_stage = [&](const char *pt) {
-        const char *wt = pt + BM * 128;
+    auto compute_stage = [&](const char *pt) __attribute__((always_inline)) {
 #pragma unroll
         for (int kh2 = 0; kh2 < 2; ++kh2) {
-            const int chunk = lg + 4 * kh2;
+            const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
+            const unsigned wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
             uint4 pf[TP], wf[TC];
 #pragma unroll
-            for (int t = 0; t < TP; ++t) pf[t] = *reinterpret_cast<const uint4 *>(pt + poff[t] + ((chunk ^ pkey[t]) << 4));
+            for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(pt + pa + j * 2048);
 #pragma unroll
-            for (int t = 0; t < TC; ++t) wf[t] = *reinterpret_cast<const uint4 *>(wt + woff[t] + ((chunk ^ wkey[t]) << 4));
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(pt + wa + i * 512);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -260,60 +289,78 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    const int nk = a.Kpad / BKE;
-    issue_stage(0, smem0);
-    __syncthreads(); // drains the LDS-DMA (vmcnt(0)) and publishes the tile
-    for (int ks = 0; ks < nk; ks += 2) {
-        // even step: compute smem0 while the DMA fills smem1 (last read before the previous barrier)
-        if (ks + 1 < nk) issue_stage(ks + 1, smem1);
-        compute_stage(smem0);
-        __syncthreads();
-        if (ks + 1 >= nk) break;
-        if (ks + 2 < nk) issue_stage(ks + 2, smem0);
-        compute_stage(smem1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane (pixel lr of tile j, group lg) owns couts cb .. cb+NV-1
-    const int cb = n0 + wave_c * WC + lg * NV;
-    if (cb + NV > a.Cout) return; // padded output channels (Cout < CoutPad) are never stored
-    float bias[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
+    // ---- epilogue of one finished tile: lane (pixel lr of tile j, group lg) owns couts cb .. cb+NV-1
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
     const T *res = reinterpret_cast<const T *>(a.res);
+    auto epilogue = [&](int i) __attribute__((always_inline)) {
+        const int tile = t_begin + i * t_stride;
+        const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
+        const int cb = (tile - ptile * nct) * BN + wave_c * WC + lg * NV;
+        if (cb + NV <= a.Cout) { // padded output channels (Cout < CoutPad) are never stored
+            float bias[NV];
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        int n, ho, wo;
-        if (!pixel_coords(wave_p * WP + j * 16 + lr, n, ho, wo)) continue;
-        float v[NV];
+            for (int e = 0; e < NV; ++e) bias[e] = a.bias[cb + e];
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
+            for (int j = 0; j < TP; ++j) {
+                int n, ho, wo;
+                if (!pixel_coords(ptile, wave_p * WP + j * 16 + lr, n, ho, wo)) continue;
+                float v[NV];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
-        if (a.act) {
+                for (int t = 0; t < TC; ++t)
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = silu_f(v[i]);
-        }
-        const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
-        if (res) {
-            float rv[NV];
-            load_run<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + bias[t * 4 + r];
+                if (a.act) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] += rv[i];
-        }
-        store_run<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
-        if (out2) {
-            const int Ho2 = a.Ho * 2, Wo2 = a.Wo * 2;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const long long pix2 = ((long long)n * Ho2 + (2 * ho + dy)) * Wo2 + (2 * wo + dx);
-                    store_run<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
+                    for (int e = 0; e < NV; ++e) v[e] = silu_f(v[e]);
                 }
+                const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+                if (res) {
+                    float rv[NV];
+                    load_run<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) v[e] += rv[e];
+                }
+                store_run<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
+                if (out2) {
+                    const int Ho2 = a.Ho * 2, Wo2 = a.Wo * 2;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const long long pix2 = ((long long)n * Ho2 + (2 * ho + dy)) * Wo2 + (2 * wo + dx);
+                            store_run<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
+                        }
+                }
+            }
         }
+        zero_acc();
+    };
+
+    // ---- flat pipeline over (tile, K step) stages: stage s+1 is in flight (LDS-DMA) while stage s is
+    // multiplied and, at a tile's last K step, its epilogue runs — so the next tile's loads hide behind it.
+    const int total_stages = my_tiles * nk;
+    int cp_ks = 0, cp_i = 0;
+    auto after_compute = [&]() __attribute__((always_inline)) {
+        if (++cp_ks == nk) {
+            epilogue(cp_i);
+            cp_ks = 0;
+            ++cp_i;
+        }
+    };
+    setup_loader(0);
+    issue_stage(smem0);
+    __syncthreads(); // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+    for (int s = 0; s < total_stages; s += 2) {
+        if (s + 1 < total_stages) issue_stage(smem1); // smem1 was last read before the previous barrier
+        compute_stage(smem0);
+        after_compute();
+        __syncthreads();
+        if (s + 1 >= total_stages) break;
+        if (s + 2 < total_stages) issue_stage(smem0);
+        compute_stage(smem1);
+        after_compute();
+        __syncthreads();
     }
 }
 
@@ -322,16 +369,38 @@ int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x64 
 
 hipError_t conv_init_attributes() { return hipSuccess; } // LDS is static: nothing to raise
 
+static int g_num_cus = 0;
+
 template <typename T, int BM, int BN, int WAVES_P, int WAVES_C>
-static hipError_t launch_t(const ConvArgs &a, hipStream_t stream) {
+static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     long long ptiles;
     if (a.tile_w == 0)
         ptiles = (a.M + BM - 1) / BM;
     else
         ptiles = (long long)a.N * a.tiles_x * a.tiles_y;
-    const long long blocks = ptiles * (a.CoutPad / BN);
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    const long long tiles = ptiles * (a.CoutPad / BN);
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.ptiles = (int)ptiles;
+    if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.d_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.d_wo = make_fastdiv((unsigned)a.Wo);
+    a.d_tilew = make_fastdiv((unsigned)(a.tile_w > 0 ? a.tile_w : 1));
+    a.d_tilesx = make_fastdiv((unsigned)(a.tiles_x > 0 ? a.tiles_x : 1));
+    a.d_tpi = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y > 0 ? a.tiles_x * a.tiles_y : 1));
+    a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    const long long resident = 2LL * g_num_cus; // 2 blocks of 256 threads per CU (LDS 64-80 KB each)
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (k1)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true>), dim3(grid), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, false>), dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

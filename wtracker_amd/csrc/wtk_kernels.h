@@ -6,6 +6,33 @@
 
 namespace wtk {
 
+// Unsigned division by a launch-invariant divisor (Granlund-Montgomery / libdivide branch-free form):
+// q = (t + ((n - t) >> 1)) >> sh with t = umulhi(n, mul).  Exact for every 32-bit n; ~5 VALU ops instead of
+// the ~25-instruction software division hipcc emits for n / d with a runtime d.
+struct FastDiv {
+    unsigned mul, sh, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) {
+        f.mul = 0;
+        f.sh = 0;
+        return f;
+    }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l; // ceil(log2 d)
+    const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    f.mul = (unsigned)m;
+    f.sh = l - 1;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
+    if (f.d == 1) return n;
+    const unsigned t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> 1)) >> f.sh;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip).  Activations are NHWC; a tensor argument is a
 // *channel-slice view* (base pointer, pixel stride `ld` in elements, first channel `coff`), so
@@ -32,6 +59,8 @@ struct ConvArgs {
     int tile_w; // 0: linear pixel order over N*Ho*Wo; >0: 2-D pixel tiles tile_w x (BM/tile_w)
     int tiles_x, tiles_y;
     long long M; // N*Ho*Wo
+    int ptiles;  // pixel tiles (filled by launch_conv)
+    FastDiv d_howo, d_wo, d_tilew, d_tilesx, d_tpi, d_nct; // filled by launch_conv
     const void *zeros; // >= 16 zero bytes in device memory (source of padded / out-of-range chunks)
 };
 
