@@ -71,3 +71,41 @@ def movement_vector(state: dict, boxes7: np.ndarray, cam_position, max_dist_per_
     pred = forward(state, boxes.astype(np.float32)).flatten()
     pred = np.clip(pred, -max_dist_per_pred, max_dist_per_pred)
     return round(pred[0].item() + rel_x), round(pred[1].item() + rel_y)
+
+
+# ---- plain-C twin (oracle/resmlp_oracle.c), built by `make -C oracle` -----------------------------
+def c_forward(state: dict, x: np.ndarray) -> np.ndarray:
+    import ctypes as C
+    import os
+
+    lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libresmlp_oracle.so")
+    lib = C.CDLL(lib_path)
+
+    class Desc(C.Structure):
+        _fields_ = [("in_dim", C.c_int), ("out_dim", C.c_int), ("has_bn", C.c_int)]
+
+    sd = state["sd"]
+    prefixes = ["model.input.mlp_layer"]
+    n_blocks = len({int(m.group(1)) for k in sd for m in [re.match(r"model\.blocks\.(\d+)\.", k)] if m})
+    per_block = 0
+    while f"model.blocks.0.sequence.{per_block}.mlp_layer.0.weight" in sd:
+        per_block += 1
+    for b in range(n_blocks):
+        for l in range(per_block):
+            prefixes.append(f"model.blocks.{b}.sequence.{l}.mlp_layer")
+    descs, blob = [], []
+    for p in prefixes:
+        w = sd[p + ".0.weight"].astype(np.float32)
+        descs.append((w.shape[1], w.shape[0], 1))
+        blob += [w.ravel(), sd[p + ".0.bias"], sd[p + ".1.weight"], sd[p + ".1.bias"], sd[p + ".1.running_mean"], sd[p + ".1.running_var"]]
+    w = sd["model.output.weight"].astype(np.float32)
+    descs.append((w.shape[1], w.shape[0], 0))
+    blob += [w.ravel(), sd["model.output.bias"]]
+    params = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float32).ravel() for a in blob]))
+    arr = (Desc * len(descs))(*[Desc(*d) for d in descs])
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty((x.shape[0], descs[-1][1]), dtype=np.float32)
+    rc = lib.resmlp_forward(arr, n_blocks, per_block, params.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), x.shape[0],
+                            y.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return y

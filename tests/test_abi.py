@@ -1,0 +1,63 @@
+"""CPU-only checks of the drop-in boundary: libwtk_hip.so builds, loads, exports every symbol that
+include/wtk_hip.h declares, and its own conv table equals the Python-side spec.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from wtracker_amd import hip
+from wtracker_amd import yolo_spec as ys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "wtk_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wtk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_agree():
+    assert header_symbols() == sorted(hip.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for name in header_symbols():
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.wtk_abi_version() == 1
+    assert hip_lib.wtk_last_error() is not None
+    assert hip_lib.wtk_device_count() >= 0
+
+
+@pytest.mark.parametrize("scale,nc", [("n", 1), ("s", 1), ("s", 80), ("m", 3)])
+def test_conv_table_matches_python_spec(hip_lib, scale, nc):
+    w, d, m = ys.scale_params(scale)
+    assert hip.yolo_conv_table(w, d, m, nc) == ys.conv_table(scale, nc)
+
+
+def test_bad_scale_is_reported(hip_lib):
+    assert hip_lib.wtk_yolo_conv_count(ctypes.c_float(0.0), ctypes.c_float(0.33), 1024, 1) == -1
+    with pytest.raises(hip.WtkError):
+        hip.yolo_conv_table(0.5, 0.33, 1024, 0)
+
+
+def test_product_path_fails_loudly_without_gpu(hip_lib):
+    """No CPU fallback: with no visible device every create call must raise, never compute."""
+    if hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import numpy as np
+
+    with pytest.raises(hip.WtkError, match="GPU"):
+        hip.HipMLP([(np.zeros((2, 28), np.float32), np.zeros(2, np.float32), False)] * 2, 0, 0)
+    with pytest.raises(hip.WtkError, match="GPU"):
+        hip.HipYolo(ys.synthetic_weights("n", 1), (64, 64), 1, width=0.25)
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "wtracker_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

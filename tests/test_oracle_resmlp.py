@@ -55,3 +55,15 @@ def test_folded_model_structure_and_values(golden_dir, tag, shape):
         h = h + t
     y = h @ m.layers[-1][0].T + m.layers[-1][1]
     np.testing.assert_allclose(y, z["y_batch"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("tag", ["100ms", "200ms"])
+def test_plain_c_oracle_matches_reference_outputs(golden_dir, tag):
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle")], check=True)
+    path = os.path.join(golden_dir, f"resmlp_{tag}.npz")
+    z = np.load(path)
+    y = resmlp_oracle.c_forward(resmlp_oracle.load_state(path), z["x"])
+    np.testing.assert_allclose(y, z["y_batch"], rtol=RTOL, atol=ATOL)

@@ -1,0 +1,91 @@
+"""Self-checks that pin the YOLOv8 restatement (oracle/yolo_oracle.py) without an external oracle
+(ultralytics is not available: parity unpinned) and the detector spec.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo_oracle as yo
+from wtracker_amd import frames as fr
+from wtracker_amd import yolo_spec as ys
+
+
+def test_public_model_card_numbers():
+    assert len(ys.conv_table("s", 1)) == 63
+    assert sum(1 for t in ys.conv_table("s", 1) if t["act"]) == 57
+    assert ys.num_params("s", 80) == 11_166_560  # ultralytics YOLOv8s, 80 classes
+    assert abs(ys.macs_per_frame("s", 80, 640, 640) * 2 / 1e9 - 28.6) < 0.05  # 28.6 GFLOPs model card
+    assert abs(ys.macs_per_frame("s", 1, 640, 640) / 1e9 - 14.216) < 1e-3
+    assert abs(ys.macs_per_frame("s", 1, 1280, 1280) * 2 / 1e9 - 113.727) < 1e-3
+    assert abs(ys.macs_per_frame("s", 1, 384, 384) * 2 / 1e9 - 10.235) < 1e-3
+
+
+def test_letterbox_geometry():
+    assert yo.letterbox_geometry(640, 640, 640) == (640, 640, 640, 640, 0, 0)  # identity
+    assert yo.letterbox_geometry(360, 360, 384) == (384, 384, 384, 384, 0, 0)  # the reference's real case
+    assert yo.letterbox_geometry(480, 640, 640)[:4] == (480, 640, 480, 640)    # auto=True: minimal stride-32 pad
+    assert ys.letterbox_shape(480, 640, 640) == (480, 640) and ys.letterbox_shape(360, 360, 384) == (384, 384)
+    net_h, net_w, new_h, new_w, top, left = yo.letterbox_geometry(300, 500, 640)
+    assert (new_h, new_w) == (384, 640) and net_h % 32 == 0 and net_w % 32 == 0 and top >= 0
+
+
+def test_identity_preprocess_is_bgr_to_rgb_over_255():
+    f = np.random.default_rng(0).integers(0, 256, size=(2, 64, 64, 3), dtype=np.uint8)
+    x, hw = yo.preprocess(list(f), 64)
+    assert hw == (64, 64) and x.shape == (2, 3, 64, 64)
+    np.testing.assert_array_equal(x[0, 0].numpy(), f[0, :, :, 2].astype(np.float32) / 255)  # R plane <- BGR[2]
+    g = f[..., 0]
+    xg, _ = yo.preprocess(list(g), 64)
+    assert (xg[:, 0] == xg[:, 1]).all() and (xg[:, 1] == xg[:, 2]).all()
+
+
+def test_zero_box_head_gives_15_stride_boxes():
+    size = 128
+    A = (size // 8) ** 2 + (size // 16) ** 2 + (size // 32) ** 2
+    box = torch.zeros(1, A, 64)
+    cls = torch.full((1, A, 1), -9.0)
+    idx = (size // 8) ** 2 + 5 * (size // 16) + 3  # level-1 anchor (x=3, y=5): centre (56, 88), stride 16
+    cls[0, idx, 0] = 4.0
+    xywh, conf, anchor = yo.postprocess(box, cls, (size, size), (size, size), conf=0.25)
+    assert anchor[0] == idx
+    np.testing.assert_allclose(xywh[0], [0.0, 0.0, 128.0, 128.0], atol=1e-4)  # 15*16 = 240 wide, clipped to the image
+    cls[0, idx, 0] = -9.0
+    idx0 = 8 * (size // 8) + 8  # level-0 anchor (8, 8): centre (68, 68), stride 8 -> 120 x 120 box
+    cls[0, idx0, 0] = 4.0
+    xywh, _, anchor = yo.postprocess(box, cls, (size, size), (size, size), conf=0.25)
+    np.testing.assert_allclose(xywh[0], [8.0, 8.0, 120.0, 120.0], atol=1e-4)
+
+
+def test_nms_general_path_and_ties():
+    xywh = torch.tensor([[50, 50, 20, 20], [51, 50, 20, 20], [100, 100, 10, 10], [50, 50, 20, 20]], dtype=torch.float32)
+    scores = torch.tensor([[0.9], [0.8], [0.7], [0.9]])
+    b, s, c, idx = yo.nms(xywh, scores, conf=0.1, iou=0.7, max_det=300)
+    assert idx.tolist() == [0, 2]  # 1 and 3 overlap 0; tie 0/3 resolves to the lower index
+    b, s, c, idx = yo.nms(xywh, scores, conf=0.1, iou=0.7, max_det=1)
+    assert idx.tolist() == [0]
+    b, s, c, idx = yo.nms(xywh, scores, conf=0.95, iou=0.7, max_det=1)
+    assert len(idx) == 0
+
+
+def test_controller_output_conventions():
+    w = ys.synthetic_weights("n", 1, seed=0)
+    m = yo.YoloOracle(w, ys.model_dims(0.25, 0.33, 1024, 1))
+    f, _ = fr.synthetic_frames(3, 96, seed=5)
+    out = yo.predict(m, list(f), imgsz=96, conf=0.1)[0]
+    assert out.shape == (3, 4)
+    none = yo.predict(m, list(f), imgsz=96, conf=0.9999)[0]
+    assert none.dtype == np.float64 and np.isnan(none).all()  # NaN rows are float64 (yolo_controller.py:85)
+    with pytest.raises(AssertionError):
+        yo.predict(m, [], imgsz=96)
+
+
+def test_synthetic_weights_are_deterministic_and_scaled():
+    a = ys.synthetic_weights("n", 1, seed=3)
+    b = ys.synthetic_weights("n", 1, seed=3)
+    assert all((a[k][0] == b[k][0]).all() and (a[k][1] == b[k][1]).all() for k in a)
+    assert abs(a["model.22.cv3.1.2"][1][0] - np.log(5 / 1 / (640 / 16) ** 2)) < 1e-6
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "w.bin")
+        ys.save_weights(p, a, "n", 1)
+        c, nc = ys.load_weights(p)
+        assert nc == 1 and all((a[k][0] == c[k][0]).all() for k in a)
