@@ -28,26 +28,34 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(weights, dims, size: int, n_frames: int, folded_path: str) -> dict:
-    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload, all host cores."""
+def cpu_baseline(weights, dims, size: int, n_frames: int, batch: int, folded_path: str) -> dict:
+    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload.  Thread count:
+    the torch-CPU conv stack peaks near 32 threads on the GPU box's host (8: 14.8, 16: 18.3, 32: 19.2,
+    64: 11.4, 128: 5.9 frames/s measured with tools/cpu_threads_probe.py), so min(cores, 32) is used."""
     from oracle import resmlp_oracle
     from oracle import yolo_oracle as yo
     from wtracker_amd import frames as fr
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     model = yo.YoloOracle(weights, dims)
-    frames, _ = fr.synthetic_frames(n_frames, size, seed=1)
+    frames, _ = fr.synthetic_frames(min(n_frames, 2 * batch), size, seed=1)
     st = resmlp_oracle.load_state(folded_path)
     yo.predict(model, list(frames[:2]), imgsz=size)  # warm-up
     t0 = time.perf_counter()
-    xywh, _, _ = yo.predict(model, list(frames), imgsz=size)
+    done = 0
+    while done < n_frames:
+        b = min(batch, n_frames - done)
+        off = done % max(len(frames) - b + 1, 1)
+        yo.predict(model, list(frames[off : off + b]), imgsz=size)
+        done += b
     # ResMLP over the sample's cycles (one sample per 9 frames)
     x = np.zeros((max(n_frames // 9, 1), 28), dtype=np.float32)
     resmlp_oracle.forward(st, x)
     dt = time.perf_counter() - t0
     return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} synthetic {size}x{size} frames, one batch, torch-CPU fp32 restatement (oracle/yolo_oracle.py) + numpy ResMLP, {dt:.1f} s"}
+            "sample": f"{n_frames} synthetic {size}x{size} frames in batches of {batch}, torch-CPU fp32 restatement "
+                      f"(oracle/yolo_oracle.py) + numpy ResMLP, {cores} threads, {dt:.1f} s"}
 
 
 def main():
@@ -59,8 +67,10 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel-class HIP-event timing")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank path on a one-GPU box, where every rank then shares cuda:0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,6 +88,8 @@ def main():
 
     if _build.needs_build() and rank == 0:
         _build.build(verbose=False)
+    if args.backend != "nccl" and torch.cuda.device_count() <= local_rank:
+        local_rank = 0  # rehearsal: ranks share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -85,7 +97,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
         dist.barrier()
     if hip.device_count() <= local_rank:
         raise SystemExit("no HIP device visible: the product path has no CPU fallback")
@@ -181,7 +196,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and args.cpu_frames > 0:
-        out["cpu_baseline"] = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, args.cpu_frames, golden)
+        out["cpu_baseline"] = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, args.cpu_frames, args.batch, golden)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
