@@ -177,3 +177,72 @@ def test_full_size_640_matches_oracle(hip_lib, dtype, B):
         assert err < F16_LOGIT_ATOL
         xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (size, size), hw, conf=0.1)
         np.testing.assert_array_equal(anchor, anchor_s)
+
+
+def test_letterbox_360_to_384_like_the_reference_workflow(hip_lib):
+    """The reference's real shapes: 360x360 camera crops letterboxed to imgsz 384
+    (initialize_experiment.ipynb cell 9): device letterbox == the restated cv2 bilinear, end to end."""
+    oracle, det = _models("n", 384, "fp32", max_batch=2)
+    frames, _ = fr.synthetic_frames(2, 360, seed=21)
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(frames), 384)
+        assert tuple(x.shape[2:]) == (384, 384) and hw == (360, 360)
+        box_o, cls_o = oracle.forward(x)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+    box_g, cls_g = det.debug_head(2)
+    np.testing.assert_allclose(cls_g, cls_o.numpy(), rtol=1e-3, atol=F32_LOGIT_ATOL)
+    xywh_o, conf_o, anchor_o = yo.postprocess(box_o, cls_o, (384, 384), hw, conf=0.1)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=F32_BOX_ATOL)
+    assert (xywh[anchor >= 0, 0] + xywh[anchor >= 0, 2] <= 360 + 1e-3).all()  # boxes are in input-image pixels, clipped
+
+
+def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib, tmp_path):
+    """Rows a9/a10: the controller API (on_camera_frame ring buffer, provide_movement_vector on
+    deque[-pred_frame_num], _cycle_predict_all batch) driven by the harness exactly as Simulator.run does;
+    integer platform moves and every logged box equal to the CPU-restatement controller's."""
+    from oracle.controllers_oracle import OracleYoloController
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ArrayReader, ExperimentConfig, Simulator, TimingConfig, TrackLogger
+
+    w = ys.synthetic_weights("n", 1, seed=0)
+    path = str(tmp_path / "n.wtk")
+    ys.save_weights(path, w, "n", 1)
+    frames, _ = fr.synthetic_frames(40, 256, seed=8)
+    ec = ExperimentConfig("synthetic", 40, 60, (256, 256), 32, (128, 128))
+    tc_args = (100, 40, 50, (4, 4), (0.5, 0.5))  # camera 128 px, cycle 9 frames
+
+    def run(make):
+        tc = TimingConfig(ec, *tc_args)
+        ctrl = make(tc)
+        moves = []
+        inner = ctrl.provide_movement_vector
+
+        def wrapped(sim):
+            m = inner(sim)
+            moves.append((int(m[0]), int(m[1])))
+            return m
+
+        ctrl.provide_movement_vector = wrapped
+        log = TrackLogger(ctrl)
+        Simulator(tc, ec, log, reader=ArrayReader(frames)).run()
+        return moves, log.rows
+
+    cfg = YoloConfig(model_path=path, device="cuda", pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="fp32", scale="n", max_batch=16)
+    oracle = yo.YoloOracle(w, ys.model_dims(0.25, 0.33, 1024, 1))
+    m_g, rows_g = run(lambda tc: HipYoloController(tc, cfg))
+    m_o, rows_o = run(lambda tc: OracleYoloController(tc, oracle, imgsz=128, conf=0.1))
+    assert m_g == m_o and len(m_g) == 4 and any(m != (0, 0) for m in m_g)
+    assert len(rows_g) == len(rows_o) == 36  # 4 full cycles; the trailing partial cycle is never logged
+    for a, b in zip(rows_g, rows_o):
+        assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
+        np.testing.assert_allclose([a["wrm_x"], a["wrm_y"], a["wrm_w"], a["wrm_h"]], [b["wrm_x"], b["wrm_y"], b["wrm_w"], b["wrm_h"]], atol=F32_BOX_ATOL)
+    # error behaviour mirrors the reference
+    ctrl = HipYoloController(TimingConfig(ec, *tc_args), cfg)
+    with pytest.raises(AssertionError):
+        ctrl.predict([])
+    cfg2 = YoloConfig(model_path=path, pred_kwargs={"imgsz": 128, "conf": 0.1, "max_det": 3}, dtype="fp32", scale="n")
+    with pytest.raises(TypeError, match="max_det"):
+        HipYoloController(TimingConfig(ec, *tc_args), cfg2).predict([frames[0, :128, :128]])
+    none = HipYoloController(TimingConfig(ec, *tc_args), YoloConfig(model_path=path, pred_kwargs={"imgsz": 128, "conf": 0.99999}, dtype="fp32", scale="n")).predict([frames[0, :128, :128]])
+    assert none.dtype == np.float64 and np.isnan(none).all()

@@ -3,8 +3,8 @@
 // DFL decode of the survivor (a6), scale_boxes + clip (a8) and xyxy -> xywh
 // (BoxConverter.to_xywh, wtracker/utils/bbox_utils.py:232-253).
 //
-// One block per image.  Every thread scans a strided share of the anchors keeping
-// (best logit, lowest anchor index); a wavefront butterfly over 64 lanes and a 4-wave LDS step
+// One 1024-thread block per image.  Every thread scans a strided share of the anchors keeping
+// (best logit, lowest anchor index); a wavefront butterfly over 64 lanes and a 16-wave LDS step
 // finish the reduction; only the surviving anchor's 64 DFL logits are decoded.
 #include "wtk_kernels.h"
 
@@ -21,14 +21,14 @@ __device__ __forceinline__ void better(float &s, int &i, float s2, int i2) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void head_select_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
     const int n = blockIdx.x;
     const int A0 = a.lh[0] * a.lw[0], A1 = a.lh[1] * a.lw[1], A2 = a.lh[2] * a.lw[2];
     const int A = A0 + A1 + A2;
 
     float best = -INFINITY;
     int best_i = 0x7fffffff;
-    for (int i = threadIdx.x; i < A; i += 256) {
+    for (int i = threadIdx.x; i < A; i += 1024) {
         int lvl, j;
         if (i < A0) {
             lvl = 0, j = i;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void head_select_kernel(const HeadArgs a) {
         const int i2 = __shfl_xor(best_i, off, 64);
         better(best, best_i, s2, i2);
     }
-    __shared__ float ws[4];
-    __shared__ int wi[4];
+    __shared__ float ws[16];
+    __shared__ int wi[16];
     if ((threadIdx.x & 63) == 0) {
         ws[threadIdx.x >> 6] = best;
         wi[threadIdx.x >> 6] = best_i;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void head_select_kernel(const HeadArgs a) {
     best = ws[0];
     best_i = wi[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) better(best, best_i, ws[w], wi[w]);
+    for (int w = 1; w < 16; ++w) better(best, best_i, ws[w], wi[w]);
 
     // score = sigmoid(logit) in fp32, candidate iff score > conf (non_max_suppression `xc`)
     const float score = 1.0f / (1.0f + expf(-best));
@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void head_select_kernel(const HeadArgs a) {
 hipError_t launch_head(const HeadArgs &a, int is_f16, hipStream_t stream) {
     if (a.N <= 0 || a.nc < 1 || a.cls_ld < a.nc) return hipErrorInvalidValue;
     if (is_f16)
-        hipLaunchKernelGGL((head_select_kernel<_Float16>), dim3(a.N), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((head_select_kernel<_Float16>), dim3(a.N), dim3(1024), 0, stream, a);
     else
-        hipLaunchKernelGGL((head_select_kernel<float>), dim3(a.N), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((head_select_kernel<float>), dim3(a.N), dim3(1024), 0, stream, a);
     return hipGetLastError();
 }
 
