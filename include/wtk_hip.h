@@ -160,6 +160,17 @@ int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors);
 int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled);
 int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches);
 
+/* ------------------------------------------------------------------------------------------
+ * Camera / microscope view extraction for a batch of (frame, platform position) pairs.
+ * Replaces: ViewController.camera_view / micro_view -> read() (cv.copyMakeBorder REPLICATE by
+ *           camera_size//2) + _custom_view slice   wtracker/sim/view_controller.py:45-61,143-181
+ * frames [N][H][W][C] uint8, pos_xy [N][2] int32 (x, y), views [N][view_w][view_h][C] — rows = w,
+ * cols = h exactly as the reference slices (view_controller.py:171); all DEVICE pointers.
+ * ------------------------------------------------------------------------------------------ */
+int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, int32_t C,
+                   const int32_t *pos_xy_dev, int32_t view_w, int32_t view_h, uint8_t *views_dev,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,3 +246,38 @@ def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib,
         HipYoloController(TimingConfig(ec, *tc_args), cfg2).predict([frames[0, :128, :128]])
     none = HipYoloController(TimingConfig(ec, *tc_args), YoloConfig(model_path=path, pred_kwargs={"imgsz": 128, "conf": 0.99999}, dtype="fp32", scale="n")).predict([frames[0, :128, :128]])
     assert none.dtype == np.float64 and np.isnan(none).all()
+
+
+def test_device_view_cropping_matches_view_controller(hip_lib):
+    """camera views cut on the device equal ViewController.camera_view (replicate-padded
+    frame, window centred on the platform position), including windows hanging over every border."""
+    from wtracker_amd.sim import ArrayReader, ViewController
+
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, size=(6, 90, 120), dtype=np.uint8)
+    pos = np.array([[0, 0], [119, 89], [60, 45], [3, 80], [118, 2], [30, 30]], dtype=np.int32)
+    cam = (36, 36)
+    vc = ViewController(ArrayReader(frames), camera_size=cam, micro_size=(9, 9))
+    expect = []
+    for i in range(len(frames)):
+        vc.seek(i)
+        vc.set_position(int(pos[i, 0]), int(pos[i, 1]))
+        expect.append(vc.camera_view())
+    f_dev = torch.from_numpy(frames).cuda()
+    p_dev = torch.from_numpy(pos).cuda()
+    out = torch.empty((6, cam[0], cam[1]), dtype=torch.uint8, device="cuda")
+    hip.crop_views(f_dev, 6, 90, 120, 1, p_dev, cam[0], cam[1], out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), np.stack(expect))
+    # colour frames + micro view
+    fc = rng.integers(0, 256, size=(6, 90, 120, 3), dtype=np.uint8)
+    vc = ViewController(ArrayReader(fc), camera_size=cam, micro_size=(9, 9))
+    expect = []
+    for i in range(len(fc)):
+        vc.seek(i)
+        vc.set_position(int(pos[i, 0]), int(pos[i, 1]))
+        expect.append(vc.micro_view())
+    out = torch.empty((6, 9, 9, 3), dtype=torch.uint8, device="cuda")
+    hip.crop_views(torch.from_numpy(fc).cuda(), 6, 90, 120, 3, p_dev, 9, 9, out)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), np.stack(expect))

@@ -89,3 +89,35 @@ def test_synthetic_weights_are_deterministic_and_scaled():
         ys.save_weights(p, a, "n", 1)
         c, nc = ys.load_weights(p)
         assert nc == 1 and all((a[k][0] == c[k][0]).all() for k in a)
+
+
+def test_converter_folding_round_trip():
+    """tools/convert_ultralytics.py: Conv2d+BatchNorm2d (eps 1e-3) folding of a synthetic un-fused state dict
+    equals running conv -> BN -> SiLU explicitly."""
+    import torch.nn.functional as F
+
+    from tools.convert_ultralytics import BN_EPS, fold_state_dict
+
+    rng = np.random.default_rng(0)
+    sd = {}
+    for t in ys.conv_table("n", 2):
+        shape = (t["cout"], t["cin"], t["k"], t["k"])
+        if t["act"]:
+            sd[t["name"] + ".conv.weight"] = rng.normal(0, 0.1, shape).astype(np.float32)
+            sd[t["name"] + ".bn.weight"] = rng.uniform(0.5, 1.5, t["cout"]).astype(np.float32)
+            sd[t["name"] + ".bn.bias"] = rng.normal(0, 0.1, t["cout"]).astype(np.float32)
+            sd[t["name"] + ".bn.running_mean"] = rng.normal(0, 0.1, t["cout"]).astype(np.float32)
+            sd[t["name"] + ".bn.running_var"] = rng.uniform(0.5, 1.5, t["cout"]).astype(np.float32)
+        else:
+            sd[t["name"] + ".weight"] = rng.normal(0, 0.1, shape).astype(np.float32)
+            sd[t["name"] + ".bias"] = rng.normal(0, 0.1, t["cout"]).astype(np.float32)
+    folded = fold_state_dict(sd, "n", 2)
+    nm = "model.2.m.0.cv1"
+    x = torch.randn(1, 16, 12, 12)
+    w, b = folded[nm]
+    y = F.conv2d(x, torch.from_numpy(w).permute(0, 3, 1, 2), torch.from_numpy(b), padding=1)
+    ref = F.conv2d(x, torch.from_numpy(sd[nm + ".conv.weight"]), None, padding=1)
+    ref = F.batch_norm(ref, torch.from_numpy(sd[nm + ".bn.running_mean"]), torch.from_numpy(sd[nm + ".bn.running_var"]),
+                       torch.from_numpy(sd[nm + ".bn.weight"]), torch.from_numpy(sd[nm + ".bn.bias"]), training=False, eps=BN_EPS)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=1e-5)
+    assert folded["model.22.cv3.1.2"][0].shape == (2, 1, 1, 64)

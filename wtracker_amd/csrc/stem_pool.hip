@@ -240,6 +240,37 @@ hipError_t launch_letterbox(const LetterboxArgs &a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Camera / microscope view extraction: ViewController._custom_view on a replicate-padded frame
+// (wtracker/sim/view_controller.py:45-61,143-172) for a batch of (frame, platform position) pairs.
+// The padding (camera_size//2, BORDER_REPLICATE) cancels against the window offset, so view pixel (r, c)
+// is frame pixel (clamp(pos_y - cols//2... see below).  The reference slices `rows = w` and `cols = h`
+// (view_controller.py:171); callers pass (rows, cols) explicitly.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_views_kernel(const CropArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.N * a.rows * a.cols;
+    if (idx >= total) return;
+    const int n = (int)(idx / ((long long)a.rows * a.cols));
+    const int rem = (int)(idx - (long long)n * a.rows * a.cols);
+    const int r = rem / a.cols, c = rem - r * a.cols;
+    const int px = a.pos_xy[2 * n], py = a.pos_xy[2 * n + 1];
+    // window origin in padded coordinates: pos + pad - size//2; minus pad again -> unpadded, then clamp
+    int y = py - a.view_h / 2 + r, x = px - a.view_w / 2 + c;
+    y = min(max(y, 0), a.H - 1);
+    x = min(max(x, 0), a.W - 1);
+    const uint8_t *s = a.frames + (((long long)n * a.H + y) * a.W + x) * a.C;
+    uint8_t *d = a.views + idx * a.C;
+    for (int k = 0; k < a.C; ++k) d[k] = s[k];
+}
+
+hipError_t launch_crop_views(const CropArgs &a, hipStream_t stream) {
+    if (a.N <= 0 || a.rows <= 0 || a.cols <= 0 || (a.C != 1 && a.C != 3)) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.rows * a.cols;
+    hipLaunchKernelGGL(crop_views_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // SPPF chained 5x5 max pools (stride 1, pad 2, implicit -inf padding as nn.MaxPool2d).
 // One block = one image x one 16-byte channel group; the whole map lives in LDS and each 5x5
 // pool runs as a separable row-max / column-max pair.  y1,y2,y3 are written back to their slices.

@@ -201,6 +201,24 @@ extern "C" int wtk_mlp_predict_track(wtk_mlp *h, const float *track_dev, int32_t
 }
 
 // =============================================================================================
+// View extraction
+// =============================================================================================
+extern "C" int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, int32_t C, const int32_t *pos_xy_dev,
+                              int32_t view_w, int32_t view_h, uint8_t *views_dev, void *stream) {
+    if (!frames_dev || !pos_xy_dev || !views_dev) return fail("wtk_crop_views: null argument");
+    if (N <= 0 || H <= 0 || W <= 0 || view_w <= 0 || view_h <= 0 || (C != 1 && C != 3)) return fail("wtk_crop_views: bad shape");
+    CropArgs a;
+    a.frames = frames_dev;
+    a.pos_xy = pos_xy_dev;
+    a.views = views_dev;
+    a.N = N, a.H = H, a.W = W, a.C = C;
+    a.view_w = view_w, a.view_h = view_h;
+    a.rows = view_w, a.cols = view_h; // frame[y : y + w, x : x + h], view_controller.py:171
+    HIP_TRY(launch_crop_views(a, (hipStream_t)stream));
+    return 0;
+}
+
+// =============================================================================================
 // YOLOv8
 // =============================================================================================
 namespace {

@@ -126,6 +126,16 @@ struct LetterboxArgs {
 };
 hipError_t launch_letterbox(const LetterboxArgs &a, hipStream_t stream);
 
+struct CropArgs {
+    const uint8_t *frames; // [N][H][W][C]
+    const int *pos_xy;     // [N][2] platform position (x, y)
+    uint8_t *views;        // [N][rows][cols][C]
+    int N, H, W, C;
+    int view_w, view_h;    // the (w, h) the reference passes to _custom_view
+    int rows, cols;        // rows = w, cols = h (reference quirk, identical for square views)
+};
+hipError_t launch_crop_views(const CropArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2) on a
 // channel slice of the SPPF concat buffer; x at channels [0,c), y_k at [k*c,(k+1)*c).

@@ -50,7 +50,7 @@ SYMBOLS = [
     "wtk_mlp_create", "wtk_mlp_destroy", "wtk_mlp_forward", "wtk_mlp_forward_host", "wtk_mlp_predict_track",
     "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
-    "wtk_yolo_set_profiling", "wtk_yolo_get_profile",
+    "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_crop_views",
 ]
 
 
@@ -90,6 +90,7 @@ def load() -> C.CDLL:
     lib.wtk_yolo_workload.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
     lib.wtk_yolo_set_profiling.argtypes = [vp, i32]
     lib.wtk_yolo_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.wtk_crop_views.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     _lib = lib
     return lib
 
@@ -118,6 +119,13 @@ def _ptr(x) -> C.c_void_p:
     if hasattr(x, "data_ptr"):
         return C.c_void_p(x.data_ptr())
     raise TypeError(f"cannot take a pointer of {type(x)}")
+
+
+def crop_views(frames_dev, N: int, H: int, W: int, Cc: int, pos_xy_dev, view_w: int, view_h: int, views_dev, stream: int = 0):
+    """Device-side ViewController.camera_view for a batch: views[n] = window of frames[n] centred on pos_xy[n]
+    with replicate borders.  All arguments are device tensors / pointers."""
+    _check(load().wtk_crop_views(_ptr(frames_dev), N, H, W, Cc, _ptr(pos_xy_dev), view_w, view_h, _ptr(views_dev),
+                                 C.c_void_p(stream)), "wtk_crop_views")
 
 
 # -------------------------------------------------------------------------------------------------
