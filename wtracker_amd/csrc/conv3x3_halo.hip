@@ -90,8 +90,10 @@ template <typename T, int BN, int NHALO, int MINW>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int CE = ElemH<T>::CE;
     constexpr int CCH = 8 * CE; // channels per 128-byte chunk
-    constexpr int WAVES_C = BN / 64, WAVES_P = 8 / WAVES_C;
-    constexpr int WP = kBM / WAVES_P, TP = WP / 16, TC = 4, NV = 16;
+    // BN = 64: 8(P) x 1(C) waves of 32 px x 64 cout; BN = 128 / 192: 4(P) x 2(C) waves of 64 px x 64 / 96 cout
+    constexpr int WAVES_C = BN == 64 ? 1 : 2, WAVES_P = 8 / WAVES_C;
+    constexpr int WC = BN / WAVES_C;
+    constexpr int WP = kBM / WAVES_P, TP = WP / 16, TC = WC / 16, NV = 4 * TC;
     constexpr int WR = BN / 64; // weight rows staged per thread per tap
 
     __shared__ __attribute__((aligned(16))) char halo0[kHaloBytes];
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 
     // weight fragments: row(i) = wave_c*64 + (lr>>2)*16 + 4*i + (lr&3); the swizzle key does not depend on
     // i, so the four tiles are one base + immediates (i*512), and the second k-half is base ^ 64.
-    const int wrow_l = wave_c * 64 + (lr >> 2) * NV + (lr & 3);
+    const int wrow_l = wave_c * WC + (lr >> 2) * NV + (lr & 3);
     const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
     const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
     const int prow0 = wave_p * WP + lr; // window row of this lane's pixel in tile 0 at tap (0,0)
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
 
     // ---- epilogue
-    const int cb = n0 + wave_c * 64 + lg * NV;
+    const int cb = n0 + wave_c * WC + lg * NV;
     if (cb + NV > a.Cout) return;
     float bias[NV];
 #pragma unroll
@@ -310,13 +312,13 @@ void halo_geometry(int H, int W, int *S, int *pitch, int *strips, int *blocks_pe
     *blocks_per_strip = (H * *pitch + kBM - 1) / kBM;
 }
 
-int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : 64; }
+int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : (cout_stored % 192 == 0 ? 192 : 64); }
 
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream) {
     const int ce = is_f16 ? 8 : 4;
     const int cch = 8 * ce;
     const int bn = halo_cout_tile(a.Cout);
-    if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % 16 != 0) return hipErrorInvalidValue;
+    if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % (bn == 192 ? 24 : 16) != 0) return hipErrorInvalidValue;
     if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
     if (a.pitch != a.S + 2 || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W) return hipErrorInvalidValue;
     if (a.blocks_per_strip * kBM < a.H * a.pitch) return hipErrorInvalidValue;
@@ -325,10 +327,12 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     const int nchunks = a.Cin / cch;
     if (is_f16) {
         if (bn == 128) return launch_h<_Float16, 128, 2, 2>(a, stream);
+        if (bn == 192) return launch_h<_Float16, 192, 2, 2>(a, stream);
         if (nchunks == 1) return launch_h<_Float16, 64, 1, 4>(a, stream);
         return launch_h<_Float16, 64, 2, 2>(a, stream);
     }
     if (bn == 128) return launch_h<float, 128, 2, 2>(a, stream);
+    if (bn == 192) return launch_h<float, 192, 2, 2>(a, stream);
     if (nchunks == 1) return launch_h<float, 64, 1, 4>(a, stream);
     return launch_h<float, 64, 2, 2>(a, stream);
 }
