@@ -101,7 +101,9 @@ def main():
             fl = 2.0 * px * cout * cin * k * k
             by = px * stride_in * stride_in * cin * es + px * cout * es * (1 + extra) + cout * cin * k * k * es
         kname = mine[args.skip * per + i]["Kernel_Name"]
-        if "halo" in kname:
+        if "c32" in kname:
+            short = "c32"
+        elif "halo" in kname:
             m = re.search(r"Li(\d+)ELi(\d)ELi(\d)E", kname)
             short = f"halo{m.group(1)}/{m.group(2)}" if m else "halo"
         else:

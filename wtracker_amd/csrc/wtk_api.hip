@@ -400,7 +400,7 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
     const int ce = h->is_f16 ? 8 : 4;
     op.K = op.k * op.k * op.cin;
     op.Kpad = (op.K + 8 * ce - 1) / (8 * ce) * (8 * ce);
-    const int bn = op.halo ? halo_cout_tile(op.cout) : conv_cfg_bn(op.cfg);
+    const int bn = op.halo == 2 ? 32 : (op.halo ? halo_cout_tile(op.cout) : conv_cfg_bn(op.cfg));
     op.cout_pad = (op.cout + bn - 1) / bn * bn;
     std::vector<float> wf((size_t)op.cout_pad * op.Kpad, 0.f), bf(op.cout_pad, 0.f);
     int row = 0;
@@ -490,6 +490,7 @@ struct Planner {
         op.tile_w = 0;
         if (op.k == 3 && wo >= 64 && wo % 16 == 0 && ho % (bm / 16) == 0) op.tile_w = 16;
         op.halo = halo_eligible(op.k, op.stride, op.cin, h->is_f16) && h->use_halo ? 1 : 0;
+        if (h->use_halo && c32_eligible(op.k, op.stride, op.cin, op.cout, h->is_f16, out2_buf >= 0)) op.halo = 2;
         op.macs_per_image = (double)ho * wo * cout * op.k * op.k * op.cin;
         if (pack_conv(h, op, wp, bp, couts)) {
             failed = true;
@@ -881,7 +882,10 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
                 g.act = op.act, g.Kpad = op.Kpad;
                 halo_geometry(ib.h, ib.w, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
                 g.zeros = h->zero_page;
-                HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
+                if (op.halo == 2)
+                    HIP_TRY(launch_conv3x3_c32(g, st));
+                else
+                    HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
             } else {
                 HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
             }

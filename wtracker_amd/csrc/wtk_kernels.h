@@ -93,11 +93,15 @@ struct HaloArgs {
     int Kpad;
     int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
     const void *zeros;
+    FastDiv d_bps, d_strips, d_pitch; // filled by the launchers that need them
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
 void halo_geometry(int H, int W, int *S, int *pitch, int *strips, int *blocks_per_strip);
 int halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
+// thin fp16 layers (Cin = 32, Cout <= 96): conv3x3_c32.hip
+bool c32_eligible(int k, int stride, int cin, int cout_stored, int is_f16, bool has_out2);
+hipError_t launch_conv3x3_c32(HaloArgs a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Stem: uint8 frame -> (BGR->RGB, /255) -> 3x3 stride-2 conv (Cin=3) + bias + SiLU -> NHWC.
