@@ -279,28 +279,33 @@ template <typename T, int CE> struct __attribute__((aligned(16))) Vec16 {
     T v[CE];
 };
 
-template <typename T, int CE>
+template <typename T, int CE, int GP>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_pool[];
     using V = Vec16<T, CE>;
-    V *A = reinterpret_cast<V *>(smem_pool);
-    V *Bv = A + a.H * a.W;
-    const int groups = a.c / CE;
-    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
     const int HW = a.H * a.W;
+    V *A = reinterpret_cast<V *>(smem_pool); // [pixel][GP channel groups]
+    V *Bv = A + HW * GP;
+    const int groups = a.c / (CE * GP);
+    const int n = blockIdx.x / groups, g0 = (blockIdx.x - n * groups) * GP;
     const int ld = 4 * a.c;
-    T *base = reinterpret_cast<T *>(a.buf) + (long long)n * HW * ld + g * CE;
-    for (int i = threadIdx.x; i < HW; i += 256) A[i] = *reinterpret_cast<const V *>(base + (long long)i * ld);
+    T *base = reinterpret_cast<T *>(a.buf) + (long long)n * HW * ld + g0 * CE;
+    const int items = HW * GP; // item = pixel*GP + group: consecutive lanes read consecutive 16-B groups of a pixel
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int px = i / GP, g = i - px * GP;
+        A[i] = *reinterpret_cast<const V *>(base + (long long)px * ld + g * CE);
+    }
     __syncthreads();
     for (int pass = 1; pass <= 3; ++pass) {
         // horizontal 5-max: A -> B
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            const int y = i / a.W, x = i - y * a.W;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int px = i / GP, g = i - px * GP;
+            const int y = px / a.W, x = px - y * a.W;
             V m = A[i];
             for (int d = -2; d <= 2; ++d) {
                 const int xx = x + d;
                 if (d == 0 || xx < 0 || xx >= a.W) continue;
-                const V o = A[y * a.W + xx];
+                const V o = A[(y * a.W + xx) * GP + g];
 #pragma unroll
                 for (int e = 0; e < CE; ++e) m.v[e] = o.v[e] > m.v[e] ? o.v[e] : m.v[e];
             }
@@ -308,43 +313,58 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
         }
         __syncthreads();
         // vertical 5-max: B -> A, and out
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            const int y = i / a.W, x = i - y * a.W;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int px = i / GP, g = i - px * GP;
+            const int y = px / a.W, x = px - y * a.W;
             V m = Bv[i];
             for (int d = -2; d <= 2; ++d) {
                 const int yy = y + d;
                 if (d == 0 || yy < 0 || yy >= a.H) continue;
-                const V o = Bv[yy * a.W + x];
+                const V o = Bv[(yy * a.W + x) * GP + g];
 #pragma unroll
                 for (int e = 0; e < CE; ++e) m.v[e] = o.v[e] > m.v[e] ? o.v[e] : m.v[e];
             }
             A[i] = m;
-            *reinterpret_cast<V *>(base + (long long)i * ld + pass * a.c) = m;
+            *reinterpret_cast<V *>(base + (long long)px * ld + pass * a.c + g * CE) = m;
         }
         __syncthreads();
     }
 }
 
-static size_t pool_lds_bytes(const PoolArgs &a) { return (size_t)2 * a.H * a.W * 16; }
-
 hipError_t pool_init_attributes() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sppf_pool_kernel<_Float16, 8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sppf_pool_kernel<float, 4>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e;
+#define WTK_POOL_ATTR(T, CE, GP)                                                                                        \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sppf_pool_kernel<T, CE, GP>),                          \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)                \
+        return e;
+    WTK_POOL_ATTR(_Float16, 8, 1)
+    WTK_POOL_ATTR(_Float16, 8, 4)
+    WTK_POOL_ATTR(float, 4, 1)
+    WTK_POOL_ATTR(float, 4, 4)
+#undef WTK_POOL_ATTR
+    return hipSuccess;
 }
 
 hipError_t launch_sppf_pool(const PoolArgs &a, int is_f16, hipStream_t stream) {
     const int ce = is_f16 ? 8 : 4;
     if (a.c % ce != 0) return hipErrorInvalidValue;
-    const size_t lds = pool_lds_bytes(a);
-    if (lds > 160 * 1024) return hipErrorInvalidValue; // map too large for the LDS-resident form
-    const unsigned blocks = (unsigned)(a.N * (a.c / ce));
-    if (is_f16)
-        hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8>), dim3(blocks), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((sppf_pool_kernel<float, 4>), dim3(blocks), dim3(256), lds, stream, a);
+    const size_t per_group = (size_t)2 * a.H * a.W * 16;
+    if (per_group > 160 * 1024) return hipErrorInvalidValue; // map too large for the LDS-resident form
+    // 4 channel groups per block (64-byte contiguous global accesses) while two blocks still fit a CU
+    const int gp = (a.c % (4 * ce) == 0 && 4 * per_group <= 72 * 1024) ? 4 : 1;
+    const size_t lds = per_group * gp;
+    const unsigned blocks = (unsigned)(a.N * (a.c / (ce * gp)));
+    if (is_f16) {
+        if (gp == 4)
+            hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 4>), dim3(blocks), dim3(256), lds, stream, a);
+        else
+            hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 1>), dim3(blocks), dim3(256), lds, stream, a);
+    } else {
+        if (gp == 4)
+            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 4>), dim3(blocks), dim3(256), lds, stream, a);
+        else
+            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 1>), dim3(blocks), dim3(256), lds, stream, a);
+    }
     return hipGetLastError();
 }
 
