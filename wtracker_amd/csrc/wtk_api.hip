@@ -321,7 +321,10 @@ struct Op {
     int cfg = 0;
     int K = 0, Kpad = 0;
     int tile_w = 0;
-    int halo = 0; // 1: conv3x3_halo kernel
+    int halo = 0; // 1: conv3x3_halo kernel, 2: conv3x3_c32 kernel
+    int side = 0;        // 1: runs on the handle's side stream (Detect towers of P3 / P4)
+    int wait_feat = -1;  // side ops: feature event (0: P3 ready, 1: P4 ready) to wait for before the first one
+    int signal_feat = -1; // main ops: record this feature event after the op
     void *w = nullptr; // packed device weights
     float *bias = nullptr;
     double macs_per_image = 0;
@@ -355,6 +358,10 @@ struct wtk_yolo {
     int use_halo = 1;
     int profiling = 0;
     hipEvent_t ev[16];
+    // concurrency: the P3 / P4 Detect towers run on a side stream next to the PAN path
+    hipStream_t side_stream = nullptr;
+    hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done = nullptr;
+    int use_side = 1;
     int ev_created = 0;
     double prof_ms[4] = {0, 0, 0, 0};
     long long prof_launches[4] = {0, 0, 0, 0};
@@ -523,6 +530,10 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     (void)hipFree(h->frames_dev);
     (void)hipFree(h->lb_dev);
     for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
+    if (h->side_done) (void)hipEventDestroy(h->side_done);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     delete h;
 }
 
@@ -557,6 +568,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     h->max_batch = d->max_batch;
     h->dims = dims;
     if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
+    if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
 
     Planner P{h, specs, d->convs};
     const int *c = dims.c;
@@ -642,8 +654,10 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     // ---- neck
     P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], cat14, 0); // t12 -> cat17 slice, up -> cat14
     P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0);
+    if (!P.failed) h->ops.back().signal_feat = 0; // P3 feature map complete
     P.conv({"model.16"}, t15, 0, cat17, 0);
     P.c2f("model.18", cat17, 0, c[3], dims.n[3], false, t18, 0);
+    if (!P.failed) h->ops.back().signal_feat = 1; // P4 feature map complete
     P.conv({"model.19"}, t18, 0, cat20, 0);
     P.c2f("model.21", cat20, 0, c[4], dims.n[3], false, t21, 0);
     // ---- Detect: both towers' first 3x3 share one conv (weights concatenated along cout)
@@ -659,11 +673,16 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         h->cls_buf[i] = P.new_buf(fh[i], fw[i], h->cls_ld);
         h->lh[i] = fh[i];
         h->lw[i] = fw[i];
+        const size_t first_op = h->ops.size();
         P.conv({b + ".0", cl + ".0"}, feat[i], 0, d1, 0);
         P.conv({b + ".1"}, d1, 0, d2b, 0);
         P.conv({cl + ".1"}, d1, dims.hb, d2c, 0);
         P.conv({b + ".2"}, d2b, 0, h->box_buf[i], 0);
         P.conv({cl + ".2"}, d2c, 0, h->cls_buf[i], 0, -1, 0, -1, 0, h->cls_ld);
+        if (!P.failed && i < 2) { // P3 and P4 towers only need t15 / t18: independent of the rest of the PAN path
+            for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = 1;
+            h->ops[first_op].wait_feat = i;
+        }
     }
     if (P.failed) {
         wtk_yolo_destroy(h);
@@ -691,6 +710,15 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (hipMemset(h->zero_page, 0, 256) != hipSuccess) {
         wtk_yolo_destroy(h);
         return fail("wtk_yolo_create: hipMemset failed");
+    }
+    if (h->use_side) {
+        if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->feat_ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->feat_ev[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming) != hipSuccess) {
+            wtk_yolo_destroy(h);
+            return fail("wtk_yolo_create: side stream / event creation failed");
+        }
     }
     *out = h;
     return 0;
@@ -807,7 +835,19 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     };
     long long launches[4] = {0, 0, 0, 0};
 
+    // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
+    // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
+    // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
+    const bool two_lanes = h->use_side && h->side_stream && !h->profiling;
+    bool side_used = false;
+    hipStream_t main_st = st;
     for (const Op &op : h->ops) {
+        st = main_st;
+        if (two_lanes && op.side) {
+            st = h->side_stream;
+            if (op.wait_feat >= 0) HIP_TRY(hipStreamWaitEvent(st, h->feat_ev[op.wait_feat], 0));
+            side_used = true;
+        }
         if (op.kind == OP_STEM) {
             if (mark(0)) return 1;
             StemArgs a;
@@ -890,7 +930,13 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
                 HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
             }
             ++launches[1];
+            if (two_lanes && op.signal_feat >= 0) HIP_TRY(hipEventRecord(h->feat_ev[op.signal_feat], main_st));
         }
+    }
+    st = main_st;
+    if (side_used) {
+        HIP_TRY(hipEventRecord(h->side_done, h->side_stream));
+        HIP_TRY(hipStreamWaitEvent(main_st, h->side_done, 0));
     }
     if (mark(3)) return 1;
     if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st)) return 1;
