@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel-class HIP-event timing")
+    ap.add_argument("--lanes", type=int, default=3, help="forward passes in flight per GPU (each lane = own workspace + HIP stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box, where every rank then shares cuda:0)")
     args = ap.parse_args()
@@ -108,8 +109,9 @@ def main():
     scale, nc = "s", 1
     weights = ys.synthetic_weights(scale, nc, seed=0)
     depth, width, maxch = ys.SCALES[scale]
-    det = hip.HipYolo(weights, (args.size, args.size), args.batch, dtype=args.dtype, nc=nc, width=width, depth=depth,
-                      max_channels=maxch, device=local_rank)
+    dets = [hip.HipYolo(weights, (args.size, args.size), args.batch, dtype=args.dtype, nc=nc, width=width, depth=depth,
+                        max_channels=maxch, device=local_rank) for _ in range(args.lanes)]
+    det = dets[0]
     golden = os.path.join(ROOT, "tests", "golden", "resmlp_100ms.npz")
     folded = resmlp.load_npz(golden)  # ResMLP(imaging-100ms_pred-40ms_moving-50ms): the reference's shipped weights
     mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
@@ -123,7 +125,7 @@ def main():
     total_steps = args.warmup + args.steps
     total_frames = total_steps * args.batch * world
     # 60 fps, 100/40/50 ms timing (BASELINE config 3): imaging 6, pred 3, moving 3 frames
-    pipe = TrackPipeline(det, mlp, folded, args.batch, total_frames, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9,
+    pipe = TrackPipeline(dets, mlp, folded, args.batch, total_frames, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9,
                          conf=0.1, rank=rank, world=world, group=group, device=dev)
 
     def run(s: int):
@@ -131,6 +133,7 @@ def main():
         pipe.step(s, frames[b * args.batch : (b + 1) * args.batch])
 
     def fence():
+        pipe.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             import torch.distributed as dist
@@ -156,11 +159,12 @@ def main():
     # ---- per-kernel-class device time with HIP events on the launch stream (same workload, rank 0)
     roofline = None
     if not args.no_profile:
+        fence()
         det.set_profiling(True)
         prof_steps = max(min(args.steps, 10), 1)
         for s in range(prof_steps):
-            run(args.warmup + s)
-        torch.cuda.synchronize(dev)
+            run((args.warmup + s) // args.lanes * args.lanes)  # lane 0 = the profiled handle
+        fence()
         prof = det.get_profile()
         det.set_profiling(False)
         conv = prof["conv"]
@@ -190,7 +194,7 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full sim loop, YOLOv8s (nc=1, seeded synthetic weights) + ResMLP(imaging-100ms_pred-40ms_moving-50ms, reference weights)",
-                   "frame": f"{args.size}x{args.size} uint8 gray, resident in HBM", "batch_per_gpu": args.batch,
+                   "frame": f"{args.size}x{args.size} uint8 gray, resident in HBM", "batch_per_gpu": args.batch, "lanes_per_gpu": args.lanes,
                    "global_batch": args.batch * world, "timing_ms": [100, 40, 50], "conf": 0.1,
                    "parallelism": f"frame-sharded x{world}, one RCCL all-gather of [B,4] tracks per step" if world > 1 else "single GPU"},
         "roofline": roofline,

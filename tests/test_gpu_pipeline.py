@@ -1,0 +1,55 @@
+"""GPU: the batched open-loop pipeline (detect -> track -> ResMLP per cycle), one lane vs three lanes in
+flight, and its ResMLP outputs vs the oracle arithmetic on the same track."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resmlp_oracle
+from wtracker_amd import frames as fr
+from wtracker_amd import hip, resmlp
+from wtracker_amd import yolo_spec as ys
+from wtracker_amd.pipeline import TrackPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lanes, frames, B, steps, folded, weights):
+    dets = [hip.HipYolo(weights, (128, 128), B, dtype="fp16", nc=1, width=0.25, depth=0.33, max_channels=1024) for _ in range(lanes)]
+    mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block)
+    pipe = TrackPipeline(dets, mlp, folded, B, steps * B, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9, conf=0.1)
+    for s in range(steps):
+        pipe.step(s, frames[s * B : (s + 1) * B])
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    return pipe.track.cpu().numpy(), pipe.moves.cpu().numpy(), pipe.valid.cpu().numpy(), pipe.plan
+
+
+def test_three_lanes_equal_one_lane_and_oracle_mlp(hip_lib, golden_dir):
+    B, steps = 32, 6
+    path = os.path.join(golden_dir, "resmlp_100ms.npz")
+    folded = resmlp.load_npz(path)
+    weights = ys.synthetic_weights("n", 1, seed=0)
+    f_np, _ = fr.synthetic_frames(B * steps, 128, seed=4)
+    frames = torch.from_numpy(f_np).cuda()
+    t1, m1, v1, plan = _run(1, frames, B, steps, folded, weights)
+    t3, m3, v3, _ = _run(3, frames, B, steps, folded, weights)
+    np.testing.assert_array_equal(t1, t3)
+    np.testing.assert_array_equal(v1, v3)
+    np.testing.assert_array_equal(m1, m3)
+    assert np.isfinite(t1).all() or np.isnan(t1).any()
+    # ResMLP outputs == oracle arithmetic on the same (fp32) track
+    st = resmlp_oracle.load_state(path)
+    n_valid = 0
+    for i, a in enumerate(plan.anchors):
+        idx = a + np.asarray(folded.input_frames)
+        ok = (idx >= 0).all() and np.isfinite(t1[np.clip(idx, 0, len(t1) - 1)]).all()
+        assert bool(v1[i]) == bool(ok)
+        if ok:
+            b = t1[idx].copy()
+            b[:, 0] -= b[0, 0]
+            b[:, 1] -= b[0, 1]
+            np.testing.assert_allclose(m1[i], resmlp_oracle.forward(st, b.reshape(1, -1))[0], rtol=1e-4, atol=5e-4)
+            n_valid += 1
+    assert n_valid >= 10 and len(plan.anchors) == (B * steps - 6) // 9 + 1

@@ -61,9 +61,9 @@ def test_fp32_head_logits_and_boxes_match_oracle(hip_lib, scale, size, B):
     np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("size,B", [(128, 2), (256, 3)])
-def test_fp16_matches_oracle_within_stated_tolerance(hip_lib, size, B):
-    oracle, det = _models("s", size, "fp16")
+@pytest.mark.parametrize("scale,size,B", [("s", 128, 2), ("s", 256, 3), ("n", 128, 3), ("n", 160, 2)])
+def test_fp16_matches_oracle_within_stated_tolerance(hip_lib, scale, size, B):
+    oracle, det = _models(scale, size, "fp16")
     frames, _ = fr.synthetic_frames(B, size, seed=12)
     box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
     xywh, conf, anchor = det.predict_host(frames, conf=0.1)

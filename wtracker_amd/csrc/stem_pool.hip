@@ -144,13 +144,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
             }
         T *o = out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout + cb;
         if constexpr (sizeof(T) == 2) {
-            typedef _Float16 half8_o __attribute__((ext_vector_type(8)));
+            // NV = 4*TC halves per lane: 8-byte units (TC odd: 16 / 48 couts) or 16-byte units
 #pragma unroll
-            for (int i = 0; i < NV; i += 8) {
-                half8_o h;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) h[q] = (_Float16)v[i + q];
-                *reinterpret_cast<half8_o *>(o + i) = h;
+            for (int i = 0; i < NV; i += 4) {
+                half4_s h;
+                h.x = (_Float16)v[i], h.y = (_Float16)v[i + 1], h.z = (_Float16)v[i + 2], h.w = (_Float16)v[i + 3];
+                *reinterpret_cast<half4_s *>(o + i) = h;
             }
         } else {
 #pragma unroll

@@ -67,37 +67,69 @@ def exchange_tracks(track: torch.Tensor, local_xywh: torch.Tensor, plan: ShardPl
 
 
 class TrackPipeline:
-    def __init__(self, det: hip.HipYolo, mlp: hip.HipMLP, folded: FoldedResMLP, batch: int, total_frames: int,
+    """`dets`: one detector handle per lane.  With two lanes consecutive super-batches run on two HIP streams
+    (each with its own activation workspace), so the tails and the latency-bound layers of one forward pass
+    are filled by the other; the ResMLP of step s waits for the detections of steps s and s-1 (its 27-frame
+    look-back never reaches further than one super-batch of >= 27 frames)."""
+
+    def __init__(self, dets, mlp: hip.HipMLP, folded: FoldedResMLP, batch: int, total_frames: int,
                  imaging_frame_num: int, pred_frame_num: int, cycle_frame_num: int, conf: float = 0.1,
                  rank: int = 0, world: int = 1, group=None, device: Optional[torch.device] = None):
-        self.det, self.mlp, self.folded = det, mlp, folded
+        self.dets = list(dets) if isinstance(dets, (list, tuple)) else [dets]
+        self.mlp, self.folded = mlp, folded
         self.rank, self.world, self.group = rank, world, group
         self.conf = conf
-        self.device = device or torch.device("cuda", det.device)
+        self.device = device or torch.device("cuda", self.dets[0].device)
         self.plan = ShardPlan(batch, world, total_frames, imaging_frame_num, pred_frame_num, cycle_frame_num)
+        lookback = -min(folded.input_frames) + pred_frame_num
+        if len(self.dets) > 1 and self.plan.super_batch < lookback:
+            raise ValueError("two lanes need super-batches of at least the predictor's look-back")
+        n_lanes = len(self.dets)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 else [None]
+        self.det_done = [torch.cuda.Event() for _ in range(n_lanes)]
         # device-resident track of the whole run: xywh per frame (NaN = no detection yet / none found)
         self.track = torch.full((total_frames, 4), float("nan"), dtype=torch.float32, device=self.device)
-        self.local_xywh = torch.empty((batch, 4), dtype=torch.float32, device=self.device)
-        self.local_conf = torch.empty((batch,), dtype=torch.float32, device=self.device)
-        self.local_anchor = torch.empty((batch,), dtype=torch.int32, device=self.device)
+        self.local_xywh = [torch.empty((batch, 4), dtype=torch.float32, device=self.device) for _ in range(n_lanes)]
+        self.local_conf = [torch.empty((batch,), dtype=torch.float32, device=self.device) for _ in range(n_lanes)]
+        self.local_anchor = [torch.empty((batch,), dtype=torch.int32, device=self.device) for _ in range(n_lanes)]
         n = max(len(self.plan.anchors), 1)
         self.anchors = torch.from_numpy(self.plan.anchors).to(self.device)
         self.moves = torch.zeros((n, 2), dtype=torch.float32, device=self.device)  # raw ResMLP (dx, dy) per cycle
         self.valid = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self._steps_done = 0
 
-    def step(self, s: int, frames_dev: torch.Tensor) -> int:
-        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles."""
+    def _step_on_current_stream(self, s: int, lane: int, frames_dev: torch.Tensor) -> int:
         B, H, W = frames_dev.shape[0], frames_dev.shape[1], frames_dev.shape[2]
         C = frames_dev.shape[3] if frames_dev.dim() == 4 else 1
+        det = self.dets[lane]
         st = torch.cuda.current_stream(self.device).cuda_stream
         if self.world == 1:
             f0, f1 = self.plan.local_range(s, 0)
-            self.det.predict(frames_dev, B, H, W, C, self.track[f0:f1], self.local_conf, self.local_anchor, conf=self.conf, stream=st)
+            det.predict(frames_dev, B, H, W, C, self.track[f0:f1], self.local_conf[lane], self.local_anchor[lane], conf=self.conf, stream=st)
         else:
-            self.det.predict(frames_dev, B, H, W, C, self.local_xywh, self.local_conf, self.local_anchor, conf=self.conf, stream=st)
-            exchange_tracks(self.track, self.local_xywh, self.plan, s, self.group)
+            det.predict(frames_dev, B, H, W, C, self.local_xywh[lane], self.local_conf[lane], self.local_anchor[lane], conf=self.conf, stream=st)
+            exchange_tracks(self.track, self.local_xywh[lane], self.plan, s, self.group)
+        self.det_done[lane].record(torch.cuda.current_stream(self.device))
         lo, hi = self.plan.cycles(s)
         if hi > lo:
+            if len(self.dets) > 1 and self._steps_done > 0:  # rows of the previous super-batch come from the other lane
+                torch.cuda.current_stream(self.device).wait_event(self.det_done[(lane + len(self.dets) - 1) % len(self.dets)])
             self.mlp.predict_track(self.track, self.plan.total_frames, self.anchors[lo:hi], hi - lo, self.folded.input_frames,
                                    self.moves[lo:hi], self.valid[lo:hi], stream=st)
+        self._steps_done += 1
         return hi - lo
+
+    def step(self, s: int, frames_dev: torch.Tensor) -> int:
+        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles."""
+        lane = s % len(self.dets)
+        if self.streams[lane] is None:
+            return self._step_on_current_stream(s, lane, frames_dev)
+        stream = self.streams[lane]
+        stream.wait_stream(torch.cuda.current_stream(self.device))  # inputs produced on the caller's stream
+        with torch.cuda.stream(stream):
+            return self._step_on_current_stream(s, lane, frames_dev)
+
+    def synchronize(self):
+        for st in self.streams:
+            if st is not None:
+                st.synchronize()
