@@ -173,15 +173,23 @@ def main():
         launches_per_forward = conv["launches"] / prof_steps
         avg_launch_ms = conv["total_ms"] / max(conv["launches"], 1)
         achieved = conv_flops_per_forward / launches_per_forward / (avg_launch_ms * 1e-3) / 1e12
-        roofline = {"kernel": "conv_igemm_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype],
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": None,
+        # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE x2 +
+        # WRITE_SIZE, tools/traffic_from_pmc.py); only valid for the configuration it was collected on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        if os.path.exists(tpath) and args.size == 640 and args.dtype == "fp16":
+            tj = json.load(open(tpath))
+            traffic = tj["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]
+        roofline = {"kernel": "conv family: conv_igemm_kernel + conv3x3_halo_kernel + conv3x3_c32_kernel (59 launches/step)",
+                    "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype],
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
                     "launches_per_step": launches_per_forward, "avg_launch_ms": avg_launch_ms,
                     "flop_per_launch_avg": conv_flops_per_forward / launches_per_forward,
                     "class_ms_per_step": {k: v["total_ms"] / prof_steps for k, v in prof.items()}}
 
     frames_done = args.steps * args.batch * world
     out = {
-        "metric": "frames/sec YOLOv8s+ResMLP sim loop @640x640",
+        "metric": f"frames/sec YOLOv8s+ResMLP sim loop @{args.size}x{args.size}",
         "value": frames_done / dt,
         "unit": "frames/s",
         "n_gpus": world,
