@@ -362,6 +362,17 @@ struct wtk_yolo {
     hipStream_t side_stream = nullptr;
     hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done = nullptr;
     int use_side = 1;
+    // launch-bound regime (small batches): the whole forward is captured once per argument set and replayed
+    struct GraphEntry {
+        const void *frames;
+        int B, H, W, C;
+        float conf;
+        void *o_xywh, *o_conf, *o_anchor;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
+    int graph_max_batch = 16; // WTK_GRAPH_MAX_BATCH; 0 disables
+    hipStream_t host_stream = nullptr; // stream of the *_host entry points (graph capture needs a non-null stream)
     int ev_created = 0;
     double prof_ms[4] = {0, 0, 0, 0};
     long long prof_launches[4] = {0, 0, 0, 0};
@@ -534,6 +545,8 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
     if (h->side_done) (void)hipEventDestroy(h->side_done);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     delete h;
 }
 
@@ -569,6 +582,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     h->dims = dims;
     if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
     if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
+    if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
 
     Planner P{h, specs, d->convs};
     const int *c = dims.c;
@@ -711,6 +725,10 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         wtk_yolo_destroy(h);
         return fail("wtk_yolo_create: hipMemset failed");
     }
+    if (hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking) != hipSuccess) {
+        wtk_yolo_destroy(h);
+        return fail("wtk_yolo_create: stream creation failed");
+    }
     if (h->use_side) {
         if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->feat_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -789,28 +807,12 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
     return 0;
 }
 
-extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
-                                int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
-    (void)iou; // with max_det == 1 the IoU threshold cannot change the survivor (SURVEY.md §8 a7)
-    if (!h || !frames_dev || !out_xywh) return fail("wtk_yolo_predict: null argument");
-    if (B <= 0) return fail("wtk_yolo_predict: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
-    if (B > h->max_batch) return fail("wtk_yolo_predict: batch exceeds max_batch");
-    if (C != 1 && C != 3) return fail("wtk_yolo_predict: frames must have 1 (gray) or 3 (BGR) channels");
-    if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
-    if (H <= 0 || W <= 0) return fail("wtk_yolo_predict: bad frame size");
-    hipStream_t st = (hipStream_t)stream;
+// Enqueue one forward pass (letterbox, stem, convs, pool, head) on `st`.  No allocation, no synchronisation
+// (profiling mode excepted): safe inside stream capture.
+static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
+                        float *out_conf, int32_t *out_anchor, hipStream_t st) {
     const uint8_t *net_in = frames_dev;
     if (H != h->S_h || W != h->S_w) {
-        // letterbox into the handle's staging image
-        const size_t need = (size_t)B * h->S_h * h->S_w * C;
-        if (need > h->lb_cap) {
-            HIP_TRY(hipStreamSynchronize(st));
-            (void)hipFree(h->lb_dev);
-            h->lb_dev = nullptr;
-            h->lb_cap = 0;
-            HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
-            h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
-        }
         LetterboxArgs la;
         la.src = frames_dev;
         la.dst = h->lb_dev;
@@ -958,6 +960,55 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     return 0;
 }
 
+extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
+                                int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
+    (void)iou; // with max_det == 1 the IoU threshold cannot change the survivor (SURVEY.md §8 a7)
+    if (!h || !frames_dev || !out_xywh) return fail("wtk_yolo_predict: null argument");
+    if (B <= 0) return fail("wtk_yolo_predict: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
+    if (B > h->max_batch) return fail("wtk_yolo_predict: batch exceeds max_batch");
+    if (C != 1 && C != 3) return fail("wtk_yolo_predict: frames must have 1 (gray) or 3 (BGR) channels");
+    if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
+    if (H <= 0 || W <= 0) return fail("wtk_yolo_predict: bad frame size");
+    hipStream_t st = (hipStream_t)stream;
+    if ((H != h->S_h || W != h->S_w) && h->lb_cap == 0) { // letterbox staging image, allocated once
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
+        h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
+    }
+    // Small batches are launch bound (~62 launches of a few microseconds): replay a captured hipGraph.
+    // Only for the handle's own staging buffers (the *_host entry points): their addresses never change, so
+    // one capture per (B, H, W, C, conf) is replayed forever; arbitrary caller buffers would thrash the cache.
+    const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
+    const bool use_graph = own_buffers && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
+    if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
+    for (auto &g : h->graphs)
+        if (g.frames == frames_dev && g.B == B && g.H == H && g.W == W && g.C == C && g.conf == conf && g.o_xywh == out_xywh &&
+            g.o_conf == out_conf && g.o_anchor == out_anchor) {
+            HIP_TRY(hipGraphLaunch(g.exec, st));
+            return 0;
+        }
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return 1;
+    }
+    if (ec != hipSuccess) return fail_hip("hipStreamEndCapture", ec);
+    wtk_yolo::GraphEntry e{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
+    const hipError_t ei = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail_hip("hipGraphInstantiate", ei);
+    if (h->graphs.size() >= 16) { // bounded cache: callers that rotate buffers would otherwise grow it without limit
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back(e);
+    HIP_TRY(hipGraphLaunch(e.exec, st));
+    return 0;
+}
+
 extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, int32_t B, int32_t H, int32_t W, int32_t C, float conf,
                                      float iou, int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor) {
     if (!h || !frames_host || !out_xywh) return fail("wtk_yolo_predict_host: null argument");
@@ -974,11 +1025,13 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
         HIP_TRY(hipMalloc(&h->frames_dev, cap));
         h->frames_cap = cap;
     }
-    HIP_TRY(hipMemcpy(h->frames_dev, frames_host, need, hipMemcpyHostToDevice));
-    if (wtk_yolo_predict(h, h->frames_dev, B, H, W, C, conf, iou, max_det, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;
-    HIP_TRY(hipMemcpy(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost));
-    if (out_conf) HIP_TRY(hipMemcpy(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost));
-    if (out_anchor) HIP_TRY(hipMemcpy(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost));
+    hipStream_t st = h->host_stream;
+    HIP_TRY(hipMemcpyAsync(h->frames_dev, frames_host, need, hipMemcpyHostToDevice, st));
+    if (wtk_yolo_predict(h, h->frames_dev, B, H, W, C, conf, iou, max_det, h->o_xywh, h->o_conf, h->o_anchor, st)) return 1;
+    HIP_TRY(hipMemcpyAsync(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost, st));
+    if (out_conf) HIP_TRY(hipMemcpyAsync(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost, st));
+    if (out_anchor) HIP_TRY(hipMemcpyAsync(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
