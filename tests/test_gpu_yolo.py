@@ -281,3 +281,26 @@ def test_device_view_cropping_matches_view_controller(hip_lib):
     hip.crop_views(torch.from_numpy(fc).cuda(), 6, 90, 120, 3, p_dev, 9, 9, out)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), np.stack(expect))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_non_square_frames(hip_lib, dtype):
+    """480x640-style inputs: ultralytics' auto letterbox keeps the aspect ratio (net input 96 x 160 here)."""
+    H, W, imgsz = 96, 160, 160
+    assert ys.letterbox_shape(H, W, imgsz) == (96, 160)
+    w = ys.synthetic_weights("n", 1, seed=0)
+    oracle = yo.YoloOracle(w, ys.model_dims(0.25, 0.33, 1024, 1))
+    det = hip.HipYolo(w, (H, W), 3, dtype=dtype, nc=1, width=0.25, depth=0.33, max_channels=1024)
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(3, H, W), dtype=np.uint8)
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(frames), imgsz)
+        assert tuple(x.shape[2:]) == (H, W)
+        box_o, cls_o = oracle.forward(x)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.05)
+    box_g, cls_g = det.debug_head(3)
+    tol = F32_LOGIT_ATOL if dtype == "fp32" else F16_LOGIT_ATOL
+    assert np.abs(cls_g - cls_o.numpy()).max() < tol and np.abs(box_g - box_o.numpy()).max() < tol
+    xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (H, W), hw, conf=0.05)
+    np.testing.assert_array_equal(anchor, anchor_s)
+    np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=2e-2)
