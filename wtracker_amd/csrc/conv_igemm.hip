@@ -90,15 +90,18 @@ template <int NV> __device__ __forceinline__ void store_run(float *p, const floa
 // LDS-DMA loads carry the non-temporal hint (measured: +8..17 % on the HBM-bound 1x1 layers, -15..25 % when a
 // second cout tile re-reads the rows from L2 — hence only for CoutPad == BN).
 template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_P * WAVES_C, 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int CE = Elem<T>::CE;
     constexpr int BKE = 8 * CE; // K elements per step = one 128-byte row
     constexpr int WP = BM / WAVES_P, WC = BN / WAVES_C;
     constexpr int TP = WP / 16, TC = WC / 16;
-    constexpr int PR = BM / 32, WR = BN / 32; // staging rows per thread
+    constexpr int NW = WAVES_P * WAVES_C;     // 4 waves (256 threads, 2 blocks / CU) or 8 waves (512, 1 block / CU)
+    constexpr int RPP = 8 * NW;               // tile rows staged per pass of the whole block
+    constexpr int PR = BM / RPP, WR = BN / RPP; // staging rows per thread
     constexpr int NV = 4 * TC;                // consecutive couts owned by a lane
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static_assert(WAVES_P * WAVES_C == 4, "4 waves per block");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
     static_assert(TP >= 1 && TC >= 1, "tile too small");
 
     // Two DISTINCT LDS objects (not one array indexed by `buf`): hipcc's waitcnt pass tracks pending
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     unsigned wvoff[WR]; // per-lane byte offset inside a [BN][Kpad] weight slab, loop invariant
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-        const int row = r0 + 32 * i;
+        const int row = r0 + RPP * i;
         const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
         wvoff[i] = (unsigned)(((long long)row * a.Kpad + (ch ^ key) * CE) * (long long)sizeof(T));
     }
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
             int n, ho, wo;
-            const bool ok = pixel_coords(ptile, r0 + 32 * r, n, ho, wo);
+            const bool ok = pixel_coords(ptile, r0 + RPP * r, n, ho, wo);
             if (K1) {
                 pbase[r] = ok ? (((long long)n * a.H + ho) * a.W + wo) * a.in_ld + a.in_coff + lchunk * CE : -1;
             } else if (ok) {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             for (int r = 0; r < PR; ++r) {
                 const char *src = (k_ok && pbase[r] >= 0) ? reinterpret_cast<const char *>(in + pbase[r] + ld_ks * BKE) : zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(pt + (32 * r + 8 * wave) * 128), 16, 0, NT ? 2 : 0);
+                                                 (__attribute__((address_space(3))) void *)(pt + (RPP * r + 8 * wave) * 128), 16, 0, NT ? 2 : 0);
             }
         } else {
             const int kh = a.KW == 3 ? (tap * 11) >> 5 : tap / a.KW, kw = tap - kh * a.KW; // tap/3 for tap < 32
@@ -238,14 +241,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 const bool ok = tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 const char *src = ok ? reinterpret_cast<const char *>(in + pbase[r] + delta) : zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(pt + (32 * r + 8 * wave) * 128), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(pt + (RPP * r + 8 * wave) * 128), 16, 0, 0);
             }
         }
         const char *ub = wslab + (size_t)ld_ks * (BKE * sizeof(T));
 #pragma unroll
         for (int i = 0; i < WR; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + wvoff[i]),
-                                             (__attribute__((address_space(3))) void *)(wt + (32 * i + 8 * wave) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(wt + (RPP * i + 8 * wave) * 128), 16, 0, 0);
         // advance the loader; crossing into the next tile recomputes the row table
         kc += BKE;
         if (!K1)
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 int conv_cfg_bm(int cfg) { return cfg == CFG_128x128 ? 128 : 256; }
-int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x64 ? 64 : 32); }
+int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x64 ? 64 : (cfg == CFG_256x256 ? 256 : 32)); }
 
 hipError_t conv_init_attributes() { return hipSuccess; } // LDS is static: nothing to raise
 
@@ -397,15 +400,16 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
         g_num_cus = prop.multiProcessorCount;
     }
-    const long long resident = 2LL * g_num_cus; // 2 blocks of 256 threads per CU (LDS 64-80 KB each)
+    constexpr int NW = WAVES_P * WAVES_C;
+    const long long resident = (NW == 4 ? 2LL : 1LL) * g_num_cus; // 2 blocks of 256 threads or 1 of 512 per CU
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     if (k1 && a.CoutPad == BN)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true>), dim3(grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
     else if (k1)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false>), dim3(grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false>), dim3(grid), dim3(64 * NW), 0, stream, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, false, false>), dim3(grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, false, false>), dim3(grid), dim3(64 * NW), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -424,12 +428,14 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
         case CFG_128x128: return launch_t<_Float16, 128, 128, 2, 2>(a, stream);
         case CFG_256x64: return launch_t<_Float16, 256, 64, 4, 1>(a, stream);
         case CFG_256x32: return launch_t<_Float16, 256, 32, 4, 1>(a, stream);
+        case CFG_256x256: return launch_t<_Float16, 256, 256, 4, 2>(a, stream);
         }
     } else {
         switch (cfg) {
         case CFG_128x128: return launch_t<float, 128, 128, 2, 2>(a, stream);
         case CFG_256x64: return launch_t<float, 256, 64, 4, 1>(a, stream);
         case CFG_256x32: return launch_t<float, 256, 32, 4, 1>(a, stream);
+        case CFG_256x256: return launch_t<float, 256, 256, 4, 2>(a, stream);
         }
     }
     return hipErrorInvalidValue;

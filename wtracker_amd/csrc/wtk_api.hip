@@ -406,7 +406,11 @@ static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
     return 0;
 }
 
-static int pick_cfg(int cout) {
+static int pick_cfg(int cout, bool k1) {
+    // The 8-wave 256x256 tile (64 px x 128 cout per wave) is kept for experiments only: on this network it
+    // measured 0..+30 % SLOWER than 128x128 on every 1x1 layer with Cout >= 256 (fewer, fatter blocks).
+    static const bool big = []() { const char *e = std::getenv("WTK_BIG_TILE"); return e && e[0] == '1'; }();
+    if (big && k1 && cout % 256 == 0) return CFG_256x256;
     if (cout % 128 == 0) return CFG_128x128;
     if (cout % 64 == 0) return CFG_256x64;
     return CFG_256x32;
@@ -485,7 +489,7 @@ struct Planner {
             cout += s.cout;
         }
         op.cout = std::max(cout, cout_store_pad); // channels actually stored (>= real cout, zero rows beyond)
-        op.cfg = pick_cfg(op.cout);
+        op.cfg = pick_cfg(op.cout, op.k == 1 && op.stride == 1);
         op.in_buf = in_buf;
         op.in_coff = in_coff;
         op.out_buf = out_buf;
