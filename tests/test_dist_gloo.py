@@ -74,3 +74,19 @@ def test_shard_plan_single_rank_degenerate_case():
         lo, hi = plan.cycles(s)
         seen += list(range(lo, hi))
     assert seen == list(range(len(plan.anchors)))
+
+
+def test_shard_plan_50k_frames_over_8_ranks():
+    """BASELINE config 4 geometry (index arithmetic only): 50 000 frames, 8 ranks x 64 frames per step."""
+    plan = ShardPlan(64, 8, 50_000 // 512 * 512, 6, 3, 9)
+    assert plan.super_batch == 512 and plan.steps == 97
+    covered = np.zeros(plan.total_frames, dtype=np.int32)
+    for s in range(plan.steps):
+        for r in range(8):
+            f0, f1 = plan.local_range(s, r)
+            covered[f0:f1] += 1
+        lo, hi = plan.cycles(s)
+        if hi > lo:  # every look-back row of these cycles is inside the gathered prefix
+            assert plan.anchors[hi - 1] + plan.pred < plan.super_range(s)[1]
+    assert (covered == 1).all()
+    assert plan.cycles(plan.steps - 1)[1] == len(plan.anchors) == (plan.total_frames - 6) // 9 + 1

@@ -304,3 +304,27 @@ def test_non_square_frames(hip_lib, dtype):
     xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (H, W), hw, conf=0.05)
     np.testing.assert_array_equal(anchor, anchor_s)
     np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=2e-2)
+
+
+def test_full_size_batch64_properties(hip_lib):
+    """BASELINE config 3 shape (64 frames of 640x640, YOLOv8s fp16): size-independent properties —
+    determinism (same input twice), batch invariance (a frame's result does not depend on its batch mates:
+    sub-batches of 8 and a permuted batch give bit-identical rows)."""
+    size, B = 640, 64
+    _, det = _models("s", size, "fp16", max_batch=B)
+    frames, _ = fr.synthetic_frames(B, size, seed=42)
+    a = det.predict_host(frames, conf=0.1)
+    b = det.predict_host(frames, conf=0.1)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    sub = [det.predict_host(frames[i : i + 8], conf=0.1) for i in range(0, B, 8)]
+    np.testing.assert_array_equal(np.concatenate([s[0] for s in sub]), a[0])
+    np.testing.assert_array_equal(np.concatenate([s[2] for s in sub]), a[2])
+    perm = np.random.default_rng(0).permutation(B)
+    p = det.predict_host(frames[perm], conf=0.1)
+    np.testing.assert_array_equal(p[0], a[0][perm])
+    np.testing.assert_array_equal(p[2], a[2][perm])
+    assert (a[2] >= 0).sum() > 0 and (a[0][a[2] >= 0, 2:] > 0).all()
+    # boxes lie inside the frame (scale_boxes clip)
+    ok = a[2] >= 0
+    assert (a[0][ok, 0] >= 0).all() and (a[0][ok, 0] + a[0][ok, 2] <= size + 1e-3).all()
