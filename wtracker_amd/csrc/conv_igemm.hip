@@ -90,7 +90,7 @@ template <int NV> __device__ __forceinline__ void store_run(float *p, const floa
 // LDS-DMA loads carry the non-temporal hint (measured: +8..17 % on the HBM-bound 1x1 layers, -15..25 % when a
 // second cout tile re-reads the rows from L2 — hence only for CoutPad == BN).
 template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT>
-__global__ __launch_bounds__(64 * WAVES_P * WAVES_C, 2) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 * 1024) ? 3 : 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int CE = Elem<T>::CE;
     constexpr int BKE = 8 * CE; // K elements per step = one 128-byte row
     constexpr int WP = BM / WAVES_P, WC = BN / WAVES_C;
@@ -370,8 +370,8 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, 2) void conv_igemm_kernel(c
     }
 }
 
-int conv_cfg_bm(int cfg) { return cfg == CFG_128x128 ? 128 : 256; }
-int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x64 ? 64 : (cfg == CFG_256x256 ? 256 : 32)); }
+int conv_cfg_bm(int cfg) { return (cfg == CFG_128x128 || cfg == CFG_128x64) ? 128 : 256; }
+int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : ((cfg == CFG_256x64 || cfg == CFG_128x64) ? 64 : (cfg == CFG_256x256 ? 256 : 32)); }
 
 hipError_t conv_init_attributes() { return hipSuccess; } // LDS is static: nothing to raise
 
@@ -401,7 +401,8 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
         g_num_cus = prop.multiProcessorCount;
     }
     constexpr int NW = WAVES_P * WAVES_C;
-    const long long resident = (NW == 4 ? 2LL : 1LL) * g_num_cus; // 2 blocks of 256 threads or 1 of 512 per CU
+    const long long per_cu = NW == 8 ? 1 : ((2 * (BM + BN) * 128 <= 52 * 1024) ? 3 : 2); // LDS-limited residency
+    const long long resident = per_cu * g_num_cus;
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     if (k1 && a.CoutPad == BN)
@@ -429,6 +430,7 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
         case CFG_256x64: return launch_t<_Float16, 256, 64, 4, 1>(a, stream);
         case CFG_256x32: return launch_t<_Float16, 256, 32, 4, 1>(a, stream);
         case CFG_256x256: return launch_t<_Float16, 256, 256, 4, 2>(a, stream);
+        case CFG_128x64: return launch_t<_Float16, 128, 64, 4, 1>(a, stream);
         }
     } else {
         switch (cfg) {
@@ -436,6 +438,7 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
         case CFG_256x64: return launch_t<float, 256, 64, 4, 1>(a, stream);
         case CFG_256x32: return launch_t<float, 256, 32, 4, 1>(a, stream);
         case CFG_256x256: return launch_t<float, 256, 256, 4, 2>(a, stream);
+        case CFG_128x64: return launch_t<float, 128, 64, 4, 1>(a, stream);
         }
     }
     return hipErrorInvalidValue;

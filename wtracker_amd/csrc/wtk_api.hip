@@ -412,6 +412,7 @@ static int pick_cfg(int cout, bool k1) {
     static const bool big = []() { const char *e = std::getenv("WTK_BIG_TILE"); return e && e[0] == '1'; }();
     if (big && k1 && cout % 256 == 0) return CFG_256x256;
     if (cout % 128 == 0) return CFG_128x128;
+    if (k1 && cout % 64 == 0) return CFG_128x64; // 48 KB LDS, 123 VGPRs: 3 blocks per CU on the HBM-bound 1x1 layers (+8 %)
     if (cout % 64 == 0) return CFG_256x64;
     return CFG_256x32;
 }
