@@ -107,7 +107,7 @@ def main():
             m = re.search(r"Li(\d+)ELi(\d)ELi(\d)E", kname)
             short = f"halo{m.group(1)}/{m.group(2)}" if m else "halo"
         else:
-            short = "128x64" if "Li128ELi64E" in kname else "256x256" if "Li256ELi256" in kname else "128x128" if "Li128ELi128" in kname else ("256x64" if "Li256ELi64" in kname else ("256x32" if "Li256ELi32" in kname else kind))
+            short = "64x128" if "Li64ELi128E" in kname else "128x64" if "Li128ELi64E" in kname else "256x256" if "Li256ELi256" in kname else "128x128" if "Li128ELi128" in kname else ("256x64" if "Li256ELi64" in kname else ("256x32" if "Li256ELi32" in kname else kind))
         print(f"{name:28s} {short:10s} {us:9.1f} {fl / 1e9:8.2f} {fl / us / 1e6 if us else 0:8.1f} {by / 1e6:9.1f} {by / us / 1e3 if us else 0:8.0f}")
         tot_us += us
         tot_fl += fl

@@ -411,6 +411,8 @@ static int pick_cfg(int cout, bool k1) {
     // measured 0..+30 % SLOWER than 128x128 on every 1x1 layer with Cout >= 256 (fewer, fatter blocks).
     static const bool big = []() { const char *e = std::getenv("WTK_BIG_TILE"); return e && e[0] == '1'; }();
     if (big && k1 && cout % 256 == 0) return CFG_256x256;
+    static const bool t64 = []() { const char *e = std::getenv("WTK_TILE_64x128"); return e && e[0] == '1'; }();
+    if (t64 && k1 && cout % 128 == 0) return CFG_64x128;
     if (cout % 128 == 0) return CFG_128x128;
     if (k1 && cout % 64 == 0) return CFG_128x64; // 48 KB LDS, 123 VGPRs: 3 blocks per CU on the HBM-bound 1x1 layers (+8 %)
     if (cout % 64 == 0) return CFG_256x64;
