@@ -184,6 +184,47 @@ def main():
             shutil.rmtree(tmp, ignore_errors=True)
         moves[out_name] = rec
 
+    from wtracker.sim.sim_controllers.optimal_controller import OptimalController
+    from wtracker.sim.sim_controllers.polyfit_controller import PolyfitConfig, PolyfitController
+
+    def run_other(kind: str, out_name: str, timing=(100, 40, 50)):
+        ec = ExperimentConfig(
+            name="exp0", num_frames=num_frames, frames_per_sec=exp_cfg_json["frames_per_sec"],
+            orig_resolution=tuple(exp_cfg_json["orig_resolution"]), px_per_mm=exp_cfg_json["px_per_mm"],
+            init_position=tuple(exp_cfg_json["init_position"]))
+        tc = TimingConfig(ec, timing[0], timing[1], timing[2], (4, 4), (0.32, 0.32))
+        if kind == "optimal":
+            ctrl = OptimalController(tc, init_csv)
+        else:
+            ctrl = PolyfitController(tc, PolyfitConfig(degree=2, sample_times=[-9, -6, -3, 0, 2, 4], weights=[1, 1, 2, 3, 4, 5]), init_csv)
+        rec = []
+        orig = ctrl.provide_movement_vector
+
+        def wrapped(sim):
+            dx, dy = orig(sim)
+            rec.append([int(sim.frame_number), int(dx), int(dy)])
+            return dx, dy
+
+        ctrl.provide_movement_vector = wrapped
+        tmp = tempfile.mkdtemp(prefix="wtk_golden_")
+        try:
+            lc = LogConfig(root_folder=tmp, save_mic_view=False, save_cam_view=False, save_err_view=False, save_wrm_view=False)
+            Simulator(tc, ec, LoggingController(ctrl, lc)).run()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        moves[out_name] = rec
+
+    run_other("optimal", "sim_optimal")
+    run_other("polyfit", "sim_polyfit")
+
+    # ---- training-pair builder (neural/dataset.py:42-96) on the same synthetic log
+    from wtracker.neural.config import DatasetConfig
+    from wtracker.neural.dataset import NumpyDataset
+
+    ds = NumpyDataset.create_from_config(DatasetConfig(list(loaded["100ms"].io_config.input_frames), list(loaded["100ms"].io_config.pred_frames), init_csv))
+    np.savez(os.path.join(HERE, "dataset_100ms.npz"), X=ds.X.numpy(), y=ds.y.numpy())
+    print("dataset", tuple(ds.X.shape), tuple(ds.y.shape))
+
     run("mlp", "sim_mlp_bboxes.csv")
     run("csv", "sim_csv_bboxes.csv")
     run("mlp", "sim_mlp200_bboxes.csv", timing=(200, 40, 50), model_tag="200ms")

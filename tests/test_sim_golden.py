@@ -9,7 +9,8 @@ import pytest
 
 from oracle import resmlp_oracle
 from oracle.controllers_oracle import OracleMLPController
-from wtracker_amd.controllers import CsvController
+from wtracker_amd.controllers import CsvController, OptimalController, PolyfitConfig, PolyfitController
+from wtracker_amd.resmlp import make_training_pairs
 from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger, discretize
 
 EXP0 = dict(name="exp0", num_frames=200, frames_per_sec=60, orig_resolution=(1600, 1400), px_per_mm=90, init_position=(1300, 1200))
@@ -76,6 +77,33 @@ def test_oracle_mlp_controller_loop_matches_reference_log(golden_dir, tag, timin
     rows, moves = run(lambda tc: OracleMLPController(tc, init, st), timing)
     assert moves == json.load(open(os.path.join(golden_dir, "sim_moves.json")))[name]
     assert_rows_equal(rows, read_log(os.path.join(golden_dir, name)))
+
+
+def test_optimal_and_polyfit_controllers_match_reference_moves(golden_dir):
+    """the comparison baselines around the ResMLP — per-cycle (dx, dy) equal to what the
+    real reference's OptimalController / PolyfitController returned on the same track."""
+    init = os.path.join(golden_dir, "sim_init_bboxes.csv")
+    gold = json.load(open(os.path.join(golden_dir, "sim_moves.json")))
+    _, moves = run(lambda tc: OptimalController(tc, init))
+    assert moves == gold["sim_optimal"]
+    cfg = PolyfitConfig(degree=2, sample_times=[-9, -6, -3, 0, 2, 4], weights=[1, 1, 2, 3, 4, 5])
+    _, moves = run(lambda tc: PolyfitController(tc, cfg, init))
+    assert moves == gold["sim_polyfit"]
+    assert PolyfitConfig(1, [0, 1, 2]).weights == [1.0, 1.0, 1.0]
+    with pytest.raises(AssertionError):
+        PolyfitConfig(1, [0, 1, 2], [1.0])
+
+
+def test_training_pairs_match_reference_dataset(golden_dir):
+    """NumpyDataset.create_from_config on the golden track (neural/dataset.py:42-96), bit for bit."""
+    g = np.load(os.path.join(golden_dir, "dataset_100ms.npz"))
+    m = np.load(os.path.join(golden_dir, "resmlp_100ms.npz"))
+    X, y = make_training_pairs(os.path.join(golden_dir, "sim_init_bboxes.csv"), m["input_frames"].tolist(), m["pred_frames"].tolist())
+    assert X.dtype == np.float32 and y.dtype == np.float32
+    assert X.shape == g["X"].shape and y.shape == g["y"].shape
+    assert np.array_equal(X, g["X"]) and np.array_equal(y, g["y"])
+    X0, y0 = make_training_pairs(os.path.join(golden_dir, "sim_init_bboxes.csv"), [-300, 0], [400])
+    assert X0.shape == (0, 8) and y0.shape == (0, 2)
 
 
 def test_csv_predict_edge_cases(golden_dir):

@@ -3,6 +3,8 @@ arithmetic executed by libwtk_hip.so on the MI355X.
 
 Mirrors (same constructor arguments, method names, return conventions, error behaviour):
   CsvController      wtracker/sim/sim_controllers/csv_controller.py:11-73
+  OptimalController  wtracker/sim/sim_controllers/optimal_controller.py:8-32   (host arithmetic)
+  PolyfitConfig / PolyfitController  wtracker/sim/sim_controllers/polyfit_controller.py:13-84  (host arithmetic, f4)
   HipMLPController   <- MLPController   wtracker/sim/sim_controllers/mlp_controllers.py:14-71
   YoloConfig         wtracker/sim/sim_controllers/yolo_controller.py:15-45
   HipYoloController  <- YoloController  wtracker/sim/sim_controllers/yolo_controller.py:48-109
@@ -72,6 +74,72 @@ class CsvController(SimController):
         start = (sim.cycle_number - 1) * self.timing_config.cycle_frame_num
         end = min(start + self.timing_config.cycle_frame_num, len(self._csv_data))
         return self.predict(np.arange(start, end))
+
+
+class OptimalController(CsvController):
+    """Upper-bound baseline: looks into the future of the replayed track and centres the camera on the
+    median head position of the NEXT imaging phase (optimal_controller.py:8-32).  A few flops per cycle:
+    stays on the host."""
+
+    def __init__(self, timing_config: TimingConfig, csv_path: str):
+        super().__init__(timing_config, csv_path)
+        d = self._csv_data
+        self._csv_centers = np.stack([d[:, 0] + d[:, 2] / 2, d[:, 1] + d[:, 3] / 2], axis=1)
+
+    def provide_movement_vector(self, sim) -> tuple:
+        lo = (sim.cycle_number + 1) * self.timing_config.cycle_frame_num
+        window = self._csv_centers[lo : lo + self.timing_config.imaging_frame_num, :]
+        window = window[np.isfinite(window).all(axis=1)]
+        if len(window) == 0:
+            return 0, 0
+        x_next, y_next = np.median(window, axis=0)
+        cx, cy, cw, ch = sim.view.camera_position
+        return round(x_next - (cx + cw / 2)), round(y_next - (cy + ch / 2))
+
+
+@dataclass
+class PolyfitConfig:
+    """degree / sample_times / weights of the weighted polynomial fit (polyfit_controller.py:13-27).
+    sample_times are frame offsets from the START of the current cycle."""
+
+    degree: int
+    sample_times: list
+    weights: Optional[list] = None
+
+    def __post_init__(self):
+        if self.weights is None:
+            self.weights = [1.0 for _ in self.sample_times]
+        assert len(self.sample_times) == len(self.weights)
+
+
+class PolyfitController(CsvController):
+    """Classical baseline the ResMLP is compared with: weighted least-squares polynomial through the
+    sampled head centres, evaluated at the middle of the next imaging phase
+    (polyfit_controller.py:30-84).  Uses numpy.polynomial.polynomial like the reference so the
+    coefficients are the same bits."""
+
+    def __init__(self, timing_config: TimingConfig, polyfit_config: PolyfitConfig, csv_path: str) -> None:
+        super().__init__(timing_config, csv_path)
+        self.polyfit_config = polyfit_config
+        self._sample_times = np.asanyarray(polyfit_config.sample_times, dtype=int)
+        self._weights = np.asanyarray(polyfit_config.weights, dtype=float)
+
+    def provide_movement_vector(self, sim) -> tuple:
+        from numpy.polynomial import polynomial as poly
+
+        timing = self.timing_config
+        boxes = self.predict(sim.cycle_number * timing.cycle_frame_num + self._sample_times, relative=False)
+        cam = sim.view.camera_position
+        boxes[:, 0] -= cam[0]
+        boxes[:, 1] -= cam[1]
+        centers = np.stack([boxes[:, 0] + boxes[:, 2] / 2, boxes[:, 1] + boxes[:, 3] / 2], axis=1)
+        ok = np.isfinite(centers).all(axis=1)
+        t = self._sample_times[ok]
+        if len(t) == 0:
+            return 0, 0
+        coeffs = poly.polyfit(t, centers[ok], deg=self.polyfit_config.degree, w=self._weights[ok])
+        x_pred, y_pred = poly.polyval(timing.cycle_frame_num + timing.imaging_frame_num // 2, coeffs)
+        return round(x_pred - sim.view.camera_size[0] / 2), round(y_pred - sim.view.camera_size[1] / 2)
 
 
 class HipMLPController(CsvController):

@@ -88,3 +88,36 @@ def from_torch_module(model) -> FoldedResMLP:
     `state_dict()` and `io_config.{input_frames,pred_frames}`."""
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     return fold_state_dict(sd, list(model.io_config.input_frames), list(model.io_config.pred_frames))
+
+
+def make_training_pairs(log_path: str, input_frames: Sequence[int], pred_frames: Sequence[int]):
+    """(X [n, 4*len(input_frames)], y [n, 2*len(pred_frames)]) float32 training pairs from a bboxes.csv
+    log — the arithmetic of NumpyDataset.create_from_config (wtracker/neural/dataset.py:42-96), vectorised
+    (the reference fills two object DataFrames row by row).
+
+    Row i (abs(min(input_frames)) + 1 <= i < len - max(pred_frames) - 1) holds the xywh boxes at
+    i + input_frames and the box centres at i + pred_frames; rows with any NaN are dropped; values are
+    cast to float32 FIRST and only then made relative to the frame-i box corner (that order is part of
+    the result's bits)."""
+    import pandas as pd
+
+    data = pd.read_csv(log_path)
+    boxes = data[["wrm_x", "wrm_y", "wrm_w", "wrm_h"]].to_numpy(dtype=np.float64)
+    centers = np.stack([boxes[:, 0] + boxes[:, 2] / 2, boxes[:, 1] + boxes[:, 3] / 2], axis=1)
+    xi = np.asanyarray(input_frames, dtype=int)
+    yi = np.asanyarray(pred_frames, dtype=int)
+    rows = np.arange(abs(int(xi.min())) + 1, len(boxes) - int(yi.max()) - 1)
+    if rows.size == 0:
+        return np.empty((0, 4 * len(xi)), np.float32), np.empty((0, 2 * len(yi)), np.float32)
+    X = boxes[rows[:, None] + xi[None, :]].reshape(rows.size, -1)
+    y = centers[rows[:, None] + yi[None, :]].reshape(rows.size, -1)
+    keep = ~(np.isnan(X).any(axis=1) | np.isnan(y).any(axis=1))
+    X = X[keep].astype(np.float32)
+    y = y[keep].astype(np.float32)
+    x0 = X[:, 0:1].copy()
+    y0 = X[:, 1:2].copy()
+    y[:, 0::2] -= x0
+    y[:, 1::2] -= y0
+    X[:, 0::4] -= x0
+    X[:, 1::4] -= y0
+    return X, y
