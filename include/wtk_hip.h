@@ -146,6 +146,12 @@ int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, int32_t B, in
 /* Test / profiling hooks: raw head outputs of the last forward pass, copied to HOST as fp32.
  *   level 0..2 -> stride 8/16/32.  box: [B][h*w][64] DFL logits; cls: [B][h*w][nc] logits. */
 int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float *box_host, float *cls_host);
+/* Test hook: the output tensor of conv blob `conv_index` (wtk_yolo_conv_info order) after the last forward pass,
+ * copied to HOST as fp32 [B][h][w][cout].  shape_hwc (optional) receives {h, w, cout}; pass out_host = NULL to
+ * query the shape only.  Intermediates that a fused kernel keeps on chip (model.0 / model.1 when the fused
+ * front is active) hold stale data. */
+int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B, float *out_host, size_t out_cap,
+                          int32_t *shape_hwc);
 /* Run ONLY decode + selection on caller-provided head logits (HOST fp32, same layout as
  * wtk_yolo_debug_head, levels concatenated in anchor order) — isolates the NMS/argmax logic
  * from conv rounding for bit-exact index tests. */

@@ -328,3 +328,27 @@ def test_full_size_batch64_properties(hip_lib):
     # boxes lie inside the frame (scale_boxes clip)
     ok = a[2] >= 0
     assert (a[0][ok, 0] >= 0).all() and (a[0][ok, 0] + a[0][ok, 2] <= size + 1e-3).all()
+
+
+@pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3), (352, 224, 1), (640, 640, 3)])
+def test_fused_front_equals_layer_by_layer(hip_lib, monkeypatch, H, W, C):
+    """front_fused_kernel (preprocess + model.0 + model.1 + model.2.cv1 in one launch) rounds to fp16 where
+    the layer-by-layer kernels store fp16 and walks K in the same order: every head logit must be
+    bit-identical, on full tiles, ragged tiles (quarter map not a multiple of 16), gray and BGR frames."""
+    B = 3
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    rng = np.random.default_rng(H * 7 + W + C)
+    frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
+    outs = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("WTK_NO_FUSED_FRONT", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        outs.append((res, det.debug_head(B)))
+        del det
+    (ra, (box_a, cls_a)), (rb, (box_b, cls_b)) = outs
+    np.testing.assert_array_equal(box_a, box_b)
+    np.testing.assert_array_equal(cls_a, cls_b)
+    for x, y in zip(ra, rb):
+        np.testing.assert_array_equal(x, y)

@@ -328,6 +328,7 @@ struct Op {
     void *w = nullptr; // packed device weights
     float *bias = nullptr;
     double macs_per_image = 0;
+    int spec = -1; // index of the (first) conv blob this op computes, for wtk_yolo_debug_tensor
 };
 
 } // namespace
@@ -356,6 +357,9 @@ struct wtk_yolo {
     int *o_anchor = nullptr;
     // profiling
     int use_halo = 1;
+    int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
+    int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
+    int num_cus = 0;
     int profiling = 0;
     hipEvent_t ev[16];
     // concurrency: the P3 / P4 Detect towers run on a side stream next to the PAN path
@@ -482,6 +486,7 @@ struct Planner {
                 return;
             }
             const ConvSpec &s = specs[i];
+            if (op.spec < 0) op.spec = i;
             op.cin = s.cin;
             op.k = s.k;
             op.stride = s.stride;
@@ -589,6 +594,11 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     h->dims = dims;
     if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
     if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+        h->num_cus = prop.multiProcessorCount;
+    }
     if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
 
     Planner P{h, specs, d->convs};
@@ -623,6 +633,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         op.cout = c[0];
         op.macs_per_image = (double)h2 * w2 * c[0] * 27;
         const int i0 = find_spec(specs, "model.0");
+        op.spec = i0;
         // repack [cout][3][3][3(RGB)] -> K = tap*4 + channel (see stem_mfma_kernel)
         const float *w0 = d->convs[i0].weight;
         const int taps = h->is_f16 ? 16 : 9;
@@ -711,6 +722,16 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     }
     h->anchors = h8 * w8 + h16 * w16 + h32 * w32;
     for (const Op &op : h->ops) h->macs_per_frame += op.macs_per_image;
+    // ops[0..2] are stem, model.1, model.2.cv1 by construction; fuse them when the widths match the kernel
+    {
+        const char *e = std::getenv("WTK_NO_FUSED_FRONT");
+        const bool off = e && e[0] == '1';
+        if (const char *dbg = std::getenv("WTK_FRONT_DEBUG")) h->front_debug = dbg[0] == '1';
+        h->use_front = !off && h->ops.size() > 3 && h->ops[0].kind == OP_STEM && h->ops[1].kind == OP_CONV && h->ops[2].kind == OP_CONV &&
+                       h->ops[1].k == 3 && h->ops[1].stride == 2 && h->ops[2].k == 1 && h->ops[1].act && h->ops[2].act &&
+                       h->ops[2].out2_buf < 0 && h->ops[2].res_buf < 0 &&
+                       front_fused_eligible(h->is_f16, h->ops[0].cout, h->ops[1].cout, h->ops[2].cout);
+    }
 
     // ---- activation workspace: every tensor gets its own allocation (288 GB HBM: no liveness reuse needed)
     for (Buf &b : h->bufs) {
@@ -850,7 +871,27 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     const bool two_lanes = h->use_side && h->side_stream && !h->profiling;
     bool side_used = false;
     hipStream_t main_st = st;
-    for (const Op &op : h->ops) {
+    size_t first_op = 0;
+    if (h->use_front && reinterpret_cast<uintptr_t>(net_in) % 4 == 0) {
+        if (mark(1)) return 1;
+        const Op &o0 = h->ops[0], &o1 = h->ops[1], &o2 = h->ops[2];
+        FrontArgs f;
+        std::memset(&f, 0, sizeof(f));
+        f.frames = net_in;
+        f.N = B, f.H = h->S_h, f.W = h->S_w, f.C = C;
+        f.w0 = o0.w, f.b0 = o0.bias;
+        f.w1 = o1.w, f.b1 = o1.bias, f.Kpad1 = o1.Kpad;
+        f.w2 = o2.w, f.b2 = o2.bias, f.Kpad2 = o2.Kpad;
+        f.out = h->bufs[o2.out_buf].ptr;
+        f.out_ld = h->bufs[o2.out_buf].C;
+        f.out_coff = o2.out_coff;
+        if (h->front_debug) f.dbg_t0 = h->bufs[o0.out_buf].ptr, f.dbg_t1 = h->bufs[o1.out_buf].ptr;
+        HIP_TRY(launch_front_fused(f, h->num_cus, st));
+        ++launches[1];
+        first_op = 3;
+    }
+    for (size_t oi = first_op; oi < h->ops.size(); ++oi) {
+        const Op &op = h->ops[oi];
         st = main_st;
         if (two_lanes && op.side) {
             st = h->side_stream;
@@ -1072,6 +1113,27 @@ extern "C" int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float 
         for (size_t i = 0; i < (size_t)B * A; ++i)
             for (int k = 0; k < h->dims.nc; ++k) cls_host[i * h->dims.nc + k] = full[i * h->cls_ld + k];
     }
+    return 0;
+}
+
+extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B, float *out_host, size_t out_cap, int32_t *shape_hwc) {
+    if (!h || B <= 0 || B > h->max_batch) return fail("wtk_yolo_debug_tensor: bad argument");
+    const Op *op = nullptr;
+    for (const Op &o : h->ops)
+        if (o.spec == conv_index && o.out_buf >= 0) op = &o;
+    if (!op) return fail("wtk_yolo_debug_tensor: no op computes conv " + std::to_string(conv_index));
+    const Buf &b = h->bufs[op->out_buf];
+    if (shape_hwc) shape_hwc[0] = b.h, shape_hwc[1] = b.w, shape_hwc[2] = op->cout;
+    if (!out_host) return 0;
+    const size_t px = (size_t)B * b.h * b.w;
+    if (out_cap < px * op->cout) return fail("wtk_yolo_debug_tensor: output buffer too small");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<char> tmp(px * b.C * h->esize);
+    HIP_TRY(hipMemcpy(tmp.data(), b.ptr, tmp.size(), hipMemcpyDeviceToHost));
+    std::vector<float> full(px * b.C);
+    to_f32(tmp.data(), full.data(), full.size(), h->is_f16);
+    for (size_t i = 0; i < px; ++i) std::memcpy(out_host + i * op->cout, &full[i * b.C + op->out_coff], sizeof(float) * op->cout);
     return 0;
 }
 

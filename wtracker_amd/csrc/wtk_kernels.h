@@ -118,6 +118,28 @@ struct StemArgs {
 };
 hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream);
 
+// Fused front (front_fused.hip): preprocess + model.0 + model.1 + model.2.cv1, fp16, widths 32 / 64 / 64.
+struct FrontArgs {
+    const uint8_t *frames; // [N][H][W][C] network-size frames, C = 1 or 3 (BGR); 4-byte aligned
+    int N, H, W, C;
+    const void *w0; // stem, packed as StemArgs::w (fp16)
+    const float *b0;
+    const void *w1; // model.1, [64][Kpad1] fp16, K = tap*32 + channel
+    const float *b1;
+    int Kpad1;
+    const void *w2; // model.2.cv1, [64][Kpad2] fp16
+    const float *b2;
+    int Kpad2;
+    void *out; // [N][H/4][W/4] slice view (out_ld, out_coff), 64 channels
+    int out_ld, out_coff;
+    unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_FRONT_STAMPS) only: [grid][8 waves][8 stages] cycle sums
+    void *dbg_t0, *dbg_t1; // test hook (normally null): also materialise model.0 [N][H/2][W/2][32] / model.1 [N][H/4][W/4][64]
+    int Ho, Wo, tiles_x, tiles_y, total_tiles; // filled by the launcher
+    FastDiv d_tpi, d_tilesx;
+};
+bool front_fused_eligible(int is_f16, int c0, int c1, int c2_out);
+hipError_t launch_front_fused(FrontArgs a, int num_cus, hipStream_t stream);
+
 // Letterbox (ultralytics LetterBox, cv2.INTER_LINEAR fixed-point bilinear + pad 114) of uint8
 // frames [N][H][W][C] into [N][S_h][S_w][C].
 struct LetterboxArgs {

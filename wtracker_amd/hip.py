@@ -50,7 +50,7 @@ SYMBOLS = [
     "wtk_mlp_create", "wtk_mlp_destroy", "wtk_mlp_forward", "wtk_mlp_forward_host", "wtk_mlp_predict_track",
     "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
-    "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_crop_views",
+    "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
 ]
 
 
@@ -89,6 +89,7 @@ def load() -> C.CDLL:
     lib.wtk_yolo_decode_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
     lib.wtk_yolo_workload.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
     lib.wtk_yolo_set_profiling.argtypes = [vp, i32]
+    lib.wtk_yolo_debug_tensor.argtypes = [vp, i32, i32, vp, C.c_size_t, vp]
     lib.wtk_yolo_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.wtk_crop_views.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     _lib = lib
@@ -272,6 +273,15 @@ class HipYolo:
             boxes.append(bx)
             clss.append(cl)
         return np.concatenate(boxes, 1), np.concatenate(clss, 1)
+
+    def debug_tensor(self, conv_index: int, B: int) -> np.ndarray:
+        """Output of conv blob `conv_index` (yolo_conv_table order) of the last forward: fp32 [B,h,w,cout]."""
+        lib = load()
+        shp = (C.c_int32 * 3)()
+        _check(lib.wtk_yolo_debug_tensor(self._h, conv_index, B, None, 0, shp), "wtk_yolo_debug_tensor")
+        out = np.empty((B, shp[0], shp[1], shp[2]), dtype=np.float32)
+        _check(lib.wtk_yolo_debug_tensor(self._h, conv_index, B, _ptr(out), out.size, shp), "wtk_yolo_debug_tensor")
+        return out
 
     def decode_host(self, box: np.ndarray, cls: np.ndarray, H: int, W: int, conf: float = 0.1):
         box = np.ascontiguousarray(box, dtype=np.float32)
