@@ -331,24 +331,28 @@ def test_full_size_batch64_properties(hip_lib):
 
 
 @pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3), (352, 224, 1), (640, 640, 3)])
-def test_fused_front_equals_layer_by_layer(hip_lib, monkeypatch, H, W, C):
-    """front_fused_kernel (preprocess + model.0 + model.1 + model.2.cv1 in one launch) rounds to fp16 where
-    the layer-by-layer kernels store fp16 and walks K in the same order: every head logit must be
-    bit-identical, on full tiles, ragged tiles (quarter map not a multiple of 16), gray and BGR frames."""
+def test_fused_kernels_equal_layer_by_layer(hip_lib, monkeypatch, H, W, C):
+    """front_fused_kernel (preprocess + model.0 + model.1 + model.2.cv1) and c2f32_fused_kernel (model.2's
+    bottleneck + cv2) round to fp16 where the layer-by-layer kernels store fp16 and walk K in the same order:
+    every head logit must be bit-identical, on full tiles, ragged tiles (maps not a multiple of 16), gray and
+    BGR frames, with either or both fusions active."""
     B = 3
     w = ys.synthetic_weights("s", 1, seed=0)
     depth, width, maxch = ys.SCALES["s"]
     rng = np.random.default_rng(H * 7 + W + C)
     frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
     outs = []
-    for off in ("1", "0"):
-        monkeypatch.setenv("WTK_NO_FUSED_FRONT", off)
+    for no_front, no_c2f in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("WTK_NO_FUSED_FRONT", no_front)
+        monkeypatch.setenv("WTK_NO_FUSED_C2F", no_c2f)
         det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
         res = det.predict_host(frames, conf=0.05)
-        outs.append((res, det.debug_head(B)))
+        outs.append((res, det.debug_head(B), det.debug_tensor(3, B)))  # conv 3 = model.2.cv2
         del det
-    (ra, (box_a, cls_a)), (rb, (box_b, cls_b)) = outs
-    np.testing.assert_array_equal(box_a, box_b)
-    np.testing.assert_array_equal(cls_a, cls_b)
-    for x, y in zip(ra, rb):
-        np.testing.assert_array_equal(x, y)
+    ref_res, (ref_box, ref_cls), ref_t2 = outs[0]
+    for res, (box, cls), t2 in outs[1:]:
+        np.testing.assert_array_equal(t2, ref_t2)
+        np.testing.assert_array_equal(box, ref_box)
+        np.testing.assert_array_equal(cls, ref_cls)
+        for x, y in zip(res, ref_res):
+            np.testing.assert_array_equal(x, y)

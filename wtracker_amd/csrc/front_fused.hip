@@ -67,9 +67,12 @@ __device__ __forceinline__ float silu_ff(float x) {
 __device__ __forceinline__ _Float16 norm_byte(uint32_t b) { return (_Float16)pin_f32((float)b * kInv255); }
 
 // LDS-only barrier: waits for this wave's LDS traffic (lgkmcnt(0)), not for global loads/stores in flight.
+// The asm clobbers keep the compiler from moving LDS accesses across it (the s_barrier intrinsic alone is IntrNoMem).
 __device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f); // vmcnt = 63 (no wait), expcnt = 7, lgkmcnt = 0
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 template <bool DBG>

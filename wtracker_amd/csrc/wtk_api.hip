@@ -358,6 +358,7 @@ struct wtk_yolo {
     // profiling
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
+    int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
     int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
     int num_cus = 0;
     int profiling = 0;
@@ -731,6 +732,18 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
                        h->ops[1].k == 3 && h->ops[1].stride == 2 && h->ops[2].k == 1 && h->ops[1].act && h->ops[2].act &&
                        h->ops[2].out2_buf < 0 && h->ops[2].res_buf < 0 &&
                        front_fused_eligible(h->is_f16, h->ops[0].cout, h->ops[1].cout, h->ops[2].cout);
+        // ops[3..5] are the first C2f's bottleneck convs and cv2 (dims.n[0] == 1)
+        const char *e2 = std::getenv("WTK_NO_FUSED_C2F");
+        const bool off2 = e2 && e2[0] == '1';
+        if (!off2 && h->ops.size() > 6 && dims.n[0] == 1) {
+            const Op &m1 = h->ops[3], &m2 = h->ops[4], &cv2 = h->ops[5], &cv1 = h->ops[2];
+            h->use_c2f = m1.kind == OP_CONV && m2.kind == OP_CONV && cv2.kind == OP_CONV && m1.k == 3 && m2.k == 3 && cv2.k == 1 &&
+                         m1.stride == 1 && m2.stride == 1 && m1.act && m2.act && cv2.act && m1.in_buf == cv1.out_buf &&
+                         m2.res_buf == cv1.out_buf && m2.res_coff == m1.in_coff && cv2.in_buf == cv1.out_buf && cv2.in_coff == cv1.out_coff &&
+                         m1.in_coff == cv1.out_coff + 32 && m2.out_coff == cv1.out_coff + 64 && cv2.cin == 96 && m1.Kpad == m2.Kpad &&
+                         cv2.out2_buf < 0 && cv2.res_buf < 0 && m1.cout == 32 && m2.cout == 32 &&
+                         c2f_fused_eligible(h->is_f16, m1.cin, dims.n[0], m2.res_buf >= 0, cv2.cout);
+        }
     }
 
     // ---- activation workspace: every tensor gets its own allocation (288 GB HBM: no liveness reuse needed)
@@ -892,6 +905,23 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     }
     for (size_t oi = first_op; oi < h->ops.size(); ++oi) {
         const Op &op = h->ops[oi];
+        if (h->use_c2f && (oi == 3 || oi == 4)) continue; // folded into the fused C2f tail launched at op 5
+        if (h->use_c2f && oi == 5) {
+            if (mark(1)) return 1;
+            const Op &m1 = h->ops[3], &m2 = h->ops[4];
+            const Buf &cb = h->bufs[op.in_buf];
+            C2fArgs c;
+            std::memset(&c, 0, sizeof(c));
+            c.cat = cb.ptr, c.cat_ld = cb.C, c.a_coff = op.in_coff, c.b_coff = m1.in_coff;
+            c.N = B, c.H = cb.h, c.W = cb.w;
+            c.w_m1 = m1.w, c.b_m1 = m1.bias, c.w_m2 = m2.w, c.b_m2 = m2.bias, c.Kpad_m = m1.Kpad;
+            c.w_cv2 = op.w, c.b_cv2 = op.bias, c.Kpad_cv2 = op.Kpad;
+            c.out = h->bufs[op.out_buf].ptr, c.out_ld = h->bufs[op.out_buf].C, c.out_coff = op.out_coff;
+            c.zeros = h->zero_page;
+            HIP_TRY(launch_c2f_fused(c, h->num_cus, main_st));
+            ++launches[1];
+            continue;
+        }
         st = main_st;
         if (two_lanes && op.side) {
             st = h->side_stream;

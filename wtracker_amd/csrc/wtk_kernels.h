@@ -137,6 +137,27 @@ struct FrontArgs {
     int Ho, Wo, tiles_x, tiles_y, total_tiles; // filled by the launcher
     FastDiv d_tpi, d_tilesx;
 };
+// Fused C2f tail (c2f_fused.hip): m.0.cv1 + m.0.cv2 (+ residual) + cv2 of a C2f block with hidden width 32 and one
+// bottleneck (YOLOv8s model.2), fp16.
+struct C2fArgs {
+    const void *cat; // [N][H][W] concat buffer holding a (a_coff) and b (b_coff), 32 channels each
+    int cat_ld, a_coff, b_coff;
+    int N, H, W;
+    const void *w_m1, *w_m2; // [32][Kpad_m] fp16, K = tap*32 + channel
+    const float *b_m1, *b_m2;
+    int Kpad_m;
+    const void *w_cv2; // [64][Kpad_cv2] fp16, K = concat channel (a, b, m)
+    const float *b_cv2;
+    int Kpad_cv2;
+    void *out; // [N][H][W] slice view, 64 channels
+    int out_ld, out_coff;
+    const void *zeros;
+    int tiles_x, tiles_y, total_tiles; // filled by the launcher
+    FastDiv d_tpi, d_tilesx;
+};
+bool c2f_fused_eligible(int is_f16, int c_hidden, int n_bottlenecks, int shortcut, int c_out);
+hipError_t launch_c2f_fused(C2fArgs a, int num_cus, hipStream_t stream);
+
 bool front_fused_eligible(int is_f16, int c0, int c1, int c2_out);
 hipError_t launch_front_fused(FrontArgs a, int num_cus, hipStream_t stream);
 
