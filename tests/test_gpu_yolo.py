@@ -356,3 +356,25 @@ def test_fused_kernels_equal_layer_by_layer(hip_lib, monkeypatch, H, W, C):
         np.testing.assert_array_equal(cls, ref_cls)
         for x, y in zip(res, ref_res):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("dtype,H,W", [("fp16", 128, 128), ("fp32", 96, 160), ("fp16", 352, 224)])
+def test_two_source_upsample_loader_equals_materialised_concat(hip_lib, monkeypatch, dtype, H, W):
+    """nn.Upsample(2x nearest) + Concat in the FPN: the consumer's 1x1 conv reads the half-resolution tensor at
+    (y/2, x/2) instead of a materialised 4x copy.  Same values in the same K order: bit-identical logits."""
+    B = 2
+    w = ys.synthetic_weights("s", 1, seed=1)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(H + W).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    outs = []
+    for mat in ("1", "0"):
+        monkeypatch.setenv("WTK_MATERIALIZE_UPSAMPLE", mat)
+        det = hip.HipYolo(w, (H, W), B, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        outs.append((res, det.debug_head(B)))
+        del det
+    (ra, (box_a, cls_a)), (rb, (box_b, cls_b)) = outs
+    np.testing.assert_array_equal(box_a, box_b)
+    np.testing.assert_array_equal(cls_a, cls_b)
+    for x, y in zip(ra, rb):
+        np.testing.assert_array_equal(x, y)

@@ -74,6 +74,18 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     mine = [r for r in rows if "wtk" in r["Kernel_Name"] and "mlp_kernel" not in r["Kernel_Name"]]
     ops = plan()
+    # fused launches (fp16, YOLOv8s): front = model.0 + model.1 + model.2.cv1; c2f tail = model.2.m.0.cv1/cv2 + model.2.cv2
+    if any("front_fused" in r["Kernel_Name"] for r in mine):
+        px4 = (args.size // 4) ** 2 * args.batch
+        fl = sum(2.0 * (args.size // st) ** 2 * args.batch * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[:3])
+        by = args.size * args.size * args.batch + px4 * ops[2][3] * es
+        ops = [("front(model.0+1+2.cv1)", "fused", 4, 0, 0, 0, (fl, by))] + ops[3:]
+    if any("c2f32_fused" in r["Kernel_Name"] for r in mine):
+        i0 = next(i for i, o in enumerate(ops) if o[0] == "model.2.m.0.cv1")
+        px4 = (args.size // 4) ** 2 * args.batch
+        fl = sum(2.0 * px4 * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[i0 : i0 + 3])
+        by = px4 * 64 * es + px4 * 64 * es
+        ops = ops[:i0] + [("model.2 tail(m.0+cv2)", "fused", 4, 0, 0, 0, (fl, by))] + ops[i0 + 3 :]
     per = len(ops)
     n_fw = len(mine) // per
     assert n_fw > args.skip, f"{len(mine)} wtk dispatches, {per} per forward"
@@ -81,7 +93,7 @@ def main():
     cnt = 0
     for f in range(args.skip, n_fw):
         chunk = mine[f * per : (f + 1) * per]
-        assert "stem" in chunk[0]["Kernel_Name"] and "head" in chunk[-1]["Kernel_Name"], "dispatch order does not match the plan"
+        assert ("stem" in chunk[0]["Kernel_Name"] or "front_fused" in chunk[0]["Kernel_Name"]) and "head" in chunk[-1]["Kernel_Name"], "dispatch order does not match the plan"
         for i, r in enumerate(chunk):
             acc[i] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
         cnt += 1
@@ -90,7 +102,9 @@ def main():
     for i, (name, kind, s, cout, cin, k, extra) in enumerate(ops):
         us = acc[i] / cnt
         px = (args.size // s) ** 2 * args.batch
-        if kind == "head":
+        if kind == "fused":
+            fl, by = extra
+        elif kind == "head":
             fl, by = 0.0, 0.0
         elif kind == "pool":
             fl, by = 0.0, px * (cin + cout) * es
@@ -101,7 +115,9 @@ def main():
             fl = 2.0 * px * cout * cin * k * k
             by = px * stride_in * stride_in * cin * es + px * cout * es * (1 + extra) + cout * cin * k * k * es
         kname = mine[args.skip * per + i]["Kernel_Name"]
-        if "c32" in kname:
+        if kind == "fused":
+            short = "fused"
+        elif "c32" in kname:
             short = "c32"
         elif "halo" in kname:
             m = re.search(r"Li(\d+)ELi(\d)ELi(\d)E", kname)

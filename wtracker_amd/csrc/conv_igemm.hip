@@ -89,7 +89,8 @@ template <int NV> __device__ __forceinline__ void store_run(float *p, const floa
 // K1: 1x1 stride-1 conv (no tap walk).  NT: the pixel operand is read by exactly one cout tile, so its
 // LDS-DMA loads carry the non-temporal hint (measured: +8..17 % on the HBM-bound 1x1 layers, -15..25 % when a
 // second cout tile re-reads the rows from L2 — hence only for CoutPad == BN).
-template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT>
+// UP (K1 only): two-source input, channels [0, in2_split) come from a half-resolution tensor (see ConvArgs::in2).
+template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT, bool UP = false>
 __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 * 1024) ? 3 : 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int CE = Elem<T>::CE;
     constexpr int BKE = 8 * CE; // K elements per step = one 128-byte row
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 
     // loader state: the tile / K step being staged runs one stage ahead of the tile being computed
     long long pbase[PR]; // element offset of the (hi0, wi0) input pixel of each staged row (-1: no pixel)
+    long long pbase2[UP ? PR : 1]; // UP: element offset of the half-resolution pixel (ho/2, wo/2) in in2
+    const T *in2 = reinterpret_cast<const T *>(a.in2);
     int phi0[PR], pwi0[PR];
     const char *wslab = nullptr; // wave-uniform
     int kc = 0, tap = 0, ld_ks = 0, ld_i = 0;
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
             const bool ok = pixel_coords(ptile, r0 + RPP * r, n, ho, wo);
             if (K1) {
                 pbase[r] = ok ? (((long long)n * a.H + ho) * a.W + wo) * a.in_ld + a.in_coff + lchunk * CE : -1;
+                if (UP) pbase2[r] = ok ? (((long long)n * (a.H >> 1) + (ho >> 1)) * (a.W >> 1) + (wo >> 1)) * a.in2_ld + a.in2_coff + lchunk * CE : -1;
             } else if (ok) {
                 phi0[r] = ho * a.stride - a.pad;
                 pwi0[r] = wo * a.stride - a.pad;
@@ -225,11 +229,20 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         char *wt = pt + BM * 128;
         if (K1) {
             const bool k_ok = kc < a.Cin; // K tail of the last step is zero
+            if (UP && ld_ks * BKE < a.in2_split) { // block-uniform: in2_split is a multiple of the K step
 #pragma unroll
-            for (int r = 0; r < PR; ++r) {
-                const char *src = (k_ok && pbase[r] >= 0) ? reinterpret_cast<const char *>(in + pbase[r] + ld_ks * BKE) : zero_page;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(pt + (RPP * r + 8 * wave) * 128), 16, 0, NT ? 2 : 0);
+                for (int r = 0; r < PR; ++r) { // low-resolution rows are shared by 4 pixels: no non-temporal hint
+                    const char *src = pbase[r] >= 0 ? reinterpret_cast<const char *>(in2 + pbase2[r] + ld_ks * BKE) : zero_page;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(pt + (RPP * r + 8 * wave) * 128), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < PR; ++r) {
+                    const char *src = (k_ok && pbase[r] >= 0) ? reinterpret_cast<const char *>(in + pbase[r] + ld_ks * BKE) : zero_page;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(pt + (RPP * r + 8 * wave) * 128), 16, 0, NT ? 2 : 0);
+                }
             }
         } else {
             const int kh = a.KW == 3 ? (tap * 11) >> 5 : tap / a.KW, kw = tap - kh * a.KW; // tap/3 for tap < 32
@@ -405,6 +418,18 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     const long long resident = per_cu * g_num_cus;
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (a.in2) {
+        if constexpr (BM == 128 && BN == 128) {
+            if (!k1) return hipErrorInvalidValue;
+            if (a.CoutPad == BN)
+                hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
+            else
+                hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue; // the two-source loader is only built for the 128x128 tile
+        }
+    }
     if (k1 && a.CoutPad == BN)
         hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
     else if (k1)
@@ -424,6 +449,9 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
     if (a.res && (a.res_ld % ce != 0 || a.res_coff % ce != 0)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % ce != 0 || a.out2_coff % ce != 0)) return hipErrorInvalidValue;
     if (a.tile_w != 0 && (bm % a.tile_w != 0)) return hipErrorInvalidValue;
+    if (a.in2 && (a.in2_split <= 0 || a.in2_split % (8 * ce) != 0 || a.in2_split > a.Cin || a.in2_ld % ce != 0 || a.in2_coff % ce != 0 ||
+                  a.H % 2 != 0 || a.W % 2 != 0 || cfg != CFG_128x128))
+        return hipErrorInvalidValue;
     if (is_f16) {
         switch (cfg) {
         case CFG_128x128: return launch_t<_Float16, 128, 128, 2, 2>(a, stream);

@@ -317,6 +317,7 @@ struct Op {
     int out_buf = -1, out_coff = 0;
     int out2_buf = -1, out2_coff = 0;
     int res_buf = -1, res_coff = 0;
+    int in2_buf = -1, in2_coff = 0, in2_split = 0; // half-resolution source of the first in2_split input channels (ConvArgs::in2)
     int cout = 0, cout_pad = 0, k = 1, stride = 1, act = 1;
     int cfg = 0;
     int K = 0, Kpad = 0;
@@ -472,7 +473,8 @@ struct Planner {
     }
     // generic conv op from one or more blobs (concatenated along cout)
     void conv(const std::vector<std::string> &names, int in_buf, int in_coff, int out_buf, int out_coff, int out2_buf = -1,
-              int out2_coff = 0, int res_buf = -1, int res_coff = 0, int cout_store_pad = 0) {
+              int out2_coff = 0, int res_buf = -1, int res_coff = 0, int cout_store_pad = 0, int in2_buf = -1, int in2_coff = 0,
+              int in2_split = 0) {
         if (failed) return;
         Op op;
         op.kind = OP_CONV;
@@ -507,6 +509,18 @@ struct Planner {
         op.out2_coff = out2_coff;
         op.res_buf = res_buf;
         op.res_coff = res_coff;
+        op.in2_buf = in2_buf;
+        op.in2_coff = in2_coff;
+        op.in2_split = in2_split;
+        if (in2_buf >= 0) {
+            const Buf &lb = h->bufs[in2_buf];
+            const Buf &hb = h->bufs[in_buf];
+            if (op.cfg != CFG_128x128 || op.k != 1 || lb.h * 2 != hb.h || lb.w * 2 != hb.w || in2_coff + in2_split > lb.C || in2_split > op.cin) {
+                failed = true;
+                fail("internal: two-source conv " + names[0] + " does not fit the 128x128 loader");
+                return;
+            }
+        }
         const Buf &ib = h->bufs[in_buf];
         const Buf &ob = h->bufs[out_buf];
         const int pad = op.k / 2;
@@ -531,13 +545,13 @@ struct Planner {
     }
     // C2f block: input view -> output view.  Returns nothing; allocates its concat + temp buffers.
     void c2f(const std::string &p, int in_buf, int in_coff, int c2, int n, bool shortcut, int out_buf, int out_coff, int out2_buf = -1,
-             int out2_coff = 0) {
+             int out2_coff = 0, int in2_buf = -1, int in2_coff = 0, int in2_split = 0) {
         if (failed) return;
         const Buf ib = h->bufs[in_buf];
         const int c = c2 / 2;
         const int cat = new_buf(ib.h, ib.w, (2 + n) * c);
         const int tmp = new_buf(ib.h, ib.w, c);
-        conv({p + ".cv1"}, in_buf, in_coff, cat, 0);
+        conv({p + ".cv1"}, in_buf, in_coff, cat, 0, -1, 0, -1, 0, 0, in2_buf, in2_coff, in2_split);
         for (int i = 0; i < n; ++i) {
             const std::string m = p + ".m." + std::to_string(i);
             conv({m + ".cv1"}, cat, (1 + i) * c, tmp, 0);
@@ -683,10 +697,20 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         op.cin = c[4] / 2;
         h->ops.push_back(op);
     }
-    P.conv({"model.9.cv2"}, sppcat, 0, cat20, c[3], cat11, 0); // t9 -> cat20 slice, upsampled copy -> cat11
-    // ---- neck
-    P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], cat14, 0); // t12 -> cat17 slice, up -> cat14
-    P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0);
+    // nn.Upsample(2x nearest) + Concat: the consumer's 1x1 conv reads the half-resolution producer directly (two-source
+    // loader of the 128x128 tile), so the 4x larger upsampled copy is never written.  Narrow scales whose cv1 does not
+    // use that tile (and WTK_MATERIALIZE_UPSAMPLE=1) keep the materialised copy in the concat buffer.
+    bool lazy_up = c[2] % 128 == 0 && c[3] % 128 == 0;
+    if (const char *e = std::getenv("WTK_MATERIALIZE_UPSAMPLE")) lazy_up = lazy_up && e[0] != '1';
+    if (lazy_up) {
+        P.conv({"model.9.cv2"}, sppcat, 0, cat20, c[3]); // t9 -> cat20 slice
+        P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], -1, 0, cat20, c[3], c[4]); // [up(t9) | t6]; t12 -> cat17 slice
+        P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0, -1, 0, cat17, c[2], c[3]);      // [up(t12) | t4]
+    } else {
+        P.conv({"model.9.cv2"}, sppcat, 0, cat20, c[3], cat11, 0); // t9 -> cat20 slice, upsampled copy -> cat11
+        P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], cat14, 0); // t12 -> cat17 slice, up -> cat14
+        P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0);
+    }
     if (!P.failed) h->ops.back().signal_feat = 0; // P3 feature map complete
     P.conv({"model.16"}, t15, 0, cat17, 0);
     P.c2f("model.18", cat17, 0, c[3], dims.n[3], false, t18, 0);
@@ -972,6 +996,12 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 a.out2 = h->bufs[op.out2_buf].ptr;
                 a.out2_ld = h->bufs[op.out2_buf].C;
                 a.out2_coff = op.out2_coff;
+            }
+            if (op.in2_buf >= 0) {
+                a.in2 = h->bufs[op.in2_buf].ptr;
+                a.in2_ld = h->bufs[op.in2_buf].C;
+                a.in2_coff = op.in2_coff;
+                a.in2_split = op.in2_split;
             }
             if (op.res_buf >= 0) {
                 a.res = h->bufs[op.res_buf].ptr;

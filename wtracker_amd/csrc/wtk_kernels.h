@@ -54,6 +54,11 @@ struct ConvArgs {
     int out2_ld, out2_coff;
     const void *res; // optional residual added after the activation (Bottleneck shortcut)
     int res_ld, res_coff;
+    // optional second source of a 1x1 conv over a concat [up2x(low) | high]: input channels [0, in2_split) are read
+    // from the half-resolution tensor `in2` at pixel (ho/2, wo/2) — nn.Upsample(2, "nearest") + Concat without
+    // ever materialising the upsampled copy; channels >= in2_split come from `in` as usual
+    const void *in2;
+    int in2_ld, in2_coff, in2_split;
     int act; // 1: SiLU
     int K, Kpad;
     int tile_w; // 0: linear pixel order over N*Ho*Wo; >0: 2-D pixel tiles tile_w x (BM/tile_w)
