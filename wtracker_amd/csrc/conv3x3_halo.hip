@@ -19,6 +19,7 @@
 //     LDS-DMA before each fragment read (see conv_igemm.hip).
 #include "wtk_kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace wtk {

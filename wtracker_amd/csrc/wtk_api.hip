@@ -417,8 +417,9 @@ static int pick_cfg(int cout, bool k1) {
     // measured 0..+30 % SLOWER than 128x128 on every 1x1 layer with Cout >= 256 (fewer, fatter blocks).
     static const bool big = []() { const char *e = std::getenv("WTK_BIG_TILE"); return e && e[0] == '1'; }();
     if (big && k1 && cout % 256 == 0) return CFG_256x256;
-    static const bool t64 = []() { const char *e = std::getenv("WTK_TILE_64x128"); return e && e[0] == '1'; }();
-    if (t64 && k1 && cout % 128 == 0) return CFG_64x128;
+    // experiment: 8-wave 256x128 tile (25 % fewer staged bytes per MFMA than 128x128); "1": 1x1 convs, "2": also 3x3
+    static const int t256 = []() { const char *e = std::getenv("WTK_TILE_256x128"); return e ? std::atoi(e) : 0; }();
+    if (t256 && (k1 || t256 > 1) && cout % 128 == 0) return CFG_256x128;
     if (cout % 128 == 0) return CFG_128x128;
     if (k1 && cout % 64 == 0) return CFG_128x64; // 48 KB LDS, 123 VGPRs: 3 blocks per CU on the HBM-bound 1x1 layers (+8 %)
     if (cout % 64 == 0) return CFG_256x64;
@@ -512,6 +513,7 @@ struct Planner {
         op.in2_buf = in2_buf;
         op.in2_coff = in2_coff;
         op.in2_split = in2_split;
+        if (in2_buf >= 0 && op.cfg == CFG_256x128) op.cfg = CFG_128x128; // the two-source loader exists for this tile only
         if (in2_buf >= 0) {
             const Buf &lb = h->bufs[in2_buf];
             const Buf &hb = h->bufs[in_buf];
