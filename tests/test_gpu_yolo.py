@@ -378,3 +378,27 @@ def test_two_source_upsample_loader_equals_materialised_concat(hip_lib, monkeypa
     np.testing.assert_array_equal(cls_a, cls_b)
     for x, y in zip(ra, rb):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_three_slab_counted_wait_schedule_equals_two_slab(hip_lib, monkeypatch, dtype):
+    """conv3x3_halo_kernel with three weight slabs and counted vmcnt waits (LDS-DMA in flight across the tap barrier)
+    against the two-slab / vmcnt(0) schedule: same arithmetic, so bit-identical logits; several runs, because a wait
+    placed one tap too late would show up as run-to-run differences."""
+    B, H, W = 3, 352, 224
+    w = ys.synthetic_weights("s", 1, seed=2)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(9).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    outs = []
+    for slabs in ("2", "3", "3", "3"):
+        monkeypatch.setenv("WTK_HALO_SLABS", slabs)
+        det = hip.HipYolo(w, (H, W), B, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        outs.append((res, det.debug_head(B)))
+        del det
+    ref_res, (ref_box, ref_cls) = outs[0]
+    for res, (box, cls) in outs[1:]:
+        np.testing.assert_array_equal(box, ref_box)
+        np.testing.assert_array_equal(cls, ref_cls)
+        for x, y in zip(res, ref_res):
+            np.testing.assert_array_equal(x, y)

@@ -61,6 +61,24 @@ def plan(scale="s", nc=1):
     return ops
 
 
+def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
+    """Replace the layer-by-layer entries by the fused launches a trace contains (fp16, YOLOv8s):
+    front = model.0 + model.1 + model.2.cv1; C2f tail = model.2.m.0.cv1/cv2 + model.2.cv2.  The fused entries carry
+    (flop, algorithmic bytes) in their last field."""
+    if any("front_fused" in k for k in kernel_names):
+        px4 = (size // 4) ** 2 * batch
+        fl = sum(2.0 * (size // st) ** 2 * batch * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[:3])
+        by = size * size * batch + px4 * ops[2][3] * es
+        ops = [("front(model.0+1+2.cv1)", "fused", 4, 0, 0, 0, (fl, by))] + ops[3:]
+    if any("c2f32_fused" in k for k in kernel_names):
+        i0 = next(i for i, o in enumerate(ops) if o[0] == "model.2.m.0.cv1")
+        px4 = (size // 4) ** 2 * batch
+        fl = sum(2.0 * px4 * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[i0 : i0 + 3])
+        by = px4 * 64 * es + px4 * 64 * es
+        ops = ops[:i0] + [("model.2 tail(m.0+cv2)", "fused", 4, 0, 0, 0, (fl, by))] + ops[i0 + 3 :]
+    return ops
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
@@ -73,19 +91,7 @@ def main():
     rows = list(csv.DictReader(open(args.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     mine = [r for r in rows if "wtk" in r["Kernel_Name"] and "mlp_kernel" not in r["Kernel_Name"]]
-    ops = plan()
-    # fused launches (fp16, YOLOv8s): front = model.0 + model.1 + model.2.cv1; c2f tail = model.2.m.0.cv1/cv2 + model.2.cv2
-    if any("front_fused" in r["Kernel_Name"] for r in mine):
-        px4 = (args.size // 4) ** 2 * args.batch
-        fl = sum(2.0 * (args.size // st) ** 2 * args.batch * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[:3])
-        by = args.size * args.size * args.batch + px4 * ops[2][3] * es
-        ops = [("front(model.0+1+2.cv1)", "fused", 4, 0, 0, 0, (fl, by))] + ops[3:]
-    if any("c2f32_fused" in r["Kernel_Name"] for r in mine):
-        i0 = next(i for i, o in enumerate(ops) if o[0] == "model.2.m.0.cv1")
-        px4 = (args.size // 4) ** 2 * args.batch
-        fl = sum(2.0 * px4 * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[i0 : i0 + 3])
-        by = px4 * 64 * es + px4 * 64 * es
-        ops = ops[:i0] + [("model.2 tail(m.0+cv2)", "fused", 4, 0, 0, 0, (fl, by))] + ops[i0 + 3 :]
+    ops = adapt_plan(plan(), [r["Kernel_Name"] for r in mine], args.size, args.batch, es)
     per = len(ops)
     n_fw = len(mine) // per
     assert n_fw > args.skip, f"{len(mine)} wtk dispatches, {per} per forward"

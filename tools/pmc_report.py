@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tools.layer_profile import plan  # noqa: E402
+from tools.layer_profile import adapt_plan, plan  # noqa: E402
 
 
 def load(path):
@@ -21,7 +21,7 @@ def load(path):
         e = d.setdefault(k, {"name": r["Kernel_Name"], "dur": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
         e[r["Counter_Name"]] = float(r["Counter_Value"])
     ks = sorted(d)
-    per = len(plan())
+    per = len(adapt_plan(plan(), [d[k]["name"] for k in ks]))
     return [d[k] for k in ks[-per:]]
 
 
@@ -31,7 +31,7 @@ def main():
     if "--filter" in sys.argv:
         flt = sys.argv[sys.argv.index("--filter") + 1]
     runs = [load(f) for f in files]
-    ops = plan()
+    ops = adapt_plan(plan(), [e["name"] for e in runs[0]])
     names = []
     for run in runs:
         for k in run[1]:

@@ -14,13 +14,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tools.layer_profile import plan  # noqa: E402
+from tools.layer_profile import adapt_plan, plan  # noqa: E402
 
 
 def last_forward(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "wtk" in r["Kernel_Name"] and "mlp" not in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    per = len(plan())
+    per = len(adapt_plan(plan(), [r["Kernel_Name"] for r in rows]))
     return rows[-per:]
 
 
@@ -30,8 +30,8 @@ def main():
     ap.add_argument("write_csv")
     ap.add_argument("--batch", type=int, default=64)
     a = ap.parse_args()
-    ops = plan()
     f = last_forward(a.fetch_csv, "FETCH_SIZE")
+    ops = adapt_plan(plan(), [r["Kernel_Name"] for r in f])
     w = last_forward(a.write_csv, "WRITE_SIZE")
     total = 0.0
     n = 0
@@ -39,7 +39,7 @@ def main():
     for (name, kind, *_), rf, rw in zip(ops, f, w):
         b = 2.0 * float(rf["Counter_Value"]) * 1024 + float(rw["Counter_Value"]) * 1024
         per_op[name] = b
-        if kind == "conv":
+        if kind in ("conv", "fused"):
             total += b
             n += 1
     print(json.dumps({"conv_launches": n, "hbm_bytes_per_forward": total, "hbm_bytes_per_launch_avg": total / n,

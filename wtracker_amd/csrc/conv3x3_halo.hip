@@ -87,7 +87,38 @@ template <int NV> __device__ __forceinline__ void store_run_h(float *p, const fl
 constexpr int kBM = 256;
 constexpr int kHaloBytes = kHaloRowsMax * 128;
 
-template <typename T, int BN, int NHALO, int MINW>
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address).  RAW = true issues it from inline asm:
+// hipcc then does not know an LDS write is pending and inserts no vmcnt wait of its own in front of later ds_reads —
+// the three-slab schedule orders every read behind an explicit counted wait + barrier instead.  (With the builtin, the
+// waitcnt pass tracks pending LDS-DMA per LDS object; once a few are in flight it gives up counting and drains with
+// vmcnt(0) before the first fragment read of a slab, which is exactly the in-flight request the schedule relies on.)
+template <bool RAW> __device__ __forceinline__ void lds_dma16(const char *src, char *lds_dst) {
+    if constexpr (RAW) {
+        const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds_dst;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+    } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+    }
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// HROWS: window rows one LDS buffer holds.  NWB: weight slabs in the ring.  With NWB == 3 the slab of tap g+2 is
+// requested while tap g is multiplied and a COUNTED s_waitcnt vmcnt leaves it in flight across the tap barrier
+// (raw s_barrier): a slab has two full taps to arrive instead of one.  PMC on the two-slab kernel showed every wave
+// waiting ~1/3 of its life in the vmcnt(0) that __syncthreads puts in front of each tap barrier (1 block per CU:
+// nothing else hides the L2 latency of the slab requested at the top of the same tap).
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int CE = ElemH<T>::CE;
     constexpr int CCH = 8 * CE; // channels per 128-byte chunk
@@ -97,10 +128,12 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     constexpr int WP = kBM / WAVES_P, TP = WP / 16, TC = WC / 16, NV = 4 * TC;
     constexpr int WR = BN / 64; // weight rows staged per thread per tap
 
-    __shared__ __attribute__((aligned(16))) char halo0[kHaloBytes];
-    __shared__ __attribute__((aligned(16))) char halo1[NHALO == 2 ? kHaloBytes : 16];
+    constexpr int kHaloBytesT = HROWS * 128;
+    __shared__ __attribute__((aligned(16))) char halo0[kHaloBytesT];
+    __shared__ __attribute__((aligned(16))) char halo1[NHALO == 2 ? kHaloBytesT : 16];
     __shared__ __attribute__((aligned(16))) char wbuf0[BN * 128];
     __shared__ __attribute__((aligned(16))) char wbuf1[BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf2[NWB == 3 ? BN * 128 : 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -138,7 +171,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // matrix pipe).
     // Window pieces: wave w stages pieces w, w+8, ... (<= kMaxPiecesPerWave); the window geometry does not
     // depend on the channel chunk, so each piece's per-lane byte offset inside the image is computed once.
-    constexpr int kMaxPiecesPerWave = (kHaloRowsMax / 8 + 7) / 8;
+    constexpr int kMaxPiecesPerWave = (HROWS / 8 + 7) / 8;
     unsigned hoff[kMaxPiecesPerWave];
     unsigned hvalid = 0;
 #pragma unroll
@@ -159,8 +192,19 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         const int piece = wave + 8 * q;
         if (piece >= halo_pieces) return; // wave-uniform
         const char *src = ((hvalid >> q) & 1u) ? img + (size_t)c * (CCH * sizeof(T)) + hoff[q] : zero_page;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(buf + piece * 1024), 16, 0, 0);
+        lds_dma16<NWB == 3>(src, buf + piece * 1024);
+    };
+    // Same, but never skipped (see the three-slab schedule below).  Pieces past the window rows carry zeros into unused
+    // rows; a piece index past the BUFFER (only the last q of the highest waves) re-requests the wave's previous piece.
+    auto issue_halo_piece_always = [&](char *buf, int q, int c) __attribute__((always_inline)) { // q static after unrolling
+        constexpr int kPieces = HROWS / 8;
+        static_assert(kPieces >= 16, "window buffer too small");
+        const bool back = q > 0 && wave + 8 * q >= kPieces; // wave-uniform
+        const int piece = back ? wave + 8 * (q - 1) : wave + 8 * q;
+        const unsigned off = back ? hoff[q > 0 ? q - 1 : 0] : hoff[q];
+        const bool ok = back ? ((hvalid >> (q > 0 ? q - 1 : 0)) & 1u) : ((hvalid >> q) & 1u);
+        const char *src = ok ? img + (size_t)c * (CCH * sizeof(T)) + off : zero_page;
+        lds_dma16<NWB == 3>(src, buf + piece * 1024);
     };
     // Weight slab of (tap, chunk c): rows = couts n0 .. n0+BN, 128 bytes each.  Uniform base + invariant
     // per-lane 32-bit offset (lets the compiler use the SGPR-base form of global_load_lds).
@@ -176,9 +220,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     auto issue_weights = [&](char *buf, int tap, int c) {
         const char *ub = wtile + ((size_t)tap * a.Cin + (size_t)c * CCH) * sizeof(T); // wave-uniform
 #pragma unroll
-        for (int i = 0; i < WR; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + wvoff[i]),
-                                             (__attribute__((address_space(3))) void *)(buf + (64 * i + 8 * wave) * 128), 16, 0, 0);
+        for (int i = 0; i < WR; ++i) lds_dma16<NWB == 3>(ub + wvoff[i], buf + (64 * i + 8 * wave) * 128);
     };
 
     floatx4 acc[TC][TP];
@@ -215,13 +257,20 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 
     const int nchunks = a.Cin / CCH;
 
-    // ---- prologue: whole window of chunk 0 + weights of (tap 0, chunk 0)
+    // ---- prologue: whole window of chunk 0 + weights of tap 0 (and tap 1 with the three-slab ring)
 #pragma unroll
     for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_halo_piece(halo0, q, 0);
     issue_weights(wbuf0, 0, 0);
+    if (NWB == 3) {
+        issue_weights(wbuf1, 1, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the raw requests are invisible to the compiler's own wait insertion
+    }
     __syncthreads();
 
-    // one channel chunk = 9 taps.  CP = parity of the chunk: window in halo[CP], tap t's weights in wbuf[(CP+t)&1]
+    // one channel chunk = 9 taps.  CP = parity of the chunk: window in halo[CP].
+    // NWB == 2: tap t's weights in wbuf[(CP+t)&1], next tap's slab requested at the top of the tap, vmcnt(0) at its end.
+    // NWB == 3: tap t's weights in wbuf[t % 3] (9 taps per chunk keep the ring aligned), slab of tap t+2 requested at the
+    //           top of tap t, counted wait at its end: only the requests of THIS tap stay in flight across the barrier.
     auto chunk_body = [&](auto cp_tag, int c) {
         constexpr int CP = decltype(cp_tag)::value;
         const char *hcur = (NHALO == 2 && CP == 1) ? halo1 : halo0;
@@ -229,16 +278,39 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         const bool more = c + 1 < nchunks;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            char *wnext = ((CP + tap) & 1) ? wbuf0 : wbuf1;
-            const char *wcur = ((CP + tap) & 1) ? wbuf1 : wbuf0;
-            if (tap < 8)
-                issue_weights(wnext, tap + 1, c);
-            else if (more)
-                issue_weights(wnext, 0, c + 1);
-            if (NHALO == 2 && more && tap < kMaxPiecesPerWave) // next chunk's window, one piece per wave per
-                issue_halo_piece(hnext, tap, c + 1);           // tap, underneath the MFMAs
-            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
-            __syncthreads(); // vmcnt(0): everything issued above has landed; everyone is done reading wcur
+            if constexpr (NWB == 2) {
+                char *wnext = ((CP + tap) & 1) ? wbuf0 : wbuf1;
+                const char *wcur = ((CP + tap) & 1) ? wbuf1 : wbuf0;
+                if (tap < 8)
+                    issue_weights(wnext, tap + 1, c);
+                else if (more)
+                    issue_weights(wnext, 0, c + 1);
+                if (NHALO == 2 && more && tap < kMaxPiecesPerWave) // next chunk's window, one piece per wave per
+                    issue_halo_piece(hnext, tap, c + 1);           // tap, underneath the MFMAs
+                compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+                __syncthreads(); // vmcnt(0): everything issued above has landed; everyone is done reading wcur
+            } else {
+                const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
+                char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
+                // The number of LDS-DMA instructions per tap is a compile-time constant (no branch around any of them):
+                // hipcc tracks pending LDS-DMA per LDS object and, when it cannot count the younger requests, puts a
+                // vmcnt(0) in front of the first fragment read of a slab — draining exactly what this schedule keeps
+                // in flight.  Where nothing is needed (last chunk: no next slab / no next window) a harmless duplicate
+                // is requested instead: a slab nobody reads again, or a window piece of the dead buffer.
+                const int issued = WR + ((NHALO == 2 && tap < kMaxPiecesPerWave) ? 1 : 0); // constant after unrolling
+                if (tap < 7)
+                    issue_weights(wnext2, tap + 2, c);
+                else
+                    issue_weights(wnext2, tap - 7, more ? c + 1 : c);
+                if (NHALO == 2 && tap < kMaxPiecesPerWave) issue_halo_piece_always(hnext, tap, more ? c + 1 : c); // tap is unrolled
+                compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+                // everything requested in EARLIER taps (next tap's slab, older window pieces) has landed; this tap's
+                // requests keep flying.  lgkmcnt(0): this wave's fragment reads of wcur / hcur are done.
+                wait_vmcnt(issued);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
         }
     };
     for (int c = 0; c < nchunks; c += 2) {
@@ -291,10 +363,11 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
 }
 
-template <typename T, int BN, int NHALO, int MINW> hipError_t launch_h(const HaloArgs &a, hipStream_t stream) {
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS> hipError_t launch_h(const HaloArgs &a, hipStream_t stream) {
     const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    if (kBM + 2 * a.pitch + 2 > HROWS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -305,8 +378,10 @@ bool halo_eligible(int k, int stride, int cin, int is_f16) {
     return k == 3 && stride == 1 && cin % cch == 0;
 }
 
-void halo_geometry(int H, int W, int *S, int *pitch, int *strips, int *blocks_per_strip) {
-    const int smax = (kHaloRowsMax - kBM - 2) / 2 - 2; // BM + 2*(S+2) + 2 <= kHaloRowsMax
+int halo_rows_max(int cout_stored, int slabs) { return (slabs == 3 && halo_cout_tile(cout_stored) == 192) ? kHaloRowsSmall : kHaloRowsMax; }
+
+void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip) {
+    const int smax = (rows_max - kBM - 2) / 2 - 2; // BM + 2*(S+2) + 2 <= rows_max
     *strips = (W + smax - 1) / smax;
     *S = (W + *strips - 1) / *strips;
     *pitch = *S + 2;
@@ -326,16 +401,30 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     if (a.res && (a.res_ld % ce || a.res_coff % ce)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % ce || a.out2_coff % ce)) return hipErrorInvalidValue;
     const int nchunks = a.Cin / cch;
-    if (is_f16) {
-        if (bn == 128) return launch_h<_Float16, 128, 2, 2>(a, stream);
-        if (bn == 192) return launch_h<_Float16, 192, 2, 2>(a, stream);
-        if (nchunks == 1) return launch_h<_Float16, 64, 1, 4>(a, stream);
-        return launch_h<_Float16, 64, 2, 2>(a, stream);
+    // three weight slabs + counted vmcnt (default) or the two-slab / vmcnt(0) schedule (slabs == 2).  A 192-cout tile with three
+    // slabs only leaves room for 352-row windows: the planner then cuts wide maps into strips of <= 45 columns.
+    if (a.slabs != 2) {
+        if (is_f16) {
+            if (bn == 128) return launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax>(a, stream);
+            if (bn == 192) return launch_h<_Float16, 192, 2, 2, 3, kHaloRowsSmall>(a, stream);
+            if (nchunks == 1) return launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax>(a, stream);
+            return launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax>(a, stream);
+        }
+        if (bn == 128) return launch_h<float, 128, 2, 2, 3, kHaloRowsMax>(a, stream);
+        if (bn == 192) return launch_h<float, 192, 2, 2, 3, kHaloRowsSmall>(a, stream);
+        if (nchunks == 1) return launch_h<float, 64, 1, 4, 3, kHaloRowsMax>(a, stream);
+        return launch_h<float, 64, 2, 2, 3, kHaloRowsMax>(a, stream);
     }
-    if (bn == 128) return launch_h<float, 128, 2, 2>(a, stream);
-    if (bn == 192) return launch_h<float, 192, 2, 2>(a, stream);
-    if (nchunks == 1) return launch_h<float, 64, 1, 4>(a, stream);
-    return launch_h<float, 64, 2, 2>(a, stream);
+    if (is_f16) {
+        if (bn == 128) return launch_h<_Float16, 128, 2, 2, 2, kHaloRowsMax>(a, stream);
+        if (bn == 192) return launch_h<_Float16, 192, 2, 2, 2, kHaloRowsMax>(a, stream);
+        if (nchunks == 1) return launch_h<_Float16, 64, 1, 4, 2, kHaloRowsMax>(a, stream);
+        return launch_h<_Float16, 64, 2, 2, 2, kHaloRowsMax>(a, stream);
+    }
+    if (bn == 128) return launch_h<float, 128, 2, 2, 2, kHaloRowsMax>(a, stream);
+    if (bn == 192) return launch_h<float, 192, 2, 2, 2, kHaloRowsMax>(a, stream);
+    if (nchunks == 1) return launch_h<float, 64, 1, 4, 2, kHaloRowsMax>(a, stream);
+    return launch_h<float, 64, 2, 2, 2, kHaloRowsMax>(a, stream);
 }
 
 } // namespace wtk

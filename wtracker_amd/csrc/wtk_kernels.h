@@ -80,7 +80,8 @@ hipError_t conv_init_attributes();
 // ---------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input window (conv3x3_halo.hip).
 // ---------------------------------------------------------------------------------------------
-constexpr int kHaloRowsMax = 432; // window rows (128 B each) one LDS buffer holds: 54 KiB
+constexpr int kHaloRowsMax = 432;   // window rows (128 B each) one LDS buffer holds: 54 KiB
+constexpr int kHaloRowsSmall = 352; // ... for the 192-cout tile with three weight slabs (2 x 44 KiB + 3 x 24 KiB = 160 KiB)
 struct HaloArgs {
     const void *in;
     int in_ld, in_coff;
@@ -98,10 +99,12 @@ struct HaloArgs {
     int Kpad;
     int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
     const void *zeros;
+    int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
     FastDiv d_bps, d_strips, d_pitch; // filled by the launchers that need them
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
-void halo_geometry(int H, int W, int *S, int *pitch, int *strips, int *blocks_per_strip);
+int halo_rows_max(int cout_stored, int slabs); // window rows the kernel variant for this Cout can hold
+void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip);
 int halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
 // thin fp16 layers (Cin = 32, Cout <= 96): conv3x3_c32.hip
