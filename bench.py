@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel-class HIP-event timing")
-    ap.add_argument("--lanes", type=int, default=3, help="forward passes in flight per GPU (each lane = own workspace + HIP stream)")
+    ap.add_argument("--lanes", type=int, default=2, help="forward passes in flight per GPU (each lane = own workspace + HIP stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box, where every rank then shares cuda:0)")
     args = ap.parse_args()

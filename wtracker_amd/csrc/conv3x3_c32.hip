@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const HaloArgs a) {
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // bias of this lane's couts, fetched while the window is in flight (bias rows exist up to CoutPad)
+    const int cb = lg * NV;
+    float bias[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
 
     const int wrow_l = (lr >> 2) * NV + (lr & 3); // + 4*i per cout tile, + tap*BN
     const int wkey_l = (((wrow_l / NV) & 1) << 1) | ((wrow_l >> 1) & 1);
@@ -106,11 +111,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const HaloArgs a) {
     }
 
     // ---- epilogue: lane (pixel lr of tile j, group lg) owns couts lg*NV .. lg*NV+NV-1
-    const int cb = lg * NV;
     if (cb + NV > a.Cout) return;
-    float bias[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
     _Float16 *out = reinterpret_cast<_Float16 *>(a.out);
     const _Float16 *res = reinterpret_cast<const _Float16 *>(a.res);
 #pragma unroll

@@ -120,6 +120,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // nothing else hides the L2 latency of the slab requested at the top of the same tap).
 template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
+#ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int CE = ElemH<T>::CE;
     constexpr int CCH = 8 * CE; // channels per 128-byte chunk
     // BN = 64: 8(P) x 1(C) waves of 32 px x 64 cout; BN = 128 / 192: 4(P) x 2(C) waves of 64 px x 64 / 96 cout
@@ -149,13 +152,17 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    // launch-invariant divisors go through FastDiv: a runtime integer division is ~40 instructions, and the ~25 of them this
+    // kernel used to execute before its first LDS-DMA request cost every block 1.3-1.9 us (stamped) of an 11-33 us life
     const int nct = a.CoutPad / BN;
-    const int n0 = (L % nct) * BN;
-    int t = L / nct;
-    const int rb = t % a.blocks_per_strip;
-    t /= a.blocks_per_strip;
-    const int strip = t % a.strips;
-    const int n = t / a.strips;
+    unsigned t = fdiv((unsigned)L, a.d_nct);
+    const int n0 = (L - (int)t * nct) * BN;
+    unsigned tq = fdiv(t, a.d_bps);
+    const int rb = (int)(t - tq * (unsigned)a.blocks_per_strip);
+    t = tq;
+    tq = fdiv(t, a.d_strips);
+    const int strip = (int)(t - tq * (unsigned)a.strips);
+    const int n = (int)tq;
     const int o0 = rb * kBM;
     const int xs = strip * a.S;
     const int pitch = a.pitch;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         const int hr = piece * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ (hr & 7); // logical chunk landing on this lane's physical slot
         const int flat = o0 + hr;
-        const int r = flat / pitch;
+        const int r = (int)fdiv((unsigned)flat, a.d_pitch);
         const int cc = flat - r * pitch;
         const int iy = r - 1, ix = xs + cc - 1;
         const bool ok = hr < halo_rows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -256,7 +263,14 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     };
 
     const int nchunks = a.Cin / CCH;
+    const int cb = n0 + wave_c * WC + lg * NV; // first of the NV consecutive couts this lane owns
+    float bias[NV];                            // bias rows exist up to CoutPad
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
 
+#ifdef WTK_HALO_STAMPS
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- prologue: whole window of chunk 0 + weights of tap 0 (and tap 1 with the three-slab ring)
 #pragma unroll
     for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_halo_piece(halo0, q, 0);
@@ -318,19 +332,25 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         if (c + 1 < nchunks) chunk_body(std::integral_constant<int, 1>{}, c + 1);
     }
 
-    // ---- epilogue
-    const int cb = n0 + wave_c * WC + lg * NV;
+#ifdef WTK_HALO_STAMPS
+    const unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
+    struct StampOnExit {
+        unsigned long long *p, t0, t1, t2;
+        bool on;
+        __device__ ~StampOnExit() {
+            if (on) p[0] = t0, p[1] = t1, p[2] = t2, p[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    } stamp_on_exit{a.dbg_stamps + ((long long)blockIdx.x * 8 + wave) * 4, st_t0, st_t1, st_t2, a.dbg_stamps != nullptr && lane == 0};
+#endif
+    // ---- epilogue (the bias was fetched before the main loop: a load issued here would expose a full L2 round trip)
     if (cb + NV > a.Cout) return;
-    float bias[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
     const T *res = reinterpret_cast<const T *>(a.res);
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int o = o0 + wave_p * WP + j * 16 + lr;
-        const int y = o / pitch;
+        const int y = (int)fdiv((unsigned)o, a.d_pitch);
         const int x = o - y * pitch;
         if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
         float v[NV];
@@ -363,10 +383,14 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
 }
 
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS> hipError_t launch_h(const HaloArgs &a, hipStream_t stream) {
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (kBM + 2 * a.pitch + 2 > HROWS) return hipErrorInvalidValue;
+    a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
+    a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
+    a.d_strips = make_fastdiv((unsigned)a.strips);
+    a.d_pitch = make_fastdiv((unsigned)a.pitch);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }

@@ -308,6 +308,17 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         }
     };
 
+    // bias of the tile being multiplied (rows exist up to CoutPad), loaded while the previous tile's epilogue retires
+    float bias_r[NV];
+    auto load_bias = [&](int i) __attribute__((always_inline)) {
+        const int tile = t_begin + i * t_stride;
+        const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
+        const int cb = (tile - ptile * nct) * BN + wave_c * WC + lg * NV;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) bias_r[e] = a.bias[cb + e];
+    };
+    load_bias(0);
+
     // ---- epilogue of one finished tile: lane (pixel lr of tile j, group lg) owns couts cb .. cb+NV-1
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
@@ -317,9 +328,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
         const int cb = (tile - ptile * nct) * BN + wave_c * WC + lg * NV;
         if (cb + NV <= a.Cout) { // padded output channels (Cout < CoutPad) are never stored
-            float bias[NV];
-#pragma unroll
-            for (int e = 0; e < NV; ++e) bias[e] = a.bias[cb + e];
+            const float(&bias)[NV] = bias_r; // fetched one tile ahead: a load issued here would expose an L2 round trip per tile
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 int n, ho, wo;
@@ -354,6 +363,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
             }
         }
         zero_acc();
+        if (i + 1 < my_tiles) load_bias(i + 1);
     };
 
     // ---- flat pipeline over (tile, K step) stages: stage s+1 is in flight (LDS-DMA) while stage s is

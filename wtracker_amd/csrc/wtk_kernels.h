@@ -99,8 +99,9 @@ struct HaloArgs {
     int Kpad;
     int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
     const void *zeros;
+    unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_HALO_STAMPS) only
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
-    FastDiv d_bps, d_strips, d_pitch; // filled by the launchers that need them
+    FastDiv d_bps, d_strips, d_pitch, d_nct; // filled by the launchers
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
 int halo_rows_max(int cout_stored, int slabs); // window rows the kernel variant for this Cout can hold

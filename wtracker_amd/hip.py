@@ -11,7 +11,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwtk_hip.so")
+# WTK_HIP_LIB: load another build of the same library instead (A/B timing of two builds in one GPU session)
+_LIB_PATH = os.environ.get("WTK_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwtk_hip.so")
 _lib: Optional[C.CDLL] = None
 
 WTK_F32 = 0
