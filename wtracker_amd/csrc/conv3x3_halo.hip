@@ -383,6 +383,266 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of the three-slab kernel (two window buffers, even number of 64-channel chunks, BN = 128 / 192).
+// A block walks tiles v = blockIdx.x, + gridDim.x, ... and the tap pipeline never drains: during the LAST chunk of a
+// tile the "next chunk" requests (window pieces at taps 0..6, weight slabs at taps 7 / 8) simply name chunk 0 of the
+// NEXT tile, whose geometry (piece offsets, image, cout tile, bias) is computed while this tile is still multiplying.
+// Per tile this removes the ~1.2 us of address setup and the ~1.5 us wait for the first window + slab that every
+// block of the one-tile-per-block kernel spends with an idle matrix pipe (stamped: 8-25 % of a block's life).
+// Arithmetic and K order are those of conv3x3_halo_kernel: bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BN, int HROWS>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a) {
+    constexpr int CE = ElemH<T>::CE;
+    constexpr int CCH = 8 * CE;
+    constexpr int WAVES_C = 2, WAVES_P = 4;
+    constexpr int WC = BN / WAVES_C;
+    constexpr int WP = kBM / WAVES_P, TP = WP / 16, TC = WC / 16, NV = 4 * TC;
+    constexpr int WR = BN / 64;
+    constexpr int kHaloBytesT = HROWS * 128;
+    constexpr int kPieces = HROWS / 8;
+    constexpr int kMaxPiecesPerWave = (kPieces + 7) / 8;
+    static_assert(kMaxPiecesPerWave <= 7, "window pieces are requested at taps 0..6");
+
+    __shared__ __attribute__((aligned(16))) char halo0[kHaloBytesT];
+    __shared__ __attribute__((aligned(16))) char halo1[kHaloBytesT];
+    __shared__ __attribute__((aligned(16))) char wbuf0[BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf1[BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf2[BN * 128];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_p = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int pitch = a.pitch;
+    const int halo_rows = kBM + 2 * pitch + 2;
+    const int nct = a.CoutPad / BN;
+    const int nchunks = a.Cin / CCH; // even (launcher)
+    const int total = a.N * a.strips * a.blocks_per_strip * nct;
+    const int G = gridDim.x; // multiple of 8: a block's tiles stay on one XCD label
+    const T *wgt = reinterpret_cast<const T *>(a.w);
+    const char *zero_page = reinterpret_cast<const char *>(a.zeros);
+
+    // per-tile context.  Two copies (current / next) of plain scalars and small arrays: everything stays in registers.
+    struct Tile {
+        int n, o0, xs, n0;
+        const char *img;   // image base of the input view
+        const char *wtile; // weight rows of this cout tile
+        unsigned hoff[kMaxPiecesPerWave];
+        unsigned hvalid;
+        float bias[NV];
+    };
+    auto setup_tile = [&](int v, Tile &tc) __attribute__((always_inline)) {
+        // XCD-aware bijective remap of the virtual block id (as conv3x3_halo_kernel, with nwg = total tiles)
+        const int xcd = v & 7, q8 = total >> 3, r8 = total & 7;
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+        unsigned t = fdiv((unsigned)L, a.d_nct);
+        tc.n0 = (L - (int)t * nct) * BN;
+        unsigned tq = fdiv(t, a.d_bps);
+        const int rb = (int)(t - tq * (unsigned)a.blocks_per_strip);
+        t = tq;
+        tq = fdiv(t, a.d_strips);
+        const int strip = (int)(t - tq * (unsigned)a.strips);
+        tc.n = (int)tq;
+        tc.o0 = rb * kBM;
+        tc.xs = strip * a.S;
+        tc.img = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.in) + (long long)tc.n * a.H * a.W * a.in_ld + a.in_coff);
+        tc.wtile = reinterpret_cast<const char *>(wgt + (long long)tc.n0 * a.Kpad);
+        tc.hvalid = 0;
+#pragma unroll
+        for (int q = 0; q < kMaxPiecesPerWave; ++q) {
+            const int piece = wave + 8 * q;
+            const int hr = piece * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ (hr & 7);
+            const int flat = tc.o0 + hr;
+            const int r = (int)fdiv((unsigned)flat, a.d_pitch);
+            const int cc = flat - r * pitch;
+            const int iy = r - 1, ix = tc.xs + cc - 1;
+            const bool ok = hr < halo_rows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            tc.hoff[q] = ok ? (unsigned)((((long long)iy * a.W + ix) * a.in_ld + lc * CE) * (long long)sizeof(T)) : 0u;
+            tc.hvalid |= ok ? (1u << q) : 0u;
+        }
+        const int cb = tc.n0 + wave_c * WC + lg * NV;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) tc.bias[i] = a.bias[cb + i];
+    };
+    // window piece q of this wave (never skipped; see issue_halo_piece_always in conv3x3_halo_kernel)
+    auto issue_piece = [&](char *buf, int q, const Tile &tc, int c) __attribute__((always_inline)) {
+        const bool back = q > 0 && wave + 8 * q >= kPieces;
+        const int qq = back ? q - 1 : q;
+        const int piece = wave + 8 * qq;
+        const unsigned off = back ? tc.hoff[q > 0 ? q - 1 : 0] : tc.hoff[q];
+        const bool ok = back ? ((tc.hvalid >> (q > 0 ? q - 1 : 0)) & 1u) : ((tc.hvalid >> q) & 1u);
+        const char *src = ok ? tc.img + (size_t)c * (CCH * sizeof(T)) + off : zero_page;
+        lds_dma16<true>(src, buf + piece * 1024);
+    };
+    const int wrow0 = tid >> 3, wp = tid & 7;
+    unsigned wvoff[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int row = wrow0 + 64 * i;
+        const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+        wvoff[i] = (unsigned)(((long long)row * a.Kpad + (wp ^ key) * CE) * (long long)sizeof(T));
+    }
+    auto issue_weights = [&](char *buf, const char *wtile, int tap, int c) __attribute__((always_inline)) {
+        const char *ub = wtile + ((size_t)tap * a.Cin + (size_t)c * CCH) * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) lds_dma16<true>(ub + wvoff[i], buf + (64 * i + 8 * wave) * 128);
+    };
+
+    floatx4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    const int wrow_l = wave_c * WC + (lr >> 2) * NV + (lr & 3);
+    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
+    const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
+    const int prow0 = wave_p * WP + lr;
+    auto compute_tap = [&](const char *halo, const char *wb, int tapoff) __attribute__((always_inline)) {
+        const int base = prow0 + tapoff;
+        const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4);
+#pragma unroll
+        for (int kh2 = 0; kh2 < 2; ++kh2) {
+            const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
+            const unsigned wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
+            uint4 pf[TP], wf[TC];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(wf[i], pf[j], acc[i][j], (T *)nullptr);
+        }
+    };
+
+    int v = blockIdx.x;
+    if (v >= total) return;
+    Tile cur, nxt;
+    setup_tile(v, cur);
+    nxt = cur;
+    // ---- prologue (once per block): whole window of chunk 0 + slabs of taps 0 and 1
+#pragma unroll
+    for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_piece(halo0, q, cur, 0);
+    issue_weights(wbuf0, cur.wtile, 0, 0);
+    issue_weights(wbuf1, cur.wtile, 1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    T *out = reinterpret_cast<T *>(a.out);
+    T *out2 = reinterpret_cast<T *>(a.out2);
+    const T *res = reinterpret_cast<const T *>(a.res);
+
+    // one channel chunk = 9 taps; CP = chunk parity inside the tile (chunk 0 of every tile is in halo0).
+    // `last`: last chunk of the tile -> the "next chunk" requests go to chunk 0 of the next tile (or, on the final tile,
+    // re-request data of the current one: the number of LDS-DMA instructions per tap stays constant)
+    auto chunk_body = [&](auto cp_tag, int c, bool last, bool has_next) __attribute__((always_inline)) {
+        constexpr int CP = decltype(cp_tag)::value;
+        const char *hcur = CP == 1 ? halo1 : halo0;
+        char *hnext = CP == 0 ? halo1 : halo0;
+        const bool to_next = last && has_next;
+        const int cn = last ? 0 : c + 1; // chunk the requests of this chunk are for
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
+            char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
+            const int issued = WR + (tap < kMaxPiecesPerWave ? 1 : 0);
+            if (tap < 7)
+                issue_weights(wnext2, cur.wtile, tap + 2, c);
+            else
+                issue_weights(wnext2, to_next ? nxt.wtile : cur.wtile, tap - 7, cn);
+            if (tap < kMaxPiecesPerWave) {
+                // select the geometry by value (no branch around the request)
+                Tile sel;
+                sel.img = to_next ? nxt.img : cur.img;
+                sel.hvalid = to_next ? nxt.hvalid : cur.hvalid;
+#pragma unroll
+                for (int q = 0; q < kMaxPiecesPerWave; ++q) sel.hoff[q] = to_next ? nxt.hoff[q] : cur.hoff[q];
+                issue_piece(hnext, tap, sel, cn);
+            }
+            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+            wait_vmcnt(issued);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
+
+    while (true) {
+        const bool has_next = v + G < total;
+        if (has_next) setup_tile(v + G, nxt); // overlaps this tile's MFMAs
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk_body(std::integral_constant<int, 0>{}, c, false, has_next);
+            chunk_body(std::integral_constant<int, 1>{}, c + 1, c + 2 >= nchunks, has_next);
+        }
+        // ---- epilogue of the finished tile
+        const int cb = cur.n0 + wave_c * WC + lg * NV;
+        if (cb + NV <= a.Cout) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int o = cur.o0 + wave_p * WP + j * 16 + lr;
+                const int y = (int)fdiv((unsigned)o, a.d_pitch);
+                const int x = o - y * pitch;
+                if (y >= a.H || x >= a.S || cur.xs + x >= a.W) continue;
+                float vv[NV];
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[i * 4 + r] = acc[i][j][r] + cur.bias[i * 4 + r];
+                if (a.act) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) vv[i] = silu_h(vv[i]);
+                }
+                const long long pix = ((long long)cur.n * a.H + y) * a.W + cur.xs + x;
+                if (res) {
+                    float rv[NV];
+                    load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) vv[i] += rv[i];
+                }
+                store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, vv);
+                if (out2) {
+                    const int H2 = a.H * 2, W2 = a.W * 2;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const long long pix2 = ((long long)cur.n * H2 + (2 * y + dy)) * W2 + (2 * (cur.xs + x) + dx);
+                            store_run_h<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, vv);
+                        }
+                }
+            }
+        }
+        if (!has_next) break;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        cur = nxt;
+        v += G;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the final tile's duplicate requests must not outlive the block's LDS
+}
+
+template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int num_cus, hipStream_t stream) {
+    const long long tiles = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
+    if (tiles <= 0 || tiles > 0x3fffffffLL || num_cus < 8) return hipErrorInvalidValue;
+    if (kBM + 2 * a.pitch + 2 > HROWS || (a.Cin / (8 * ElemH<T>::CE)) % 2 != 0) return hipErrorInvalidValue;
+    a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
+    a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
+    a.d_strips = make_fastdiv((unsigned)a.strips);
+    a.d_pitch = make_fastdiv((unsigned)a.pitch);
+    const long long cap = num_cus / 8 * 8; // one block per CU (156-160 KB of LDS); a multiple of 8 keeps a block's tiles on its XCD label
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    hipLaunchKernelGGL((conv3x3_halo_pkernel<T, BN, HROWS>), dim3(grid), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -427,6 +687,13 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     const int nchunks = a.Cin / cch;
     // three weight slabs + counted vmcnt (default) or the two-slab / vmcnt(0) schedule (slabs == 2).  A 192-cout tile with three
     // slabs only leaves room for 352-row windows: the planner then cuts wide maps into strips of <= 45 columns.
+    // persistent form only where a block gets to walk several tiles (measured: -5..-8 % at 6-7 tiles per CU, -1..2 % at 1.75, but
+    // +4 % when every block has exactly one tile: its per-tile bookkeeping then buys nothing)
+    const long long tiles = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / bn);
+    if (a.slabs != 2 && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
+        if (is_f16) return bn == 128 ? launch_hp<_Float16, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<_Float16, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
+        return bn == 128 ? launch_hp<float, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<float, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
+    }
     if (a.slabs != 2) {
         if (is_f16) {
             if (bn == 128) return launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax>(a, stream);

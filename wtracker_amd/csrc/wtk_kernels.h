@@ -100,6 +100,7 @@ struct HaloArgs {
     int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
     const void *zeros;
     unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_HALO_STAMPS) only
+    int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
     FastDiv d_bps, d_strips, d_pitch, d_nct; // filled by the launchers
 };
