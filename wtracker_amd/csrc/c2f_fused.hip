@@ -171,11 +171,11 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 
         // ======== stage 1: m.0.cv1 over the window -> T1 (flat, pitch 20)
         {
-            floatx4 acc[3][2];
+            floatx4 acc[3][2]; // accumulators start at the bias (as in every conv kernel of the library)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[q][i] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 2; ++i) acc[q][i] = (floatx4){bias1[i * 4 + 0], bias1[i * 4 + 1], bias1[i * 4 + 2], bias1[i * 4 + 3]};
             const bool third = wave + 16 < kT1Tiles; // wave uniform: waves 0..6 own three pixel tiles, wave 7 two
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)silu_cf(acc[q][i][r] + bias1[i * 4 + r]);
+                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)silu_cf(acc[q][i][r]);
                 uint4 bits = __builtin_bit_cast(uint4, hv);
                 const uint32_t m = inside ? 0xffffffffu : 0u;
                 bits.x &= m, bits.y &= m, bits.z &= m, bits.w &= m;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 2; ++i) acc[j][i] = (floatx4){bias2[i * 4 + 0], bias2[i * 4 + 1], bias2[i * 4 + 2], bias2[i * 4 + 3]};
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 half8 wf[2];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)pin_f32(silu_cf(acc[j][i][r] + bias2[i * 4 + r]) + (float)res[i * 4 + r]);
+                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)pin_f32(silu_cf(acc[j][i][r]) + (float)res[i * 4 + r]);
                 const int p = (2 * wave + j) * 16 + lr;
                 *reinterpret_cast<half8 *>(mbuf + row64(p, lg)) = hv;
             }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){bias3[i * 4 + 0], bias3[i * 4 + 1], bias3[i * 4 + 2], bias3[i * 4 + 3]};
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
                 half8 wf[4], pf[2];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const int idx = c2 * 8 + e;
-                            hv[e] = (_Float16)silu_cf(acc[idx >> 2][j][idx & 3] + bias3[idx]);
+                            hv[e] = (_Float16)silu_cf(acc[idx >> 2][j][idx & 3]);
                         }
                         *reinterpret_cast<half8 *>(o + c2 * 8) = hv;
                     }

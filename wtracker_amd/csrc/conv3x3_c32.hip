@@ -24,7 +24,7 @@ constexpr int kRowsMax = kHaloRowsMax; // same strip geometry as the 128-byte-ro
 
 __device__ __forceinline__ float silu_c(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    return wtk_pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
 }
 
 template <int BN> // BN = CoutPad: 32, 64 or 96; 4 waves, each 64 px x BN cout
@@ -77,16 +77,15 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const HaloArgs a) {
                                          (__attribute__((address_space(3))) void *)(wts + piece * 1024), 16, 0, 0);
     }
 
+    // accumulators start at the bias of this lane's couts (rows exist up to CoutPad), fetched while the window is in flight
+    const int cb = lg * NV;
     floatx4 acc[TC][TP];
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+    for (int i = 0; i < TC; ++i) {
+        const floatx4 b4 = (floatx4){a.bias[cb + i * 4 + 0], a.bias[cb + i * 4 + 1], a.bias[cb + i * 4 + 2], a.bias[cb + i * 4 + 3]};
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    // bias of this lane's couts, fetched while the window is in flight (bias rows exist up to CoutPad)
-    const int cb = lg * NV;
-    float bias[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
+        for (int j = 0; j < TP; ++j) acc[i][j] = b4;
+    }
 
     const int wrow_l = (lr >> 2) * NV + (lr & 3); // + 4*i per cout tile, + tap*BN
     const int wkey_l = (((wrow_l / NV) & 1) << 1) | ((wrow_l >> 1) & 1);
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
         if (a.act) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = silu_c(v[i]);

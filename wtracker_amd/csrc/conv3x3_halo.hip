@@ -42,7 +42,7 @@ template <> struct ElemH<float> {
 // epilogue, not the MFMA loop, the longest part of every conv.  v_exp/v_rcp are 1-ulp approximations.
 __device__ __forceinline__ float silu_h(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    return wtk_pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
 }
 
 __device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 &acc, _Float16 *) {
@@ -264,9 +264,13 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 
     const int nchunks = a.Cin / CCH;
     const int cb = n0 + wave_c * WC + lg * NV; // first of the NV consecutive couts this lane owns
-    float bias[NV];                            // bias rows exist up to CoutPad
+    // the accumulators start at the bias (rows exist up to CoutPad): no v_add per output value in the epilogue
 #pragma unroll
-    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
+    for (int i = 0; i < TC; ++i) {
+        const floatx4 b4 = (floatx4){a.bias[cb + i * 4 + 0], a.bias[cb + i * 4 + 1], a.bias[cb + i * 4 + 2], a.bias[cb + i * 4 + 3]};
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = b4;
+    }
 
 #ifdef WTK_HALO_STAMPS
     const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         }
     } stamp_on_exit{a.dbg_stamps + ((long long)blockIdx.x * 8 + wave) * 4, st_t0, st_t1, st_t2, a.dbg_stamps != nullptr && lane == 0};
 #endif
-    // ---- epilogue (the bias was fetched before the main loop: a load issued here would expose a full L2 round trip)
+    // ---- epilogue (the bias is already inside the accumulators)
     if (cb + NV > a.Cout) return;
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bias[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
         if (a.act) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = silu_h(v[i]);
@@ -526,6 +530,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
     Tile cur, nxt;
     setup_tile(v, cur);
     nxt = cur;
+    auto arm_acc = [&](const Tile &tc) __attribute__((always_inline)) { // accumulators start at the tile's bias
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){tc.bias[i * 4 + 0], tc.bias[i * 4 + 1], tc.bias[i * 4 + 2], tc.bias[i * 4 + 3]};
+    };
+    arm_acc(cur);
     // ---- prologue (once per block): whole window of chunk 0 + slabs of taps 0 and 1
 #pragma unroll
     for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_piece(halo0, q, cur, 0);
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[i * 4 + r] = acc[i][j][r] + cur.bias[i * 4 + r];
+                    for (int r = 0; r < 4; ++r) vv[i * 4 + r] = acc[i][j][r];
                 if (a.act) {
 #pragma unroll
                     for (int i = 0; i < NV; ++i) vv[i] = silu_h(vv[i]);
@@ -619,11 +630,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
             }
         }
         if (!has_next) break;
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
         cur = nxt;
+        arm_acc(cur);
         v += G;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the final tile's duplicate requests must not outlive the block's LDS

@@ -39,7 +39,7 @@ template <> struct Elem<float> {
 // epilogue, not the MFMA loop, the longest part of every conv.  v_exp/v_rcp are 1-ulp approximations.
 __device__ __forceinline__ float silu_f(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    return wtk_pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
 }
 
 // one 16-byte operand fragment pair -> MFMA(s)
@@ -274,14 +274,9 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         }
     };
 
+    // Accumulators START at the bias (the MFMA chain adds the products to it): saves one v_add per output value in the
+    // epilogue, where the SiLU's VALU work — not the matrix pipe — bounds every layer with a short K (-2 % conv time).
     floatx4 acc[TC][TP];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
 
     // fragment addresses: pixel tiles j are base + j*2048 (same swizzle key), cout tiles i are
     // base + i*512 (key independent of i); the second k-half is base ^ 64.
@@ -308,7 +303,8 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         }
     };
 
-    // bias of the tile being multiplied (rows exist up to CoutPad), loaded while the previous tile's epilogue retires
+    // bias of the NEXT tile to be multiplied (rows exist up to CoutPad): requested at the top of the current tile's
+    // epilogue, consumed at its end when the accumulators are re-armed — the L2 round trip hides behind the SiLU work
     float bias_r[NV];
     auto load_bias = [&](int i) __attribute__((always_inline)) {
         const int tile = t_begin + i * t_stride;
@@ -317,7 +313,14 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
         for (int e = 0; e < NV; ++e) bias_r[e] = a.bias[cb + e];
     };
+    auto arm_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){bias_r[i * 4 + 0], bias_r[i * 4 + 1], bias_r[i * 4 + 2], bias_r[i * 4 + 3]};
+    };
     load_bias(0);
+    arm_acc();
 
     // ---- epilogue of one finished tile: lane (pixel lr of tile j, group lg) owns couts cb .. cb+NV-1
     T *out = reinterpret_cast<T *>(a.out);
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         const int tile = t_begin + i * t_stride;
         const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
         const int cb = (tile - ptile * nct) * BN + wave_c * WC + lg * NV;
+        if (nct > 1 && i + 1 < my_tiles) load_bias(i + 1); // with one cout tile every tile has the same bias
         if (cb + NV <= a.Cout) { // padded output channels (Cout < CoutPad) are never stored
-            const float(&bias)[NV] = bias_r; // fetched one tile ahead: a load issued here would expose an L2 round trip per tile
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 int n, ho, wo;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r] + bias[t * 4 + r];
+                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r]; // bias already inside
                 if (a.act) {
 #pragma unroll
                     for (int e = 0; e < NV; ++e) v[e] = silu_f(v[e]);
@@ -362,8 +365,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
                 }
             }
         }
-        zero_acc();
-        if (i + 1 < my_tiles) load_bias(i + 1);
+        arm_acc();
     };
 
     // ---- flat pipeline over (tile, K step) stages: stage s+1 is in flight (LDS-DMA) while stage s is

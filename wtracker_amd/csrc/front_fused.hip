@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
                 if (wave + 8 * it >= kStemTiles) break; // wave uniform
                 const int pbase = st_pb[it];
                 const int sy = st_yx[it] >> 8, sx = st_yx[it] & 0xff;
-                floatx4 acc[2] = {(floatx4){0.f, 0.f, 0.f, 0.f}, (floatx4){0.f, 0.f, 0.f, 0.f}};
+                floatx4 acc[2] = {(floatx4){bias0[0], bias0[1], bias0[2], bias0[3]}, (floatx4){bias0[4], bias0[5], bias0[6], bias0[7]}}; // start at the bias
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     half8 pf;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)silu_ff(acc[i][r] + bias0[i * 4 + r]);
+                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)silu_ff(acc[i][r]);
                 {
                     uint4 bits = __builtin_bit_cast(uint4, hv);
                     const uint32_t m = inside ? 0xffffffffu : 0u;
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
 
         // ======== C: model.1 (3x3 / stride 2 over S) -> O1.  Wave = tile rows 2w, 2w+1 x all 64 couts
         {
-            floatx4 acc[4][2];
+            floatx4 acc[4][2]; // accumulators start at the bias (as in every conv kernel of the library)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){bias1[i * 4 + 0], bias1[i * 4 + 1], bias1[i * 4 + 2], bias1[i * 4 + 3]};
             const int wrow_l = (lr >> 2) * 16 + (lr & 3);
             const int wkey_l = (((wrow_l >> 4) & 1) << 1) | ((wrow_l >> 1) & 1);
             const unsigned wfrag0 = wrow_l * 64 + ((lg ^ wkey_l) << 4);
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int idx = c2 * 8 + e; // cout lg*16 + idx = tile idx>>2, row idx&3
-                        hv[e] = (_Float16)silu_ff(acc[idx >> 2][j][idx & 3] + bias1[idx]);
+                        hv[e] = (_Float16)silu_ff(acc[idx >> 2][j][idx & 3]);
                     }
                     const int c = 2 * lg + c2;
                     *reinterpret_cast<half8 *>(pobuf + p * 128 + ((c ^ (p & 7)) << 4)) = hv;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){bias2[i * 4 + 0], bias2[i * 4 + 1], bias2[i * 4 + 2], bias2[i * 4 + 3]};
             const int wrow_l = (lr >> 2) * 16 + (lr & 3);
             const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l >> 4) & 3) << 1);
             const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int idx = c2 * 8 + e;
-                        pend[j][c2][e] = (_Float16)silu_ff(acc[idx >> 2][j][idx & 3] + bias2[idx]);
+                        pend[j][c2][e] = (_Float16)silu_ff(acc[idx >> 2][j][idx & 3]);
                     }
             }
         }

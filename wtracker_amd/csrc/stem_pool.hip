@@ -64,11 +64,15 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
     }
 
     // ---- weights -> registers.  cout of (tile tc, MFMA row r): (r>>2)*4*TC + tc*4 + (r&3)
+    // accumulators start at the bias of the couts this lane owns (lg*4*TC .. +4*TC-1): no add in the epilogue
     floatx4_s acc[TC][4];
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+    for (int i = 0; i < TC; ++i) {
+        const int c0 = lg * 4 * TC + i * 4;
+        const floatx4_s b4 = (floatx4_s){a.bias[c0], a.bias[c0 + 1], a.bias[c0 + 2], a.bias[c0 + 3]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (floatx4_s){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = b4;
+    }
     __syncthreads();
 
     if constexpr (sizeof(T) == 2) {
@@ -126,9 +130,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
     // ---- epilogue: lane (pixel lr of row j, group lg) owns couts lg*4*TC .. +4*TC-1
     constexpr int NV = 4 * TC;
     const int cb = lg * NV;
-    float bias[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) bias[i] = a.bias[cb + i];
     T *out = reinterpret_cast<T *>(a.out);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
         for (int i = 0; i < TC; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = acc[i][j][r] + bias[i * 4 + r];
-                v[i * 4 + r] = s * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s * -1.4426950408889634f));
+                const float s = acc[i][j][r]; // bias already inside
+                v[i * 4 + r] = wtk_pin_f32(s * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s * -1.4426950408889634f)));
             }
         T *o = out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout + cb;
         if constexpr (sizeof(T) == 2) {

@@ -33,6 +33,15 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
     return (t + ((n - t) >> 1)) >> f.sh;
 }
 
+// Pins an fp32 value in a VGPR (no instruction).  hipcc folds "(half)(a * b)" into v_fma_mixlo_f16, which rounds the exact
+// product ONCE to fp16, whenever the conversion is not paired into a v_cvt_pk_f16_f32 — which depends on the surrounding
+// code.  Every SiLU of the library pins its product so that all kernels (stand-alone and fused) round product -> fp32 -> fp16
+// and stay bit-identical to each other.
+__device__ __forceinline__ float wtk_pin_f32(float v) {
+    asm("" : "+v"(v));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip).  Activations are NHWC; a tensor argument is a
 // *channel-slice view* (base pointer, pixel stride `ld` in elements, first channel `coff`), so
