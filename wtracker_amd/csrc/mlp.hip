@@ -4,6 +4,10 @@
 // bit-for-bit a k-ordered fp32 fma chain, so results stay within the reference's own
 // batch-size variance (abs 2e-4 + rel 1e-5).  Activations ping-pong between two
 // LDS buffers; the residual stream h lives in a third (h <- h + block(h), mlp.py:185-187).
+// The whole parameter blob (33 KB / 105 KB for the two shipped predictors) and the layer table are copied
+// into LDS first: the kernel is one dependent chain of ~20 tiny GEMMs, and fetching each weight element from
+// global memory inside that chain cost ~10 % of a call (59 -> 54 us for the 26-layer predictor; the rest is the
+// dependent MFMA / LDS / barrier chain itself: interleaving several output tiles per layer measured slower, 54 -> 70 us).
 //
 // The optional gather front-end is the batched form of MLPController.provide_movement_vector
 // (wtracker/sim/sim_controllers/mlp_controllers.py:38-56): 7 boxes of the track at
@@ -15,16 +19,17 @@ namespace wtk {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLdAct = kMlpMaxDim + 4; // LDS row stride (floats), +4 breaks the power-of-two stride
+constexpr int kMlpLdsParams = 32768;   // floats of the parameter blob that fit next to the activations (128 KB)
 
 // y[16][out_pad] = act(W x + b); src/dst are LDS [16][kLdAct]
-__device__ __forceinline__ void mlp_layer(const float *__restrict__ params, const MlpLayerDev &L, const float *src, float *dst,
-                                          int lane) {
+template <typename P> // P: const float * into LDS or global memory
+__device__ __forceinline__ void mlp_layer(P params, const MlpLayerDev &L, const float *src, float *dst, int lane) {
     const int r = lane & 15, g = lane >> 4;
-    const float *W = params + L.w_off;
-    const float *bvec = params + L.b_off;
+    P W = params + L.w_off;
+    P bvec = params + L.b_off;
     for (int n0 = 0; n0 < L.out_pad; n0 += 16) {
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float *wrow = W + (long long)(n0 + r) * L.in_pad;
+        P wrow = W + (n0 + r) * L.in_pad;
         for (int k0 = 0; k0 < L.in_pad; k0 += 4) {
             const float xa = src[r * kLdAct + k0 + g]; // A[row = sample r][k = k0 + g]
             const float wb = wrow[k0 + g];             // B[k = k0 + g][col = out n0 + r]
@@ -46,8 +51,18 @@ __global__ __launch_bounds__(64) void mlp_kernel(const MlpArgs a) {
     __shared__ float bufB[16 * kLdAct];
     __shared__ float bufH[16 * kLdAct];
     __shared__ int s_valid[16];
+    __shared__ __attribute__((aligned(16))) float wlds[kMlpLdsParams];
+    __shared__ MlpLayerDev s_layers[kMlpMaxLayers];
     const int lane = threadIdx.x;
     const int s0 = blockIdx.x * 16;
+    const bool in_lds = a.n_params <= kMlpLdsParams; // block uniform
+    if (in_lds) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(a.params); // hipMalloc'd: 16-byte aligned; blob padded to 4 floats
+        float4 *dst4 = reinterpret_cast<float4 *>(wlds);
+        for (int i = lane; i < (a.n_params + 3) / 4; i += 64) dst4[i] = src4[i];
+    }
+    for (int i = lane; i < a.n_layers * (int)(sizeof(MlpLayerDev) / sizeof(int)); i += 64)
+        reinterpret_cast<int *>(s_layers)[i] = reinterpret_cast<const int *>(a.layers)[i];
 
     // ---- stage the 16 input rows (zero-padded) into bufA
     for (int i = lane; i < 16 * kLdAct; i += 64) bufA[i] = 0.f;
@@ -93,26 +108,31 @@ __global__ __launch_bounds__(64) void mlp_kernel(const MlpArgs a) {
     }
     __syncthreads();
 
-    const float *params = a.params;
-    int li = 0;
-    // input layer -> h
-    mlp_layer(params, a.layers[li++], bufA, bufH, lane);
-    __syncthreads();
-    for (int b = 0; b < a.n_blocks; ++b) {
-        const float *src = bufH;
-        float *dst = bufA;
-        for (int l = 0; l < a.layers_per_block; ++l) {
-            mlp_layer(params, a.layers[li++], src, dst, lane);
-            __syncthreads();
-            src = dst;
-            dst = (dst == bufA) ? bufB : bufA;
-        }
-        // h <- h + block(h)
-        for (int i = lane; i < 16 * kLdAct; i += 64) bufH[i] += src[i];
+    auto run = [&](auto params) __attribute__((always_inline)) {
+        int li = 0;
+        // input layer -> h
+        mlp_layer(params, s_layers[li++], bufA, bufH, lane);
         __syncthreads();
-    }
-    mlp_layer(params, a.layers[li], bufH, bufA, lane);
-    __syncthreads();
+        for (int b = 0; b < a.n_blocks; ++b) {
+            const float *src = bufH;
+            float *dst = bufA;
+            for (int l = 0; l < a.layers_per_block; ++l) {
+                mlp_layer(params, s_layers[li++], src, dst, lane);
+                __syncthreads();
+                src = dst;
+                dst = (dst == bufA) ? bufB : bufA;
+            }
+            // h <- h + block(h)
+            for (int i = lane; i < 16 * kLdAct; i += 64) bufH[i] += src[i];
+            __syncthreads();
+        }
+        mlp_layer(params, s_layers[li], bufH, bufA, lane);
+        __syncthreads();
+    };
+    if (in_lds)
+        run(static_cast<const float *>(wlds));
+    else
+        run(a.params);
     for (int i = lane; i < 16 * a.out_dim; i += 64) {
         const int s = i / a.out_dim, k = i - s * a.out_dim;
         if (s0 + s < a.B) {

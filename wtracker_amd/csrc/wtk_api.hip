@@ -66,6 +66,7 @@ struct wtk_mlp {
     int n_layers = 0, n_blocks = 0, layers_per_block = 0;
     int in_dim = 0, out_dim = 0;
     float *params = nullptr;
+    int n_params = 0;
     MlpLayerDev *layers = nullptr;
     // scratch for the host-pointer entry point
     float *x_dev = nullptr, *y_dev = nullptr;
@@ -106,8 +107,10 @@ extern "C" int wtk_mlp_create(wtk_mlp **out, const wtk_mlp_desc *d) {
     // every block must return to the residual width
     for (int b = 0; b < d->n_blocks; ++b)
         if (L[d->layers_per_block * (b + 1)].out_dim != L[0].out_dim) return fail("wtk_mlp_create: block output dim != residual dim");
+    blob.resize((blob.size() + 3) / 4 * 4, 0.f); // the kernel copies it to LDS in float4 units
     wtk_mlp *h = new wtk_mlp();
     h->device = d->device;
+    h->n_params = (int)blob.size();
     h->n_layers = d->n_layers;
     h->n_blocks = d->n_blocks;
     h->layers_per_block = d->layers_per_block;
@@ -138,6 +141,7 @@ static MlpArgs mlp_base_args(wtk_mlp *h) {
     MlpArgs a;
     std::memset(&a, 0, sizeof(a));
     a.params = h->params;
+    a.n_params = h->n_params;
     a.layers = h->layers;
     a.n_layers = h->n_layers;
     a.n_blocks = h->n_blocks;

@@ -249,7 +249,8 @@ constexpr int kMlpMaxLayers = 64;
 constexpr int kMlpMaxDim = 128; // widest activation the kernel supports
 constexpr int kMlpMaxInputFrames = 16;
 struct MlpArgs {
-    const float *params;
+    const float *params; // 16-byte aligned blob, padded to a multiple of 4 floats
+    int n_params;        // floats in the blob
     const MlpLayerDev *layers; // device array
     int n_layers, n_blocks, layers_per_block;
     int in_dim, out_dim;
