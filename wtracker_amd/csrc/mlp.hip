@@ -14,15 +14,20 @@
 // anchor + input_frames, NaN / out-of-range guard, x/y made relative to the first box's corner.
 #include "wtk_kernels.h"
 
+#include <type_traits>
+
 namespace wtk {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLdAct = kMlpMaxDim + 4; // LDS row stride (floats), +4 breaks the power-of-two stride
-constexpr int kMlpLdsParams = 32768;   // floats of the parameter blob that fit next to the activations (128 KB)
+constexpr int kMlpLdsParams = 32768 - 64; // floats of the parameter blob staged in LDS (the fast path may read 63 floats past the blob)
 
 // y[16][out_pad] = act(W x + b); src/dst are LDS [16][kLdAct]
-template <typename P> // P: const float * into LDS or global memory
+// FAST (parameters in LDS): all fragments of a 64-deep K slice are fetched first — 32 LDS reads in flight instead of a
+// read -> wait -> MFMA round trip per k step — then the MFMA chain runs (same k order: bit-identical results).  Reads past
+// in_pad stay inside the activation row / the LDS parameter array and are never multiplied.
+template <bool FAST, typename P> // P: const float * into LDS or global memory
 __device__ __forceinline__ void mlp_layer(P params, const MlpLayerDev &L, const float *src, float *dst, int lane) {
     const int r = lane & 15, g = lane >> 4;
     P W = params + L.w_off;
@@ -30,10 +35,24 @@ __device__ __forceinline__ void mlp_layer(P params, const MlpLayerDev &L, const 
     for (int n0 = 0; n0 < L.out_pad; n0 += 16) {
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
         P wrow = W + (n0 + r) * L.in_pad;
-        for (int k0 = 0; k0 < L.in_pad; k0 += 4) {
-            const float xa = src[r * kLdAct + k0 + g]; // A[row = sample r][k = k0 + g]
-            const float wb = wrow[k0 + g];             // B[k = k0 + g][col = out n0 + r]
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc, 0, 0, 0);
+        if constexpr (FAST) {
+            for (int kb = 0; kb < L.in_pad; kb += 64) {
+                float xa[16], wb[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    xa[ks] = src[r * kLdAct + kb + 4 * ks + g];
+                    wb[ks] = wrow[kb + 4 * ks + g];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    if (kb + 4 * ks < L.in_pad) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wb[ks], acc, 0, 0, 0);
+            }
+        } else {
+            for (int k0 = 0; k0 < L.in_pad; k0 += 4) {
+                const float xa = src[r * kLdAct + k0 + g]; // A[row = sample r][k = k0 + g]
+                const float wb = wrow[k0 + g];             // B[k = k0 + g][col = out n0 + r]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc, 0, 0, 0);
+            }
         }
         // lane holds D[row = 4g + i][col = r]: sample 4g+i, out n0+r
         const float b = bvec[n0 + r];
@@ -51,7 +70,7 @@ __global__ __launch_bounds__(64) void mlp_kernel(const MlpArgs a) {
     __shared__ float bufB[16 * kLdAct];
     __shared__ float bufH[16 * kLdAct];
     __shared__ int s_valid[16];
-    __shared__ __attribute__((aligned(16))) float wlds[kMlpLdsParams];
+    __shared__ __attribute__((aligned(16))) float wlds[kMlpLdsParams + 64];
     __shared__ MlpLayerDev s_layers[kMlpMaxLayers];
     const int lane = threadIdx.x;
     const int s0 = blockIdx.x * 16;
@@ -108,16 +127,17 @@ __global__ __launch_bounds__(64) void mlp_kernel(const MlpArgs a) {
     }
     __syncthreads();
 
-    auto run = [&](auto params) __attribute__((always_inline)) {
+    auto run = [&](auto fast_tag, auto params) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         int li = 0;
         // input layer -> h
-        mlp_layer(params, s_layers[li++], bufA, bufH, lane);
+        mlp_layer<FAST>(params, s_layers[li++], bufA, bufH, lane);
         __syncthreads();
         for (int b = 0; b < a.n_blocks; ++b) {
             const float *src = bufH;
             float *dst = bufA;
             for (int l = 0; l < a.layers_per_block; ++l) {
-                mlp_layer(params, s_layers[li++], src, dst, lane);
+                mlp_layer<FAST>(params, s_layers[li++], src, dst, lane);
                 __syncthreads();
                 src = dst;
                 dst = (dst == bufA) ? bufB : bufA;
@@ -126,13 +146,13 @@ __global__ __launch_bounds__(64) void mlp_kernel(const MlpArgs a) {
             for (int i = lane; i < 16 * kLdAct; i += 64) bufH[i] += src[i];
             __syncthreads();
         }
-        mlp_layer(params, s_layers[li], bufH, bufA, lane);
+        mlp_layer<FAST>(params, s_layers[li], bufH, bufA, lane);
         __syncthreads();
     };
     if (in_lds)
-        run(static_cast<const float *>(wlds));
+        run(std::true_type{}, static_cast<const float *>(wlds));
     else
-        run(a.params);
+        run(std::false_type{}, a.params);
     for (int i = lane; i < 16 * a.out_dim; i += 64) {
         const int s = i / a.out_dim, k = i - s * a.out_dim;
         if (s0 + s < a.B) {
