@@ -391,9 +391,10 @@ def test_three_slab_counted_wait_schedule_equals_two_slab(hip_lib, monkeypatch, 
     depth, width, maxch = ys.SCALES["s"]
     frames = np.random.default_rng(9).integers(0, 256, size=(B, H, W), dtype=np.uint8)
     outs = []
-    for slabs, persist in (("2", "0"), ("3", "0"), ("3", "1"), ("3", "1"), ("3", "1")):
+    for slabs, persist, small in (("2", "0", "0"), ("3", "0", "0"), ("3", "1", "0"), ("3", "1", "1"), ("3", "1", "1")):
         monkeypatch.setenv("WTK_HALO_SLABS", slabs)
         monkeypatch.setenv("WTK_HALO_PERSIST", persist)  # persistent form: the tap pipeline runs on across tiles
+        monkeypatch.setenv("WTK_HALO_SMALL_BLOCKS", small)  # 128-pixel blocks on maps that would leave CUs idle
         det = hip.HipYolo(w, (H, W), B, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch)
         res = det.predict_host(frames, conf=0.05)
         outs.append((res, det.debug_head(min(B, 8))))

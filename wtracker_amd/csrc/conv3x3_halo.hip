@@ -118,7 +118,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // (raw s_barrier): a slab has two full taps to arrive instead of one.  PMC on the two-slab kernel showed every wave
 // waiting ~1/3 of its life in the vmcnt(0) that __syncthreads puts in front of each tap barrier (1 block per CU:
 // nothing else hides the L2 latency of the slab requested at the top of the same tap).
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS>
+// BMT: flat output pixels per block, 256 or 128 (small maps: twice the blocks, so a 20x20 map still fills the chip).
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
 #ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // BN = 64: 8(P) x 1(C) waves of 32 px x 64 cout; BN = 128 / 192: 4(P) x 2(C) waves of 64 px x 64 / 96 cout
     constexpr int WAVES_C = BN == 64 ? 1 : 2, WAVES_P = 8 / WAVES_C;
     constexpr int WC = BN / WAVES_C;
-    constexpr int WP = kBM / WAVES_P, TP = WP / 16, TC = WC / 16, NV = 4 * TC;
+    constexpr int WP = BMT / WAVES_P, TP = WP / 16, TC = WC / 16, NV = 4 * TC;
     constexpr int WR = BN / 64; // weight rows staged per thread per tap
 
     constexpr int kHaloBytesT = HROWS * 128;
@@ -163,10 +164,10 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     tq = fdiv(t, a.d_strips);
     const int strip = (int)(t - tq * (unsigned)a.strips);
     const int n = (int)tq;
-    const int o0 = rb * kBM;
+    const int o0 = rb * BMT;
     const int xs = strip * a.S;
     const int pitch = a.pitch;
-    const int halo_rows = kBM + 2 * pitch + 2;
+    const int halo_rows = BMT + 2 * pitch + 2;
     const int halo_pieces = (halo_rows + 7) >> 3;
 
     const T *in = reinterpret_cast<const T *>(a.in) + (long long)n * a.H * a.W * a.in_ld + a.in_coff;
@@ -651,15 +652,15 @@ template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int nu
     return hipGetLastError();
 }
 
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (kBM + 2 * a.pitch + 2 > HROWS) return hipErrorInvalidValue;
+    if (BMT + 2 * a.pitch + 2 > HROWS || (long long)a.blocks_per_strip * BMT < (long long)a.H * a.pitch) return hipErrorInvalidValue;
     a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
     a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
     a.d_strips = make_fastdiv((unsigned)a.strips);
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -672,12 +673,12 @@ bool halo_eligible(int k, int stride, int cin, int is_f16) {
 
 int halo_rows_max(int cout_stored, int slabs) { return (slabs == 3 && halo_cout_tile(cout_stored) == 192) ? kHaloRowsSmall : kHaloRowsMax; }
 
-void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip) {
-    const int smax = (rows_max - kBM - 2) / 2 - 2; // BM + 2*(S+2) + 2 <= rows_max
+void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm) {
+    const int smax = (rows_max - kBM - 2) / 2 - 2; // 256 + 2*(S+2) + 2 <= rows_max (the same strips for both block sizes)
     *strips = (W + smax - 1) / smax;
     *S = (W + *strips - 1) / *strips;
     *pitch = *S + 2;
-    *blocks_per_strip = (H * *pitch + kBM - 1) / kBM;
+    *blocks_per_strip = (H * *pitch + bm - 1) / bm;
 }
 
 int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : (cout_stored % 192 == 0 ? 192 : 64); }
@@ -689,7 +690,8 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % (bn == 192 ? 24 : 16) != 0) return hipErrorInvalidValue;
     if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
     if (a.pitch != a.S + 2 || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W) return hipErrorInvalidValue;
-    if (a.blocks_per_strip * kBM < a.H * a.pitch) return hipErrorInvalidValue;
+    const int bm = a.bm == 128 ? 128 : kBM;
+    if (a.blocks_per_strip * bm < a.H * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % ce || a.res_coff % ce)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % ce || a.out2_coff % ce)) return hipErrorInvalidValue;
     const int nchunks = a.Cin / cch;
@@ -698,10 +700,23 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     // persistent form only where a block gets to walk several tiles (measured: -5..-8 % at 6-7 tiles per CU, -1..2 % at 1.75, but
     // +4 % when every block has exactly one tile: its per-tile bookkeeping then buys nothing)
     const long long tiles = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / bn);
-    if (a.slabs != 2 && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
+    if (a.slabs != 2 && bm == kBM && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
         if (is_f16) return bn == 128 ? launch_hp<_Float16, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<_Float16, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
         return bn == 128 ? launch_hp<float, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<float, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
     }
+    if (a.slabs != 2 && bm == 128) { // half-size blocks: small maps that would otherwise leave CUs without a block
+        if (is_f16) {
+            if (bn == 128) return launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128>(a, stream);
+            if (bn == 192) return launch_h<_Float16, 192, 2, 2, 3, kHaloRowsSmall, 128>(a, stream);
+            if (nchunks == 1) return launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax, 128>(a, stream);
+            return launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128>(a, stream);
+        }
+        if (bn == 128) return launch_h<float, 128, 2, 2, 3, kHaloRowsMax, 128>(a, stream);
+        if (bn == 192) return launch_h<float, 192, 2, 2, 3, kHaloRowsSmall, 128>(a, stream);
+        if (nchunks == 1) return launch_h<float, 64, 1, 4, 3, kHaloRowsMax, 128>(a, stream);
+        return launch_h<float, 64, 2, 2, 3, kHaloRowsMax, 128>(a, stream);
+    }
+    if (bm != kBM) return hipErrorInvalidValue;
     if (a.slabs != 2) {
         if (is_f16) {
             if (bn == 128) return launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax>(a, stream);

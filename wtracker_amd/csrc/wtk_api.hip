@@ -363,6 +363,7 @@ struct wtk_yolo {
     // profiling
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
+    int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
@@ -619,6 +620,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
     if (const char *e = std::getenv("WTK_HALO_SLABS")) h->halo_slabs = e[0] == '2' ? 2 : 3;
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
+    if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -1042,8 +1044,17 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.act = op.act, g.Kpad = op.Kpad;
                 g.slabs = h->halo_slabs;
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
-                halo_geometry(ib.h, ib.w, op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs), &g.S, &g.pitch, &g.strips,
-                              &g.blocks_per_strip);
+                const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
+                halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
+                if (op.halo == 1 && h->halo_slabs == 3) {
+                    // small maps: with 256-pixel blocks a 20x20 map gives 2 blocks per image; halve the blocks when that
+                    // leaves at least half of the CUs without work
+                    const long long tiles = (long long)B * g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout));
+                    if (h->halo_small_blocks && 2 * tiles <= h->num_cus) {
+                        g.bm = 128;
+                        halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
+                    }
+                }
                 g.zeros = h->zero_page;
                 if (op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32(g, st));

@@ -109,13 +109,14 @@ struct HaloArgs {
     int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
     const void *zeros;
     unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_HALO_STAMPS) only
+    int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
     FastDiv d_bps, d_strips, d_pitch, d_nct; // filled by the launchers
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
 int halo_rows_max(int cout_stored, int slabs); // window rows the kernel variant for this Cout can hold
-void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip);
+void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256);
 int halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
 // thin fp16 layers (Cin = 32, Cout <= 96): conv3x3_c32.hip
