@@ -332,8 +332,8 @@ def test_full_size_batch64_properties(hip_lib):
 
 @pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3), (352, 224, 1), (640, 640, 3)])
 def test_fused_kernels_equal_layer_by_layer(hip_lib, monkeypatch, H, W, C):
-    """front_fused_kernel (preprocess + model.0 + model.1 + model.2.cv1) and c2f32_fused_kernel (model.2's
-    bottleneck + cv2) round to fp16 where the layer-by-layer kernels store fp16 and walk K in the same order:
+    """front_fused_kernel (preprocess + model.0 + model.1 + model.2.cv1), c2f32_fused_kernel (model.2's
+    bottleneck + cv2) and the fused 1x1 tail of the Detect box tower round to fp16 where the layer-by-layer kernels store fp16 and walk K in the same order:
     every head logit must be bit-identical, on full tiles, ragged tiles (maps not a multiple of 16), gray and
     BGR frames, with either or both fusions active."""
     B = 3
@@ -342,9 +342,10 @@ def test_fused_kernels_equal_layer_by_layer(hip_lib, monkeypatch, H, W, C):
     rng = np.random.default_rng(H * 7 + W + C)
     frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
     outs = []
-    for no_front, no_c2f in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+    for no_front, no_c2f, no_tail in (("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("0", "0", "1"), ("0", "0", "0")):
         monkeypatch.setenv("WTK_NO_FUSED_FRONT", no_front)
         monkeypatch.setenv("WTK_NO_FUSED_C2F", no_c2f)
+        monkeypatch.setenv("WTK_NO_FUSED_TAIL", no_tail)  # Detect box tower: last 1x1 inside the 3x3's epilogue
         det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
         res = det.predict_host(frames, conf=0.05)
         outs.append((res, det.debug_head(B), det.debug_tensor(3, B)))  # conv 3 = model.2.cv2

@@ -119,7 +119,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // waiting ~1/3 of its life in the vmcnt(0) that __syncthreads puts in front of each tap barrier (1 block per CU:
 // nothing else hides the L2 latency of the slab requested at the top of the same tap).
 // BMT: flat output pixels per block, 256 or 128 (small maps: twice the blocks, so a 20x20 map still fills the chip).
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256>
+// TAIL: instantiation with the fused 1x1 tail (see the epilogue); a separate instantiation so that its extra registers do
+// not touch the plain variant's allocation (the 64-cout variant lives at 2 blocks per CU = 128 VGPRs).
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
 #ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
@@ -349,6 +351,76 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #endif
     // ---- epilogue (the bias is already inside the accumulators)
     if (cb + NV > a.Cout) return;
+    // ---- fused 1x1 tail (fp16, 64-cout tile: the wave owns ALL 64 output channels of its pixels).  The Detect box tower's
+    // last conv (1x1, 64 -> 64, no activation) consumes this conv's output and nothing else does: instead of writing the
+    // 64-channel tensor and launching a second kernel that reads it back, the SiLU'd fp16 values go to a wave-local LDS tile
+    // (the window buffer is free after the last tap's barrier) and are multiplied by the 1x1 weights right here.  Same fp16
+    // rounding of the intermediate, same K order (two 32-deep steps), same MFMA: bit-identical to the two-kernel path.
+    if constexpr (TAIL) {
+        static_assert(!TAIL || (BN == 64 && sizeof(T) == 2), "fused tail: fp16, 64-cout tile");
+        {
+            static_assert(BN != 64 || TC == 4, "64 couts per wave");
+            char *tile = halo0 + wave * (WP * 128); // WP rows of 128 B: 64 channels of the wave's pixels
+            const _Float16 *w2 = reinterpret_cast<const _Float16 *>(a.tail_w);
+            const int arow = (lr >> 2) * 16 + (lr & 3); // + 4i: cout row of A fragment tile i (same permutation as above)
+            half8 wf2[2][4]; // A fragments straight from global memory (8 KB of weights, L2 resident); requested first, used last
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf2[ks][i] = *reinterpret_cast<const half8 *>(w2 + (long long)(arow + 4 * i) * a.tail_kpad + ks * 32 + lg * 8);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = j * 16 + lr; // row of the wave's tile
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int idx = c2 * 8 + e;
+                        const float x = acc[idx >> 2][j][idx & 3];
+                        hv[e] = (_Float16)(a.act ? silu_h(x) : x);
+                    }
+                    const int c = 2 * lg + c2;
+                    *reinterpret_cast<half8 *>(tile + p * 128 + ((c ^ (p & 7)) << 4)) = hv;
+                }
+            }
+            // the first conv's accumulators are dead now: the second set starts at the tail's bias
+            floatx4 acc2[4][TP];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const floatx4 b4 = (floatx4){a.tail_bias[lg * 16 + i * 4 + 0], a.tail_bias[lg * 16 + i * 4 + 1], a.tail_bias[lg * 16 + i * 4 + 2],
+                                             a.tail_bias[lg * 16 + i * 4 + 3]};
+#pragma unroll
+                for (int j = 0; j < TP; ++j) acc2[i][j] = b4;
+            }
+            // wave-local tile: a wave's LDS operations execute in order, no barrier
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int p = j * 16 + lr;
+                    const half8 pf = *reinterpret_cast<const half8 *>(tile + p * 128 + (((ks * 4 + lg) ^ (p & 7)) << 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf2[ks][i], pf, acc2[i][j], 0, 0, 0);
+                }
+            _Float16 *tout = reinterpret_cast<_Float16 *>(a.tail_out);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int o = o0 + wave_p * WP + j * 16 + lr;
+                const int y = (int)fdiv((unsigned)o, a.d_pitch);
+                const int x = o - y * pitch;
+                if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
+                const long long pix = ((long long)n * a.H + y) * a.W + xs + x;
+                float v2[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r];
+                store_run_h<16>(tout + pix * a.tail_ld + a.tail_coff + lg * 16, v2);
+            }
+            return;
+        }
+    }
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
     const T *res = reinterpret_cast<const T *>(a.res);
@@ -652,7 +724,7 @@ template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int nu
     return hipGetLastError();
 }
 
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (BMT + 2 * a.pitch + 2 > HROWS || (long long)a.blocks_per_strip * BMT < (long long)a.H * a.pitch) return hipErrorInvalidValue;
@@ -660,7 +732,7 @@ template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT =
     a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
     a.d_strips = make_fastdiv((unsigned)a.strips);
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT, TAIL>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -690,6 +762,9 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % (bn == 192 ? 24 : 16) != 0) return hipErrorInvalidValue;
     if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
     if (a.pitch != a.S + 2 || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W) return hipErrorInvalidValue;
+    if (a.tail_w && (!is_f16 || bn != 64 || a.Cout != 64 || a.CoutPad != 64 || a.res || a.out2 || !a.tail_bias || !a.tail_out || a.tail_kpad < 64 ||
+                     a.tail_kpad % 8 || a.tail_ld % 8 || a.tail_coff % 8 || a.slabs == 2))
+        return hipErrorInvalidValue; // the fused 1x1 tail exists for the fp16 64-cout three-slab variants only
     const int bm = a.bm == 128 ? 128 : kBM;
     if (a.blocks_per_strip * bm < a.H * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % ce || a.res_coff % ce)) return hipErrorInvalidValue;
@@ -703,6 +778,10 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     if (a.slabs != 2 && bm == kBM && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
         if (is_f16) return bn == 128 ? launch_hp<_Float16, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<_Float16, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
         return bn == 128 ? launch_hp<float, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<float, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
+    }
+    if (a.tail_w) { // validated above: fp16, 64-cout tile, three slabs
+        if (bm == 128) return nchunks == 1 ? launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax, 128, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, true>(a, stream);
+        return nchunks == 1 ? launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax, 256, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, true>(a, stream);
     }
     if (a.slabs != 2 && bm == 128) { // half-size blocks: small maps that would otherwise leave CUs without a block
         if (is_f16) {

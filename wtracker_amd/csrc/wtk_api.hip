@@ -321,6 +321,8 @@ struct Op {
     int out_buf = -1, out_coff = 0;
     int out2_buf = -1, out2_coff = 0;
     int res_buf = -1, res_coff = 0;
+    int tail_op = -1; // index of a 1x1 op (64 -> 64, no activation) computed in this op's epilogue (conv3x3_halo fused tail)
+    int folded = 0;   // 1: this op runs inside another op's kernel
     int in2_buf = -1, in2_coff = 0, in2_split = 0; // half-resolution source of the first in2_split input channels (ConvArgs::in2)
     int cout = 0, cout_pad = 0, k = 1, stride = 1, act = 1;
     int cfg = 0;
@@ -363,6 +365,7 @@ struct wtk_yolo {
     // profiling
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
+    int use_tail = 1; // WTK_NO_FUSED_TAIL=1: Detect box.2 as its own launch (A/B switch)
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
@@ -621,6 +624,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_SLABS")) h->halo_slabs = e[0] == '2' ? 2 : 3;
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
+    if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -748,6 +752,14 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         P.conv({cl + ".1"}, d1, dims.hb, d2c, 0);
         P.conv({b + ".2"}, d2b, 0, h->box_buf[i], 0);
         P.conv({cl + ".2"}, d2c, 0, h->cls_buf[i], 0, -1, 0, -1, 0, h->cls_ld);
+        if (!P.failed && h->use_tail) { // box tower: the last 1x1 runs in the epilogue of the 3x3 before it (fp16, 64 channels)
+            Op &b1 = h->ops[first_op + 1], &b2 = h->ops[first_op + 3];
+            if (h->is_f16 && b1.halo == 1 && b1.cout == 64 && b1.cout_pad == 64 && b2.k == 1 && b2.cin == 64 && b2.cout == 64 && !b2.act &&
+                b2.in_buf == b1.out_buf && b2.res_buf < 0 && b2.out2_buf < 0 && b1.res_buf < 0 && b1.out2_buf < 0 && h->halo_slabs == 3) {
+                b1.tail_op = (int)first_op + 3;
+                b2.folded = 1;
+            }
+        }
         if (!P.failed && i < 2) { // P3 and P4 towers only need t15 / t18: independent of the rest of the PAN path
             for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = 1;
             h->ops[first_op].wait_feat = i;
@@ -942,6 +954,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     for (size_t oi = first_op; oi < h->ops.size(); ++oi) {
         const Op &op = h->ops[oi];
         if (h->use_c2f && (oi == 3 || oi == 4)) continue; // folded into the fused C2f tail launched at op 5
+        if (op.folded) continue;                          // runs in the epilogue of the op that names it as tail_op
         if (h->use_c2f && oi == 5) {
             if (mark(1)) return 1;
             const Op &m1 = h->ops[3], &m2 = h->ops[4];
@@ -1043,6 +1056,11 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.res = a.res, g.res_ld = a.res_ld, g.res_coff = a.res_coff;
                 g.act = op.act, g.Kpad = op.Kpad;
                 g.slabs = h->halo_slabs;
+                if (op.tail_op >= 0) {
+                    const Op &t = h->ops[op.tail_op];
+                    g.tail_w = t.w, g.tail_bias = t.bias, g.tail_kpad = t.Kpad;
+                    g.tail_out = h->bufs[t.out_buf].ptr, g.tail_ld = h->bufs[t.out_buf].C, g.tail_coff = t.out_coff;
+                }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
                 const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
                 halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);

@@ -109,6 +109,12 @@ struct HaloArgs {
     int S, pitch, strips, blocks_per_strip; // column-strip geometry, see halo_geometry()
     const void *zeros;
     unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_HALO_STAMPS) only
+    // optional fused 1x1 tail (fp16, Cout == 64): out_tail[p][0..63] = tail_w[64][tail_kpad] . act(conv(p)) + tail_bias, no activation;
+    // when set, `out` is NOT written (the intermediate stays on chip)
+    const void *tail_w;
+    const float *tail_bias;
+    void *tail_out;
+    int tail_kpad, tail_ld, tail_coff;
     int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
