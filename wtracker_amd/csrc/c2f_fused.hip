@@ -162,11 +162,24 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
     const int wrow_c = (lr >> 2) * 16 + (lr & 3);
     const unsigned wfrag_c = wrow_c * 64 + ((lg ^ ((((wrow_c >> 4) & 1) << 1) | ((wrow_c >> 1) & 1))) << 4);
 
+#ifdef WTK_C2F_STAMPS // diagnostic builds only: per-wave cycle totals of each stage (s_memtime deltas)
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define C2F_STAMP(i)                                                 \
+    {                                                                \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        st_sum[i] += now - st_prev;                                  \
+        st_prev = now;                                               \
+    }
+#else
+#define C2F_STAMP(i)
+#endif
     auto do_tile = [&](const char *bcur, char *bnext, int tile, int next_tile) __attribute__((always_inline)) {
         int n, y0, x0;
         tile_coords(tile, n, y0, x0);
         // next window + this wave's a rows stream in while stages 1 and 2 run
         issue_a(tile);
+        C2F_STAMP(0);
         if (next_tile < a.total_tiles) issue_window(bnext, next_tile);
 
         // ======== stage 1: m.0.cv1 over the window -> T1 (flat, pitch 20)
@@ -210,7 +223,9 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
                 *reinterpret_cast<uint4 *>(t1buf + row64(o, lg)) = bits;
             }
         }
+        C2F_STAMP(1);
         lds_barrier(); // T1 complete
+        C2F_STAMP(2);
 
         // ======== stage 2: m.0.cv2 over T1 (+ b) -> M.  Wave = tile rows 2w, 2w+1, all 32 couts
         half8 bfrag[2]; // the pixel's own b channels: residual here, and the SAME 16 bytes are cv2's B fragment of k-step 1
@@ -252,7 +267,9 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
         // (window + its a rows), then the barrier retires all reads of bcur / T1.  Stage 3 below touches only
         // wave-local LDS (A, M) and registers, so waves run on into the next tile without another barrier and this
         // tile's output stores stay in flight until the same point of the next tile.
+        C2F_STAMP(3);
         vm_lds_barrier();
+        C2F_STAMP(4);
 
         // ======== stage 3: cv2 over [a | b | m] -> global.  Same pixels as stage 2: M and A are wave-local
         {
@@ -300,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
                 }
             }
         }
+        C2F_STAMP(5);
     };
 
     int tile = blockIdx.x;
@@ -313,6 +331,10 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
         do_tile(bwin1, bwin0, tile, tile + step);
         tile += step;
     }
+#ifdef WTK_C2F_STAMPS
+    if (lane == 0 && a.dbg_stamps)
+        for (int i = 0; i < 6; ++i) a.dbg_stamps[((long long)blockIdx.x * 8 + wave) * 6 + i] = st_sum[i];
+#endif
 }
 
 } // namespace

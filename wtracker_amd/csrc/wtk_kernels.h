@@ -178,6 +178,7 @@ struct C2fArgs {
     void *out; // [N][H][W] slice view, 64 channels
     int out_ld, out_coff;
     const void *zeros;
+    unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_C2F_STAMPS) only
     int tiles_x, tiles_y, total_tiles; // filled by the launcher
     FastDiv d_tpi, d_tilesx;
 };
