@@ -1,0 +1,37 @@
+// Diagnostic harness: where a tap of conv3x3_halo_kernel (three-slab form, one tile per block) spends its cycles.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DWTK_HALO_TAP_STAMPS -I wtracker_amd/csrc tools/halo_tap_stamps.hip -o /tmp/halo_tap
+#include "../wtracker_amd/csrc/conv3x3_halo.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main(int argc, char **argv) {
+    const int N = 64, HW = argc > 1 ? std::atoi(argv[1]) : 20, C = argc > 2 ? std::atoi(argv[2]) : 256, CO = argc > 3 ? std::atoi(argv[3]) : 256;
+    const size_t px = (size_t)N * HW * HW;
+    std::vector<uint16_t> in(px * C), w((size_t)CO * 9 * C);
+    for (auto &v : in) v = (uint16_t)(0x3000 + (std::rand() & 0x3ff));
+    for (auto &v : w) v = (uint16_t)(0x2000 + (std::rand() & 0x3ff) + ((std::rand() & 1) << 15));
+    std::vector<float> b(CO, 0.01f);
+    void *din, *dw, *dout, *dz; float *db; unsigned long long *dst;
+    CK(hipMalloc(&din, in.size() * 2)); CK(hipMalloc(&dw, w.size() * 2)); CK(hipMalloc(&dout, px * CO * 2)); CK(hipMalloc(&db, CO * 4)); CK(hipMalloc(&dz, 4096));
+    CK(hipMemset(dz, 0, 4096));
+    CK(hipMemcpy(din, in.data(), in.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), CO * 4, hipMemcpyHostToDevice));
+    wtk::HaloArgs a{};
+    a.in = din, a.in_ld = C, a.N = N, a.H = HW, a.W = HW, a.Cin = C, a.Cout = CO, a.CoutPad = CO, a.w = dw, a.bias = db, a.out = dout, a.out_ld = CO, a.act = 1, a.Kpad = 9 * C, a.zeros = dz, a.slabs = 3;
+    wtk::halo_geometry(HW, HW, wtk::halo_rows_max(CO, 3), &a.S, &a.pitch, &a.strips, &a.blocks_per_strip);
+    const int bn = wtk::halo_cout_tile(CO);
+    const long long blocks = (long long)N * a.strips * a.blocks_per_strip * (CO / bn);
+    CK(hipMalloc(&dst, blocks * 8 * 4 * 8)); CK(hipMemset(dst, 0, blocks * 8 * 4 * 8));
+    a.dbg_stamps = dst;
+    for (int i = 0; i < 5; ++i) CK(wtk::launch_conv3x3_halo(a, 1, nullptr));
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(blocks * 32);
+    CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+    const double taps = 9.0 * (C / 64);
+    double s0 = 0, s1 = 0, s2 = 0; long long n = 0;
+    for (long long i = 0; i < blocks * 8; ++i) { if (!st[i * 4]) continue; s0 += st[i * 4]; s1 += st[i * 4 + 1]; s2 += st[i * 4 + 2]; ++n; }
+    const double mf = (bn / 2 / 16) * 4 * 2 * 16.0; // MFMAs per wave per tap x 16 cycles
+    std::printf("%dx%d C%d->%d (bn %d): per tap and wave: work %.0f cyc (MFMA issue alone %.0f), vmcnt wait %.0f, barrier wait %.0f\n", HW, HW, C, CO, bn, s0 / n / taps, mf,
+                s1 / n / taps, s2 / n / taps);
+    return 0;
+}

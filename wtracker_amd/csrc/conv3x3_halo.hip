@@ -288,6 +288,10 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
     __syncthreads();
 
+#ifdef WTK_HALO_TAP_STAMPS // diagnostic builds: per-wave cycle totals of (issue + ds_read + MFMA), vmcnt wait, barrier wait
+    unsigned long long tap_sum[3] = {0, 0, 0};
+    unsigned long long tap_prev = __builtin_amdgcn_s_memtime();
+#endif
     // one channel chunk = 9 taps.  CP = parity of the chunk: window in halo[CP].
     // NWB == 2: tap t's weights in wbuf[(CP+t)&1], next tap's slab requested at the top of the tap, vmcnt(0) at its end.
     // NWB == 3: tap t's weights in wbuf[t % 3] (9 taps per chunk keep the ring aligned), slab of tap t+2 requested at the
@@ -319,18 +323,32 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
                 // in flight.  Where nothing is needed (last chunk: no next slab / no next window) a harmless duplicate
                 // is requested instead: a slab nobody reads again, or a window piece of the dead buffer.
                 const int issued = WR + ((NHALO == 2 && tap < kMaxPiecesPerWave) ? 1 : 0); // constant after unrolling
+                compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+                // The requests go out AFTER the tap's fragment reads and MFMAs have been issued: an LDS-DMA instruction costs
+                // 100-185 issue cycles next to ds_reads but far less in the quiet stretch before the barrier, where this wave
+                // would otherwise only wait for its SIMD neighbour (stamped: ~290 of ~1530 cycles per tap)
                 if (tap < 7)
                     issue_weights(wnext2, tap + 2, c);
                 else
                     issue_weights(wnext2, tap - 7, more ? c + 1 : c);
                 if (NHALO == 2 && tap < kMaxPiecesPerWave) issue_halo_piece_always(hnext, tap, more ? c + 1 : c); // tap is unrolled
-                compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
                 // everything requested in EARLIER taps (next tap's slab, older window pieces) has landed; this tap's
                 // requests keep flying.  lgkmcnt(0): this wave's fragment reads of wcur / hcur are done.
+#ifdef WTK_HALO_TAP_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+                wait_vmcnt(issued);
+                const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+                tap_sum[0] += ts0 - tap_prev, tap_sum[1] += ts1 - ts0, tap_sum[2] += ts2 - ts1, tap_prev = ts2;
+#else
                 wait_vmcnt(issued);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#endif
             }
         }
     };
@@ -339,6 +357,10 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         if (c + 1 < nchunks) chunk_body(std::integral_constant<int, 1>{}, c + 1);
     }
 
+#ifdef WTK_HALO_TAP_STAMPS
+    if (lane == 0 && a.dbg_stamps)
+        for (int i = 0; i < 3; ++i) a.dbg_stamps[((long long)blockIdx.x * 8 + wave) * 4 + i] = tap_sum[i];
+#endif
 #ifdef WTK_HALO_STAMPS
     const unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
     struct StampOnExit {
@@ -636,6 +658,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
             const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
             char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
             const int issued = WR + (tap < kMaxPiecesPerWave ? 1 : 0);
+            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+            // requests after the tap's reads and MFMAs (see conv3x3_halo_kernel)
             if (tap < 7)
                 issue_weights(wnext2, cur.wtile, tap + 2, c);
             else
@@ -649,7 +673,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
                 for (int q = 0; q < kMaxPiecesPerWave; ++q) sel.hoff[q] = to_next ? nxt.hoff[q] : cur.hoff[q];
                 issue_piece(hnext, tap, sel, cn);
             }
-            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
             wait_vmcnt(issued);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
