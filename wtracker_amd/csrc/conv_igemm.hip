@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 }
 
 int conv_cfg_bm(int cfg) { return (cfg == CFG_128x128 || cfg == CFG_128x64) ? 128 : 256; }
-int conv_cfg_bn(int cfg) { return (cfg == CFG_128x128 || cfg == CFG_256x128) ? 128 : ((cfg == CFG_256x64 || cfg == CFG_128x64) ? 64 : (cfg == CFG_256x256 ? 256 : 32)); }
+int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : ((cfg == CFG_256x64 || cfg == CFG_128x64) ? 64 : 32); }
 
 hipError_t conv_init_attributes() { return hipSuccess; } // LDS is static: nothing to raise
 
@@ -486,18 +486,14 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
         case CFG_128x128: return launch_t<_Float16, 128, 128, 2, 2>(a, stream);
         case CFG_256x64: return launch_t<_Float16, 256, 64, 4, 1>(a, stream);
         case CFG_256x32: return launch_t<_Float16, 256, 32, 4, 1>(a, stream);
-        case CFG_256x256: return launch_t<_Float16, 256, 256, 4, 2>(a, stream);
         case CFG_128x64: return launch_t<_Float16, 128, 64, 4, 1>(a, stream);
-        case CFG_256x128: return launch_t<_Float16, 256, 128, 4, 2>(a, stream);
         }
     } else {
         switch (cfg) {
         case CFG_128x128: return launch_t<float, 128, 128, 2, 2>(a, stream);
         case CFG_256x64: return launch_t<float, 256, 64, 4, 1>(a, stream);
         case CFG_256x32: return launch_t<float, 256, 32, 4, 1>(a, stream);
-        case CFG_256x256: return launch_t<float, 256, 256, 4, 2>(a, stream);
         case CFG_128x64: return launch_t<float, 128, 64, 4, 1>(a, stream);
-        case CFG_256x128: return launch_t<float, 256, 128, 4, 2>(a, stream);
         }
     }
     return hipErrorInvalidValue;

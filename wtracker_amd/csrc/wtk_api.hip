@@ -423,13 +423,8 @@ static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
 }
 
 static int pick_cfg(int cout, bool k1) {
-    // The 8-wave 256x256 tile (64 px x 128 cout per wave) is kept for experiments only: on this network it
-    // measured 0..+30 % SLOWER than 128x128 on every 1x1 layer with Cout >= 256 (fewer, fatter blocks).
-    static const bool big = []() { const char *e = std::getenv("WTK_BIG_TILE"); return e && e[0] == '1'; }();
-    if (big && k1 && cout % 256 == 0) return CFG_256x256;
-    // experiment: 8-wave 256x128 tile (25 % fewer staged bytes per MFMA than 128x128); "1": 1x1 convs, "2": also 3x3
-    static const int t256 = []() { const char *e = std::getenv("WTK_TILE_256x128"); return e ? std::atoi(e) : 0; }();
-    if (t256 && (k1 || t256 > 1) && cout % 128 == 0) return CFG_256x128;
+    // 8-wave tiles (256x256, 256x128, also with a three-buffer ring) all measured 3..30 % slower than two independent
+    // 4-wave 128x128 blocks per CU (profiles/r01_notes.md) and were removed.
     if (cout % 128 == 0) return CFG_128x128;
     if (k1 && cout % 64 == 0) return CFG_128x64; // 48 KB LDS, 123 VGPRs: 3 blocks per CU on the HBM-bound 1x1 layers (+8 %)
     if (cout % 64 == 0) return CFG_256x64;
@@ -523,7 +518,6 @@ struct Planner {
         op.in2_buf = in2_buf;
         op.in2_coff = in2_coff;
         op.in2_split = in2_split;
-        if (in2_buf >= 0 && op.cfg == CFG_256x128) op.cfg = CFG_128x128; // the two-source loader exists for this tile only
         if (in2_buf >= 0) {
             const Buf &lb = h->bufs[in2_buf];
             const Buf &hb = h->bufs[in_buf];

@@ -78,8 +78,8 @@ struct ConvArgs {
     const void *zeros; // >= 16 zero bytes in device memory (source of padded / out-of-range chunks)
 };
 
-// Tile configurations: 4 waves (256 threads) except CFG_256x256 (8 waves of 64 px x 128 cout) and CFG_256x128 (8 waves of 64 x 64)
-enum ConvCfg { CFG_128x128 = 0, CFG_256x64 = 1, CFG_256x32 = 2, CFG_256x256 = 3, CFG_128x64 = 4, CFG_256x128 = 5 };
+// Tile configurations (pixels x couts), all 4 waves / 256 threads
+enum ConvCfg { CFG_128x128 = 0, CFG_256x64 = 1, CFG_256x32 = 2, CFG_128x64 = 4 };
 int conv_cfg_bm(int cfg);
 int conv_cfg_bn(int cfg);
 // is_f16: 1 -> _Float16 storage + v_mfma_f32_16x16x32_f16; 0 -> fp32 + v_mfma_f32_16x16x4_f32
