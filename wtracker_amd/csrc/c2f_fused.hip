@@ -40,8 +40,7 @@ __device__ __forceinline__ float pin_f32(float v) {
 // same SiLU as the stand-alone kernels; the product is pinned to fp32 so "(half)(x * r)" is never folded into a
 // single-rounding v_fma_mixlo_f16 (see front_fused.hip)
 __device__ __forceinline__ float silu_cf(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
+    return wtk_silu_scaled(x); // scaled domain, see wtk_kernels.h
 }
 // Raw barriers: s_waitcnt + s_barrier, with compiler-level memory clobbers so no LDS access is moved across them
 // (the s_barrier intrinsic alone is IntrNoMem).  lds_barrier leaves global loads/stores and LDS-DMA in flight.

@@ -23,8 +23,7 @@ constexpr int kBM = 256;
 constexpr int kRowsMax = kHaloRowsMax; // same strip geometry as the 128-byte-row kernel
 
 __device__ __forceinline__ float silu_c(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return wtk_pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
+    return wtk_silu_scaled(x); // x is the log2(e)-scaled pre-activation (wtk_kernels.h)
 }
 
 template <int BN> // BN = CoutPad: 32, 64 or 96; 4 waves, each 64 px x BN cout

@@ -41,8 +41,7 @@ template <> struct ElemH<float> {
 // x / (1 + __expf(-x)) expands to ~35 instructions (IEEE division + range-checked exp) and made the
 // epilogue, not the MFMA loop, the longest part of every conv.  v_exp/v_rcp are 1-ulp approximations.
 __device__ __forceinline__ float silu_h(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return wtk_pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
+    return wtk_silu_scaled(x); // x is the log2(e)-scaled pre-activation (wtk_kernels.h)
 }
 
 __device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 &acc, _Float16 *) {

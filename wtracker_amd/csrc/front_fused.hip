@@ -60,8 +60,7 @@ __device__ __forceinline__ float pin_f32(float v) {
 }
 
 __device__ __forceinline__ float silu_ff(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return pin_f32(x * __builtin_amdgcn_rcpf(1.0f + e));
+    return wtk_silu_scaled(x); // scaled domain, see wtk_kernels.h
 }
 
 __device__ __forceinline__ _Float16 norm_byte(uint32_t b) { return (_Float16)pin_f32((float)b * kInv255); }

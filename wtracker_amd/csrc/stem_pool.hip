@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s = acc[i][j][r]; // bias already inside
-                v[i * 4 + r] = wtk_pin_f32(s * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s * -1.4426950408889634f)));
+                v[i * 4 + r] = wtk_silu_scaled(s);
             }
         T *o = out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout + cb;
         if constexpr (sizeof(T) == 2) {

@@ -432,6 +432,8 @@ static int pick_cfg(int cout, bool k1) {
 }
 
 // pack [cout][k][k][cin] fp32 -> [cout_pad][Kpad] storage dtype (zero padded) on the device
+// Scaled activation domain (wtk_kernels.h, kActScale): every conv but the stem reads log2(e)-scaled activations; SiLU layers
+// produce scaled outputs.  w_scale = (act ? s : 1) / s, b_scale = act ? s : 1; for a SiLU layer w_scale is exactly 1.
 static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_parts, const std::vector<const float *> &b_parts,
                      const std::vector<int> &couts) {
     const int ce = h->is_f16 ? 8 : 4;
@@ -445,6 +447,11 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
         for (int o = 0; o < couts[p]; ++o, ++row) {
             std::memcpy(&wf[(size_t)row * op.Kpad], w_parts[p] + (size_t)o * op.K, sizeof(float) * op.K);
             bf[row] = b_parts[p][o];
+            if (op.act) {
+                bf[row] = (float)((double)bf[row] * (double)kActScale);
+            } else { // linear layer fed by scaled activations: take the scale out again
+                for (int k = 0; k < op.K; ++k) wf[(size_t)row * op.Kpad + k] = (float)((double)wf[(size_t)row * op.Kpad + k] / (double)kActScale);
+            }
         }
     }
     if (dev_alloc(h, (void **)&op.bias, bf.size() * sizeof(float))) return 1;
@@ -665,7 +672,10 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         std::vector<float> wp((size_t)c[0] * taps * 4, 0.f);
         for (int co = 0; co < c[0]; ++co)
             for (int tap = 0; tap < 9; ++tap)
-                for (int ch = 0; ch < 3; ++ch) wp[((size_t)co * taps + tap) * 4 + ch] = w0[((size_t)co * 9 + tap) * 3 + ch];
+                for (int ch = 0; ch < 3; ++ch) // the stem reads unscaled pixels and produces scaled activations
+                    wp[((size_t)co * taps + tap) * 4 + ch] = (float)((double)w0[((size_t)co * 9 + tap) * 3 + ch] * (double)kActScale);
+        std::vector<float> stem_bias(c[0]);
+        for (int co = 0; co < c[0]; ++co) stem_bias[co] = (float)((double)d->convs[i0].bias[co] * (double)kActScale);
         void *wdev;
         float *bdev;
         std::vector<uint16_t> wh;
@@ -682,7 +692,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             return 1;
         }
         if (hipMemcpy(wdev, src, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(bdev, d->convs[i0].bias, sizeof(float) * c[0], hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(bdev, stem_bias.data(), sizeof(float) * c[0], hipMemcpyHostToDevice) != hipSuccess) {
             wtk_yolo_destroy(h);
             return fail("wtk_yolo_create: stem weight upload failed");
         }
@@ -1229,7 +1239,9 @@ extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B,
     HIP_TRY(hipMemcpy(tmp.data(), b.ptr, tmp.size(), hipMemcpyDeviceToHost));
     std::vector<float> full(px * b.C);
     to_f32(tmp.data(), full.data(), full.size(), h->is_f16);
-    for (size_t i = 0; i < px; ++i) std::memcpy(out_host + i * op->cout, &full[i * b.C + op->out_coff], sizeof(float) * op->cout);
+    const float unscale = op->act ? 1.0f / kActScale : 1.0f; // SiLU outputs are stored log2(e)-scaled
+    for (size_t i = 0; i < px; ++i)
+        for (int k = 0; k < op->cout; ++k) out_host[i * op->cout + k] = full[i * b.C + op->out_coff + k] * unscale;
     return 0;
 }
 

@@ -42,6 +42,18 @@ __device__ __forceinline__ float wtk_pin_f32(float v) {
     return v;
 }
 
+// Activations live in a SCALED domain: every SiLU layer's weights-and-bias are packed so that its accumulator holds
+// a = log2(e) * x, and it stores y = a / (1 + 2^-a) = log2(e) * SiLU(x).  The consumer of a scaled tensor divides its weights by
+// log2(e) when packing (for a SiLU layer fed by a SiLU layer the two factors cancel: only the bias is scaled; the stem scales its
+// weights, the linear Detect outputs divide theirs), so logits and boxes come out unscaled.  What it buys: exp(-x) = 2^(-a) needs no
+// multiply — SiLU is v_exp (with a free negate), v_add, v_rcp, v_mul: one VALU instruction less per output value in epilogues that
+// are VALU bound (-1 % end to end).  Concatenation, residual adds, max-pooling and 2x upsampling commute with a positive scale.
+constexpr float kActScale = 1.4426950408889634f; // log2(e)
+__device__ __forceinline__ float wtk_silu_scaled(float a) {
+    const float e = __builtin_amdgcn_exp2f(-a);
+    return wtk_pin_f32(a * __builtin_amdgcn_rcpf(1.0f + e));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip).  Activations are NHWC; a tensor argument is a
 // *channel-slice view* (base pointer, pixel stride `ld` in elements, first channel `coff`), so
