@@ -76,17 +76,23 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
         fl = sum(2.0 * px4 * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[i0 : i0 + 3])
         by = px4 * 64 * es + px4 * 64 * es
         ops = ops[:i0] + [("model.2 tail(m.0+cv2)", "fused", 4, 0, 0, 0, (fl, by))] + ops[i0 + 3 :]
-    if any("conv3x3_halo_kernel" in k and "Lb1EEEvNS_8HaloArgsE" in k for k in kernel_names):
-        # Detect box tower: box.2 (1x1) runs in the epilogue of box.1 (TAIL instantiation of the window kernel)
+    # Detect towers: the last 1x1 runs in the epilogue of the 3x3 before it (TAIL instantiations of the window kernel:
+    # 64-cout tile = box tower, 128-cout tile = class tower)
+    tails = {"box": any("conv3x3_halo_kernel" in k and "Li64E" in k and "Lb1EEEvNS_8HaloArgsE" in k for k in kernel_names),
+             "cls": any("conv3x3_halo_kernel" in k and "Li128E" in k and "Lb1EEEvNS_8HaloArgsE" in k for k in kernel_names)}
+    for tower, on in tails.items():
+        if not on:
+            continue
         out = []
         for o in ops:
-            if o[0].startswith("detect.") and o[0].endswith(".box.2"):
+            if o[0].startswith("detect.") and o[0].endswith(f".{tower}.2"):
                 continue
-            if o[0].startswith("detect.") and o[0].endswith(".box.1"):
+            if o[0].startswith("detect.") and o[0].endswith(f".{tower}.1"):
                 nm, kd, st, co, ci, k, ex = o
                 px = (size // st) ** 2 * batch
-                fl = 2.0 * px * co * ci * k * k + 2.0 * px * 64 * co
-                by = px * ci * es + px * 64 * es
+                tail_out = 64 if tower == "box" else 32
+                fl = 2.0 * px * co * ci * k * k + 2.0 * px * tail_out * co
+                by = px * ci * es + px * tail_out * es
                 o = (nm + "+2", "fused", st, 0, 0, 0, (fl, by))
             out.append(o)
         ops = out

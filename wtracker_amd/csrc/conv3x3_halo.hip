@@ -377,8 +377,78 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // 64-channel tensor and launching a second kernel that reads it back, the SiLU'd fp16 values go to a wave-local LDS tile
     // (the window buffer is free after the last tap's barrier) and are multiplied by the 1x1 weights right here.  Same fp16
     // rounding of the intermediate, same K order (two 32-deep steps), same MFMA: bit-identical to the two-kernel path.
-    if constexpr (TAIL) {
-        static_assert(!TAIL || (BN == 64 && sizeof(T) == 2), "fused tail: fp16, 64-cout tile");
+    if constexpr (TAIL && BN == 128) {
+        // ---- 128-cout tile (the Detect class tower: 3x3 128 -> 128, then 1x1 128 -> nc stored as 32 padded channels).  A wave
+        // holds 64 pixels x ONE HALF of the channels, so the two cout-waves of a pixel group exchange through LDS: both write
+        // their SiLU'd fp16 tile (64 px x 64 ch), one block barrier, then each of them multiplies HALF of the group's pixels over
+        // all 128 channels — k-steps 0,1 from the low-channel tile, 2,3 from the high-channel tile: the K order of the stand-alone
+        // 1x1 kernel, so the result is bit-identical.  Both window buffers are free after the last tap's barrier.
+        static_assert(sizeof(T) == 2 && WAVES_C == 2 && TC == 4 && TP % 2 == 0, "fused class-tower tail: fp16, 4 x 2 waves");
+        const _Float16 *w2 = reinterpret_cast<const _Float16 *>(a.tail_w);
+        const int arow = (lr >> 2) * 8 + (lr & 3); // + 4i: the lane ends up owning couts lg*8 .. lg*8+7 of the 32 stored ones
+        half8 wf2[4][2];                           // A fragments straight from global memory (8 KB of weights); requested first, used last
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf2[ks][i] = *reinterpret_cast<const half8 *>(w2 + (long long)(arow + 4 * i) * a.tail_kpad + ks * 32 + lg * 8);
+        auto tile_of = [&](int w) __attribute__((always_inline)) -> char * { return (w < 4 ? halo0 : halo1) + (w & 3) * (WP * 128); };
+        char *mine = tile_of(wave);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int p = j * 16 + lr;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = c2 * 8 + e;
+                    const float x = acc[idx >> 2][j][idx & 3];
+                    hv[e] = (_Float16)(a.act ? silu_h(x) : x);
+                }
+                const int c = 2 * lg + c2;
+                *reinterpret_cast<half8 *>(mine + p * 128 + ((c ^ (p & 7)) << 4)) = hv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int TPH = TP / 2; // pixel tiles of the group this wave finishes
+        floatx4 acc2[2][TPH];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const floatx4 b4 = (floatx4){a.tail_bias[lg * 8 + i * 4 + 0], a.tail_bias[lg * 8 + i * 4 + 1], a.tail_bias[lg * 8 + i * 4 + 2], a.tail_bias[lg * 8 + i * 4 + 3]};
+#pragma unroll
+            for (int j = 0; j < TPH; ++j) acc2[i][j] = b4;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const char *src = tile_of(wave_p * 2 + (ks >> 1)); // channels 0..63 of the group, then 64..127
+#pragma unroll
+            for (int j = 0; j < TPH; ++j) {
+                const int p = (wave_c * TPH + j) * 16 + lr;
+                const half8 pf = *reinterpret_cast<const half8 *>(src + p * 128 + ((((ks & 1) * 4 + lg) ^ (p & 7)) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf2[ks][i], pf, acc2[i][j], 0, 0, 0);
+            }
+        }
+        _Float16 *tout = reinterpret_cast<_Float16 *>(a.tail_out);
+#pragma unroll
+        for (int j = 0; j < TPH; ++j) {
+            const int o = o0 + wave_p * WP + (wave_c * TPH + j) * 16 + lr;
+            const int y = (int)fdiv((unsigned)o, a.d_pitch);
+            const int x = o - y * pitch;
+            if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
+            const long long pix = ((long long)n * a.H + y) * a.W + xs + x;
+            float v2[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r];
+            store_run_h<8>(tout + pix * a.tail_ld + a.tail_coff + lg * 8, v2);
+        }
+        return;
+    } else if constexpr (TAIL) {
+        static_assert(!TAIL || (BN == 64 && sizeof(T) == 2), "fused tail: fp16, 64- or 128-cout tile");
         {
             static_assert(BN != 64 || TC == 4, "64 couts per wave");
             char *tile = halo0 + wave * (WP * 128); // WP rows of 128 B: 64 channels of the wave's pixels
@@ -784,9 +854,9 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % (bn == 192 ? 24 : 16) != 0) return hipErrorInvalidValue;
     if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
     if (a.pitch != a.S + 2 || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W) return hipErrorInvalidValue;
-    if (a.tail_w && (!is_f16 || bn != 64 || a.Cout != 64 || a.CoutPad != 64 || a.res || a.out2 || !a.tail_bias || !a.tail_out || a.tail_kpad < 64 ||
-                     a.tail_kpad % 8 || a.tail_ld % 8 || a.tail_coff % 8 || a.slabs == 2))
-        return hipErrorInvalidValue; // the fused 1x1 tail exists for the fp16 64-cout three-slab variants only
+    if (a.tail_w && (!is_f16 || (bn != 64 && bn != 128) || a.Cout != bn || a.CoutPad != bn || a.res || a.out2 || !a.tail_bias || !a.tail_out ||
+                     a.tail_kpad < bn || a.tail_kpad % 8 || a.tail_ld % 8 || a.tail_coff % 8 || a.slabs == 2))
+        return hipErrorInvalidValue; // the fused 1x1 tail exists for the fp16 64-cout (-> 64) and 128-cout (-> 32) three-slab variants only
     const int bm = a.bm == 128 ? 128 : kBM;
     if (a.blocks_per_strip * bm < a.H * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % ce || a.res_coff % ce)) return hipErrorInvalidValue;
@@ -797,9 +867,13 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     // persistent form only where a block gets to walk several tiles (measured: -5..-8 % at 6-7 tiles per CU, -1..2 % at 1.75, but
     // +4 % when every block has exactly one tile: its per-tile bookkeeping then buys nothing)
     const long long tiles = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / bn);
-    if (a.slabs != 2 && bm == kBM && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
+    if (a.slabs != 2 && !a.tail_w && bm == kBM && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
         if (is_f16) return bn == 128 ? launch_hp<_Float16, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<_Float16, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
         return bn == 128 ? launch_hp<float, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<float, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
+    }
+    if (a.tail_w && bn == 128) { // class tower: one tile per block (both window buffers hold the exchange tiles afterwards)
+        if (bm == 128) return launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, true>(a, stream);
+        return launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, true>(a, stream);
     }
     if (a.tail_w) { // validated above: fp16, 64-cout tile, three slabs
         if (bm == 128) return nchunks == 1 ? launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax, 128, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, true>(a, stream);

@@ -763,6 +763,14 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
                 b1.tail_op = (int)first_op + 3;
                 b2.folded = 1;
             }
+            // class tower: 3x3 (128 -> 128) then 1x1 (128 -> nc, stored as cls_ld = 32 channels)
+            Op &c1 = h->ops[first_op + 2], &c2 = h->ops[first_op + 4];
+            if (h->is_f16 && c1.halo == 1 && c1.cout == 128 && c1.cout_pad == 128 && c2.k == 1 && c2.cin == 128 && c2.cout == 32 && c2.cout_pad == 32 &&
+                !c2.act && c2.in_buf == c1.out_buf && c2.res_buf < 0 && c2.out2_buf < 0 && c1.res_buf < 0 && c1.out2_buf < 0 && h->halo_slabs == 3 &&
+                h->cls_ld == 32) {
+                c1.tail_op = (int)first_op + 4;
+                c2.folded = 1;
+            }
         }
         if (!P.failed && i < 2) { // P3 and P4 towers only need t15 / t18: independent of the rest of the PAN path
             for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = 1;
