@@ -275,14 +275,19 @@ hipError_t launch_crop_views(const CropArgs &a, hipStream_t stream) {
 // One block = one image x one 16-byte channel group; the whole map lives in LDS and each 5x5
 // pool runs as a separable row-max / column-max pair.  y1,y2,y3 are written back to their slices.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CE> struct __attribute__((aligned(16))) Vec16 {
-    T v[CE];
+// 16-byte channel group as a native vector: element-wise max compiles to v_pk_max_f16 (4 per group) / v_max_f32
+template <typename T, int CE> struct PoolVec;
+template <> struct PoolVec<_Float16, 8> {
+    typedef _Float16 type __attribute__((ext_vector_type(8)));
+};
+template <> struct PoolVec<float, 4> {
+    typedef float type __attribute__((ext_vector_type(4)));
 };
 
 template <typename T, int CE, int GP>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_pool[];
-    using V = Vec16<T, CE>;
+    using V = typename PoolVec<T, CE>::type;
     const int HW = a.H * a.W;
     V *A = reinterpret_cast<V *>(smem_pool); // [pixel][GP channel groups]
     V *Bv = A + HW * GP;
@@ -297,17 +302,15 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
     }
     __syncthreads();
     for (int pass = 1; pass <= 3; ++pass) {
-        // horizontal 5-max: A -> B
+        // horizontal 5-max: A -> B   (neighbours in x are +-GP items away; the row ends clip the window)
         for (int i = threadIdx.x; i < items; i += 256) {
-            const int px = i / GP, g = i - px * GP;
-            const int y = px / a.W, x = px - y * a.W;
+            const int px = i / GP;
+            const int y = (int)fdiv((unsigned)px, a.d_w), x = px - y * a.W;
             V m = A[i];
-            for (int d = -2; d <= 2; ++d) {
-                const int xx = x + d;
-                if (d == 0 || xx < 0 || xx >= a.W) continue;
-                const V o = A[(y * a.W + xx) * GP + g];
 #pragma unroll
-                for (int e = 0; e < CE; ++e) m.v[e] = o.v[e] > m.v[e] ? o.v[e] : m.v[e];
+            for (int d = -2; d <= 2; ++d) {
+                if (d == 0) continue;
+                if ((unsigned)(x + d) < (unsigned)a.W) m = __builtin_elementwise_max(m, A[i + d * GP]);
             }
             Bv[i] = m;
         }
@@ -315,14 +318,12 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
         // vertical 5-max: B -> A, and out
         for (int i = threadIdx.x; i < items; i += 256) {
             const int px = i / GP, g = i - px * GP;
-            const int y = px / a.W, x = px - y * a.W;
+            const int y = (int)fdiv((unsigned)px, a.d_w);
             V m = Bv[i];
-            for (int d = -2; d <= 2; ++d) {
-                const int yy = y + d;
-                if (d == 0 || yy < 0 || yy >= a.H) continue;
-                const V o = Bv[(yy * a.W + x) * GP + g];
 #pragma unroll
-                for (int e = 0; e < CE; ++e) m.v[e] = o.v[e] > m.v[e] ? o.v[e] : m.v[e];
+            for (int d = -2; d <= 2; ++d) {
+                if (d == 0) continue;
+                if ((unsigned)(y + d) < (unsigned)a.H) m = __builtin_elementwise_max(m, Bv[i + d * a.W * GP]);
             }
             A[i] = m;
             *reinterpret_cast<V *>(base + (long long)px * ld + pass * a.c + g * CE) = m;
@@ -345,7 +346,9 @@ hipError_t pool_init_attributes() {
     return hipSuccess;
 }
 
-hipError_t launch_sppf_pool(const PoolArgs &a, int is_f16, hipStream_t stream) {
+hipError_t launch_sppf_pool(const PoolArgs &a_in, int is_f16, hipStream_t stream) {
+    PoolArgs a = a_in;
+    a.d_w = make_fastdiv((unsigned)a.W);
     const int ce = is_f16 ? 8 : 4;
     if (a.c % ce != 0) return hipErrorInvalidValue;
     const size_t per_group = (size_t)2 * a.H * a.W * 16;

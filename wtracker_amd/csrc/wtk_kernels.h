@@ -229,6 +229,7 @@ hipError_t launch_crop_views(const CropArgs &a, hipStream_t stream);
 struct PoolArgs {
     void *buf; // [N][H][W][4c]
     int N, H, W, c;
+    FastDiv d_w; // filled by the launcher
 };
 hipError_t launch_sppf_pool(const PoolArgs &a, int is_f16, hipStream_t stream);
 hipError_t pool_init_attributes();
