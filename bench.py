@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the YOLOv8s + ResMLP sim-loop hot path on MI355X (BASELINE.json metric).
 
-One "step" = one super-batch: every rank runs the detector (stem, 61 implicit-GEMM convs, SPPF pool,
-head select) on its `--batch` synthetic 640x640 frames that are already resident in HBM, the [B,4]
+One "step" = one super-batch: every rank runs the detector (63 conv layers in ~50 launches: fused front,
+fused C2f tail, implicit-GEMM and window-kernel convs with fused Detect tails, SPPF pool, head select) on its `--batch` synthetic 640x640 frames that are already resident in HBM, the [B,4]
 track slices are all-gathered (N > 1 only), and the ResMLP movement vectors of the cycles that became
 computable are produced (wtracker_amd/pipeline.py).  Prints ONE JSON line on rank 0.
 
