@@ -406,3 +406,30 @@ def test_three_slab_counted_wait_schedule_equals_two_slab(hip_lib, monkeypatch, 
         np.testing.assert_array_equal(cls, ref_cls)
         for x, y in zip(res, ref_res):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3)])
+def test_fused_front_and_c2f_tail_match_oracle_layers(hip_lib, H, W, C):
+    """Layer-level parity of the two fused kernels against the CPU restatement (not only through the head logits):
+    model.2.cv1's output (= front_fused_kernel's result) and model.2's output (= c2f32_fused_kernel's result) in
+    fp16 mode; activations there are O(1), the tolerance is a few fp16 ulps accumulated over 3 / 6 layers."""
+    B = 2
+    w = ys.synthetic_weights("s", 1, seed=4)
+    depth, width, maxch = ys.SCALES["s"]
+    oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
+    rng = np.random.default_rng(H + 3 * W + C)
+    frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
+    det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
+    det.predict_host(frames, conf=0.05)
+    cv1_g = det.debug_tensor(2, B)  # [B,h,w,64]
+    c2f_g = det.debug_tensor(3, B)
+    with torch.no_grad():
+        x, _ = yo.preprocess(list(frames), max(H, W))
+        assert tuple(x.shape[2:]) == (H, W)
+        x1 = oracle.conv("model.1", oracle.conv("model.0", x, 2), 2)
+        cv1_o = oracle.conv("model.2.cv1", x1).permute(0, 2, 3, 1).numpy()
+        c2f_o = oracle.c2f("model.2", x1, 1, True).permute(0, 2, 3, 1).numpy()
+    assert cv1_g.shape == cv1_o.shape and c2f_g.shape == c2f_o.shape
+    scale = max(1.0, float(np.abs(cv1_o).max()))
+    assert np.abs(cv1_g - cv1_o).max() < 2e-2 * scale
+    assert np.abs(c2f_g - c2f_o).max() < 4e-2 * max(1.0, float(np.abs(c2f_o).max()))
