@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r];
-            store_run_h<8>(tout + pix * a.tail_ld + a.tail_coff + lg * 8, v2);
+            if (lg * 8 < a.tail_cout) store_run_h<8>(tout + pix * a.tail_ld + a.tail_coff + lg * 8, v2); // padded couts are never stored
         }
         return;
     } else if constexpr (TAIL) {

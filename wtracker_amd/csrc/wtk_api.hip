@@ -740,7 +740,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     // ---- Detect: both towers' first 3x3 share one conv (weights concatenated along cout)
     const int feat[3] = {t15, t18, t21};
     const int fh[3] = {h8, h16, h32}, fw[3] = {w8, w16, w32};
-    h->cls_ld = 32;
+    h->cls_ld = (d->nc + 7) / 8 * 8; // class logits are stored in 16-byte groups: nc = 1 costs 16 B per anchor, not 64
     for (int i = 0; i < 3 && !P.failed; ++i) {
         const std::string b = "model.22.cv2." + std::to_string(i), cl = "model.22.cv3." + std::to_string(i);
         const int d1 = P.new_buf(fh[i], fw[i], dims.hb + dims.hc);
@@ -763,11 +763,11 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
                 b1.tail_op = (int)first_op + 3;
                 b2.folded = 1;
             }
-            // class tower: 3x3 (128 -> 128) then 1x1 (128 -> nc, stored as cls_ld = 32 channels)
+            // class tower: 3x3 (128 -> 128) then 1x1 (128 -> nc, stored as cls_ld = 8, 16, 24 or 32 channels)
             Op &c1 = h->ops[first_op + 2], &c2 = h->ops[first_op + 4];
-            if (h->is_f16 && c1.halo == 1 && c1.cout == 128 && c1.cout_pad == 128 && c2.k == 1 && c2.cin == 128 && c2.cout == 32 && c2.cout_pad == 32 &&
+            if (h->is_f16 && c1.halo == 1 && c1.cout == 128 && c1.cout_pad == 128 && c2.k == 1 && c2.cin == 128 && c2.cout <= 32 && c2.cout_pad == 32 &&
                 !c2.act && c2.in_buf == c1.out_buf && c2.res_buf < 0 && c2.out2_buf < 0 && c1.res_buf < 0 && c1.out2_buf < 0 && h->halo_slabs == 3 &&
-                h->cls_ld == 32) {
+                c2.cout == h->cls_ld) {
                 c1.tail_op = (int)first_op + 4;
                 c2.folded = 1;
             }
@@ -1072,6 +1072,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     const Op &t = h->ops[op.tail_op];
                     g.tail_w = t.w, g.tail_bias = t.bias, g.tail_kpad = t.Kpad;
                     g.tail_out = h->bufs[t.out_buf].ptr, g.tail_ld = h->bufs[t.out_buf].C, g.tail_coff = t.out_coff;
+                    g.tail_cout = t.cout;
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
                 const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);

@@ -127,6 +127,7 @@ struct HaloArgs {
     const float *tail_bias;
     void *tail_out;
     int tail_kpad, tail_ld, tail_coff;
+    int tail_cout; // channels actually stored by the tail (multiple of 8; 64 for the box tower, cls_ld for the class tower)
     int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
