@@ -285,7 +285,7 @@ template <> struct PoolVec<float, 4> {
 };
 
 template <typename T, int CE, int GP>
-__global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
+__global__ __launch_bounds__(512) void sppf_pool_kernel(const PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_pool[];
     using V = typename PoolVec<T, CE>::type;
     const int HW = a.H * a.W;
@@ -296,14 +296,14 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
     const int ld = 4 * a.c;
     T *base = reinterpret_cast<T *>(a.buf) + (long long)n * HW * ld + g0 * CE;
     const int items = HW * GP; // item = pixel*GP + group: consecutive lanes read consecutive 16-B groups of a pixel
-    for (int i = threadIdx.x; i < items; i += 256) {
+    for (int i = threadIdx.x; i < items; i += 512) {
         const int px = i / GP, g = i - px * GP;
         A[i] = *reinterpret_cast<const V *>(base + (long long)px * ld + g * CE);
     }
     __syncthreads();
     for (int pass = 1; pass <= 3; ++pass) {
         // horizontal 5-max: A -> B   (neighbours in x are +-GP items away; the row ends clip the window)
-        for (int i = threadIdx.x; i < items; i += 256) {
+        for (int i = threadIdx.x; i < items; i += 512) {
             const int px = i / GP;
             const int y = (int)fdiv((unsigned)px, a.d_w), x = px - y * a.W;
             V m = A[i];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolArgs a) {
         }
         __syncthreads();
         // vertical 5-max: B -> A, and out
-        for (int i = threadIdx.x; i < items; i += 256) {
+        for (int i = threadIdx.x; i < items; i += 512) {
             const int px = i / GP, g = i - px * GP;
             const int y = (int)fdiv((unsigned)px, a.d_w);
             V m = Bv[i];
@@ -359,14 +359,14 @@ hipError_t launch_sppf_pool(const PoolArgs &a_in, int is_f16, hipStream_t stream
     const unsigned blocks = (unsigned)(a.N * (a.c / (ce * gp)));
     if (is_f16) {
         if (gp == 4)
-            hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 4>), dim3(blocks), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 4>), dim3(blocks), dim3(512), lds, stream, a);
         else
-            hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 1>), dim3(blocks), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 1>), dim3(blocks), dim3(512), lds, stream, a);
     } else {
         if (gp == 4)
-            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 4>), dim3(blocks), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 4>), dim3(blocks), dim3(512), lds, stream, a);
         else
-            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 1>), dim3(blocks), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 1>), dim3(blocks), dim3(512), lds, stream, a);
     }
     return hipGetLastError();
 }
