@@ -30,6 +30,13 @@ int main(int argc, char **argv) {
     const double taps = 9.0 * (C / 64);
     double s0 = 0, s1 = 0, s2 = 0; long long n = 0;
     for (long long i = 0; i < blocks * 8; ++i) { if (!st[i * 4]) continue; s0 += st[i * 4]; s1 += st[i * 4 + 1]; s2 += st[i * 4 + 2]; ++n; }
+    double wmin = 0, wmax = 0; long long nb = 0; // slowest / fastest wave of a block (work phase)
+    for (long long b = 0; b < blocks; ++b) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int w8 = 0; w8 < 8; ++w8) { const unsigned long long v = st[(b * 8 + w8) * 4]; if (!v) continue; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        if (hi) wmin += lo, wmax += hi, ++nb;
+    }
+    std::printf("   fastest wave of a block %.0f cyc/tap, slowest %.0f\n", wmin / nb / taps, wmax / nb / taps);
     const double mf = (bn / 2 / 16) * 4 * 2 * 16.0; // MFMAs per wave per tap x 16 cycles
     std::printf("%dx%d C%d->%d (bn %d): per tap and wave: work %.0f cyc (MFMA issue alone %.0f), vmcnt wait %.0f, barrier wait %.0f\n", HW, HW, C, CO, bn, s0 / n / taps, mf,
                 s1 / n / taps, s2 / n / taps);
