@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main(int argc, char **argv) {
     const int N = 64, HW = argc > 1 ? std::atoi(argv[1]) : 20, C = argc > 2 ? std::atoi(argv[2]) : 256, CO = argc > 3 ? std::atoi(argv[3]) : 256;
@@ -25,6 +26,23 @@ int main(int argc, char **argv) {
     a.dbg_stamps = dst;
     for (int i = 0; i < 5; ++i) CK(wtk::launch_conv3x3_halo(a, 1, nullptr));
     CK(hipDeviceSynchronize());
+    if (argc > 4) { // hold the chip under load for argv[4] seconds first: the clock it settles at is the one a long run sees
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, nullptr));
+        float ms = 0;
+        while (ms < 1000.f * std::atof(argv[4])) {
+            for (int i = 0; i < 200; ++i) CK(wtk::launch_conv3x3_halo(a, 1, nullptr));
+            CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+    }
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 20; ++i) CK(wtk::launch_conv3x3_halo(a, 1, nullptr));
+        CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        std::printf("%dx%d C%d->%d: %.1f us per launch, %.0f TF/s\n", HW, HW, C, CO, ms * 50, 2.0 * px * CO * 9 * C / (ms * 50e-6) * 1e-12);
+    }
     std::vector<unsigned long long> st(blocks * 32);
     CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
     const double taps = 9.0 * (C / 64);
@@ -37,6 +55,11 @@ int main(int argc, char **argv) {
         if (hi) wmin += lo, wmax += hi, ++nb;
     }
     std::printf("   fastest wave of a block %.0f cyc/tap, slowest %.0f\n", wmin / nb / taps, wmax / nb / taps);
+    {
+        std::vector<double> clk;
+        for (long long i = 0; i < blocks * 8; ++i) { const unsigned long long v = st[i * 4 + 3]; if (v & 0xffffff) clk.push_back(100.0 * (double)(v >> 24) / (double)(v & 0xffffff)); }
+        if (!clk.empty()) { std::sort(clk.begin(), clk.end()); std::printf("   in-kernel clock (median over waves): %.0f MHz\n", clk[clk.size() / 2]); }
+    }
     const double mf = (bn / 2 / 16) * 4 * 2 * 16.0; // MFMAs per wave per tap x 16 cycles
     std::printf("%dx%d C%d->%d (bn %d): per tap and wave: work %.0f cyc (MFMA issue alone %.0f), vmcnt wait %.0f, barrier wait %.0f\n", HW, HW, C, CO, bn, s0 / n / taps, mf,
                 s1 / n / taps, s2 / n / taps);

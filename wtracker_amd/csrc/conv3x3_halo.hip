@@ -290,6 +290,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #ifdef WTK_HALO_TAP_STAMPS // diagnostic builds: per-wave cycle totals of (issue + ds_read + MFMA), vmcnt wait, barrier wait
     unsigned long long tap_sum[3] = {0, 0, 0};
     unsigned long long tap_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long clk_c0 = tap_prev, clk_r0 = __builtin_amdgcn_s_memrealtime(); // in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
 #endif
     // one channel chunk = 9 taps.  CP = parity of the chunk: window in halo[CP].
     // NWB == 2: tap t's weights in wbuf[(CP+t)&1], next tap's slab requested at the top of the tap, vmcnt(0) at its end.
@@ -358,7 +359,11 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 
 #ifdef WTK_HALO_TAP_STAMPS
     if (lane == 0 && a.dbg_stamps)
+    {
         for (int i = 0; i < 3; ++i) a.dbg_stamps[((long long)blockIdx.x * 8 + wave) * 4 + i] = tap_sum[i];
+        const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        a.dbg_stamps[((long long)blockIdx.x * 8 + wave) * 4 + 3] = (dc << 24) | (dr & 0xffffff);
+    }
 #endif
 #ifdef WTK_HALO_STAMPS
     const unsigned long long st_t2 = __builtin_amdgcn_s_memrealtime();
