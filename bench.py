@@ -166,27 +166,42 @@ def main():
             run((args.warmup + s) // args.lanes * args.lanes)  # lane 0 = the profiled handle
         fence()
         prof = det.get_profile()
+        kprof = det.get_kernel_profile()
         det.set_profiling(False)
-        conv = prof["conv"]
-        # the stand-alone stem is its own class; when the fused front runs (fp16, YOLOv8s widths) model.0 is part
-        # of a conv-class launch and its MACs count there
-        stem_macs = (args.size // 2) ** 2 * ys.conv_table(scale, nc)[0]["cout"] * 27 if prof["stem"]["launches"] else 0
-        conv_flops_per_forward = 2.0 * (det.macs_per_frame - stem_macs) * args.batch
-        launches_per_forward = conv["launches"] / prof_steps
-        avg_launch_ms = conv["total_ms"] / max(conv["launches"], 1)
-        achieved = conv_flops_per_forward / launches_per_forward / (avg_launch_ms * 1e-3) / 1e12
-        # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE x2 +
-        # WRITE_SIZE, tools/traffic_from_pmc.py); only valid for the configuration it was collected on
-        traffic = None
+        peak = PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE x2 + WRITE_SIZE,
+        # tools/traffic_from_pmc.py); only valid for the configuration it was collected on
+        tj = None
         tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
         if os.path.exists(tpath) and args.size == 640 and args.dtype == "fp16":
             tj = json.load(open(tpath))
-            traffic = tj["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]
-        roofline = {"kernel": "conv family: front_fused_kernel + conv_igemm_kernel + conv3x3_halo_kernel + conv3x3_c32_kernel",
-                    "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype],
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic,
-                    "launches_per_step": launches_per_forward, "avg_launch_ms": avg_launch_ms,
-                    "flop_per_launch_avg": conv_flops_per_forward / launches_per_forward,
+
+        def kernel_line(name, k):
+            avg_ms = k["total_ms"] / max(k["launches"], 1)
+            flop_per_launch = k["flops"] / max(k["launches"], 1)
+            ach = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            tr = None
+            if tj and name in tj.get("per_kernel", {}):
+                tr = tj["per_kernel"][name]["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]
+            return {"kernel": name, "achieved": ach, "frac": ach / peak, "traffic": tr, "launches_per_step": k["launches"] / prof_steps,
+                    "avg_launch_ms": avg_ms, "flop_per_launch_avg": flop_per_launch, "ms_per_step": k["total_ms"] / prof_steps}
+
+        conv_kernels = {n: k for n, k in kprof.items() if k["flops"] > 0 and k["launches"] > 0}
+        lines = sorted((kernel_line(n, k) for n, k in conv_kernels.items()), key=lambda e: -e["ms_per_step"])
+        dom = lines[0]  # the kernel the forward pass spends most of its device time in
+        fam_ms = sum(k["total_ms"] for k in conv_kernels.values())
+        fam_launches = sum(k["launches"] for k in conv_kernels.values())
+        fam_flops = sum(k["flops"] for k in conv_kernels.values())
+        fam_ach = fam_flops / (fam_ms * 1e-3) / 1e12
+        roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
+                    "frac": dom["frac"], "traffic": dom["traffic"], "launches_per_step": dom["launches_per_step"],
+                    "avg_launch_ms": dom["avg_launch_ms"], "flop_per_launch_avg": dom["flop_per_launch_avg"],
+                    "share_of_forward": dom["ms_per_step"] / sum(v["total_ms"] / prof_steps for v in prof.values()),
+                    # every MFMA kernel of the forward pass together (what `value` is made of)
+                    "conv_family": {"achieved": fam_ach, "frac": fam_ach / peak, "launches_per_step": fam_launches / prof_steps,
+                                    "avg_launch_ms": fam_ms / fam_launches, "flop_per_launch_avg": fam_flops / fam_launches,
+                                    "traffic": (tj["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]) if tj else None},
+                    "kernels": lines,
                     "class_ms_per_step": {k: v["total_ms"] / prof_steps for k, v in prof.items()}}
 
     frames_done = args.steps * args.batch * world

@@ -165,6 +165,12 @@ int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors);
  * kernel_class: 0 stem, 1 conv (implicit GEMM), 2 pool, 3 head (decode+select). */
 int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled);
 int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches);
+/* The same measurement per kernel (source file) of the forward pass, with the algorithmic FLOPs (2 x MACs) its launches
+ * executed: kernel_id 0 stem_mfma_kernel, 1 conv_igemm_kernel, 2 sppf_pool_kernel, 3 head kernels, 4 conv3x3_halo_kernel
+ * (including its fused 1x1 tails), 5 front_fused_kernel + c2f32_fused_kernel, 6 conv3x3_c32_kernel.  Class 1 of
+ * wtk_yolo_get_profile is the sum of ids 1, 4, 5 and 6.  (Build-side instrumentation for bench.py's roofline object; the
+ * reference has no counterpart.) */
+int wtk_yolo_get_kernel_profile(wtk_yolo *h, int32_t kernel_id, double *total_ms, int64_t *launches, double *flops);
 
 /* ------------------------------------------------------------------------------------------
  * Camera / microscope view extraction for a batch of (frame, platform position) pairs.

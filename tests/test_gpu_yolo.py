@@ -433,3 +433,29 @@ def test_fused_front_and_c2f_tail_match_oracle_layers(hip_lib, H, W, C):
     scale = max(1.0, float(np.abs(cv1_o).max()))
     assert np.abs(cv1_g - cv1_o).max() < 2e-2 * scale
     assert np.abs(c2f_g - c2f_o).max() < 4e-2 * max(1.0, float(np.abs(c2f_o).max()))
+
+
+@pytest.mark.parametrize("dtype,scale", [("fp16", "s"), ("fp32", "s"), ("fp16", "n")])
+def test_kernel_profile_accounts_for_every_conv_mac(hip_lib, dtype, scale):
+    """bench.py's roofline object is built from wtk_yolo_get_kernel_profile: the FLOPs it attributes to the kernels must add
+    up to the algorithmic work of the forward pass (2 x macs_per_frame x B), whatever mix of fused / plain kernels ran, and
+    the public 'conv' class must be the sum of the MFMA conv kernels."""
+    size, B, steps = 128, 3, 2
+    _, det = _models(scale, size, dtype)
+    frames, _ = fr.synthetic_frames(B, size, seed=5)
+    res_plain = det.predict_host(frames, conf=0.1)
+    det.set_profiling(True)
+    for _ in range(steps):
+        res_prof = det.predict_host(frames, conf=0.1)
+    kp = det.get_kernel_profile()
+    cp = det.get_profile()
+    det.set_profiling(False)
+    for a, b in zip(res_plain, res_prof):  # profiling (one stream, event brackets) does not change results
+        np.testing.assert_array_equal(a, b)
+    total = sum(k["flops"] for k in kp.values())
+    assert total == pytest.approx(2.0 * det.macs_per_frame * B * steps, rel=1e-9)
+    conv_ids = ["conv_igemm_kernel", "conv3x3_halo_kernel", "front_fused_kernel+c2f32_fused_kernel", "conv3x3_c32_kernel"]
+    assert cp["conv"]["launches"] == sum(kp[k]["launches"] for k in conv_ids)
+    assert cp["conv"]["total_ms"] == pytest.approx(sum(kp[k]["total_ms"] for k in conv_ids), rel=1e-9)
+    assert all(k["total_ms"] > 0 for k in kp.values() if k["launches"])
+    det.close()

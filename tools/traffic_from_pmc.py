@@ -36,15 +36,24 @@ def main():
     total = 0.0
     n = 0
     per_op = {}
+    per_kernel = {}
     for (name, kind, *_), rf, rw in zip(ops, f, w):
         b = 2.0 * float(rf["Counter_Value"]) * 1024 + float(rw["Counter_Value"]) * 1024
         per_op[name] = b
         if kind in ("conv", "fused"):
             total += b
             n += 1
+        kn = rf["Kernel_Name"]
+        key = next((k for k in ("conv3x3_halo", "conv_igemm", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma") if k in kn), "head")
+        key = {"front_fused": "front_fused_kernel+c2f32_fused_kernel", "c2f32_fused": "front_fused_kernel+c2f32_fused_kernel", "head": "head"}.get(key, key + "_kernel")
+        e = per_kernel.setdefault(key, {"launches": 0, "hbm_bytes_per_forward": 0.0})
+        e["launches"] += 1
+        e["hbm_bytes_per_forward"] += b
+    for e in per_kernel.values():
+        e["hbm_bytes_per_launch_avg"] = e["hbm_bytes_per_forward"] / e["launches"]
     print(json.dumps({"conv_launches": n, "hbm_bytes_per_forward": total, "hbm_bytes_per_launch_avg": total / n,
                       "batch": a.batch, "correction": "FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE exact, KiB units",
-                      "per_op_bytes": per_op}, indent=1))
+                      "per_kernel": per_kernel, "per_op_bytes": per_op}, indent=1))
 
 
 if __name__ == "__main__":

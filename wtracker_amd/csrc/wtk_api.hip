@@ -373,7 +373,10 @@ struct wtk_yolo {
     int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
     int num_cus = 0;
     int profiling = 0;
-    hipEvent_t ev[16];
+    // kernel ids of the profile: 0 stem, 1 conv_igemm, 2 pool, 3 head, 4 conv3x3_halo (+ fused tails), 5 fused front / C2f tail,
+    // 6 conv3x3_c32; the public class 1 ("conv") of wtk_yolo_get_profile is the sum of 1, 4, 5, 6
+    static constexpr int kProfKernels = 7, kProfEvents = 96;
+    hipEvent_t ev[kProfEvents];
     // concurrency: the P3 / P4 Detect towers run on a side stream next to the PAN path
     hipStream_t side_stream = nullptr;
     hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done = nullptr;
@@ -390,8 +393,9 @@ struct wtk_yolo {
     int graph_max_batch = 16; // WTK_GRAPH_MAX_BATCH; 0 disables
     hipStream_t host_stream = nullptr; // stream of the *_host entry points (graph capture needs a non-null stream)
     int ev_created = 0;
-    double prof_ms[4] = {0, 0, 0, 0};
-    long long prof_launches[4] = {0, 0, 0, 0};
+    double prof_ms[kProfKernels] = {};
+    double prof_flops[kProfKernels] = {};
+    long long prof_launches[kProfKernels] = {};
 };
 
 extern "C" int wtk_yolo_conv_count(float width_mult, float depth_mult, int32_t max_channels, int32_t nc) {
@@ -853,20 +857,32 @@ extern "C" int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *a
 extern "C" int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled) {
     if (!h) return fail("wtk_yolo_set_profiling: null handle");
     if (enabled && !h->ev_created) {
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < wtk_yolo::kProfEvents; ++i) {
             HIP_TRY(hipEventCreate(&h->ev[i]));
             h->ev_created = i + 1;
         }
     }
     h->profiling = enabled ? 1 : 0;
-    for (int i = 0; i < 4; ++i) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
+    for (int i = 0; i < wtk_yolo::kProfKernels; ++i) h->prof_ms[i] = 0, h->prof_flops[i] = 0, h->prof_launches[i] = 0;
+    return 0;
+}
+
+extern "C" int wtk_yolo_get_kernel_profile(wtk_yolo *h, int32_t kernel_id, double *total_ms, int64_t *launches, double *flops) {
+    if (!h || kernel_id < 0 || kernel_id >= wtk_yolo::kProfKernels) return fail("wtk_yolo_get_kernel_profile: bad argument");
+    if (total_ms) *total_ms = h->prof_ms[kernel_id];
+    if (launches) *launches = h->prof_launches[kernel_id];
+    if (flops) *flops = h->prof_flops[kernel_id];
     return 0;
 }
 
 extern "C" int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches) {
     if (!h || kernel_class < 0 || kernel_class > 3) return fail("wtk_yolo_get_profile: bad argument");
-    if (total_ms) *total_ms = h->prof_ms[kernel_class];
-    if (launches) *launches = h->prof_launches[kernel_class];
+    double ms = h->prof_ms[kernel_class];
+    long long n = h->prof_launches[kernel_class];
+    if (kernel_class == 1)
+        for (int k = 4; k < wtk_yolo::kProfKernels; ++k) ms += h->prof_ms[k], n += h->prof_launches[k];
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
     return 0;
 }
 
@@ -926,17 +942,22 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     }
 
     int cur_class = -1, nev = 0;
-    int ev_class[16];
+    int ev_class[wtk_yolo::kProfEvents];
     auto mark = [&](int cls) -> int {
         if (!h->profiling || cls == cur_class) return 0;
-        if (nev >= 16) return 0;
+        if (nev >= wtk_yolo::kProfEvents - 1) return 0;
         HIP_TRY(hipEventRecord(h->ev[nev], st));
         ev_class[nev] = cls;
         ++nev;
         cur_class = cls;
         return 0;
     };
-    long long launches[4] = {0, 0, 0, 0};
+    long long launches[wtk_yolo::kProfKernels] = {};
+    double flops[wtk_yolo::kProfKernels] = {};
+    auto op_flops = [&](const Op &o) { // algorithmic: 2 x output pixels x cout x (cin x k x k)
+        const Buf &ob = h->bufs[o.out_buf];
+        return 2.0 * B * ob.h * ob.w * o.cout * (double)(o.cin * o.k * o.k);
+    };
 
     // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
     // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
@@ -946,7 +967,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     hipStream_t main_st = st;
     size_t first_op = 0;
     if (h->use_front && reinterpret_cast<uintptr_t>(net_in) % 4 == 0) {
-        if (mark(1)) return 1;
+        if (mark(5)) return 1;
         const Op &o0 = h->ops[0], &o1 = h->ops[1], &o2 = h->ops[2];
         FrontArgs f;
         std::memset(&f, 0, sizeof(f));
@@ -960,7 +981,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         f.out_coff = o2.out_coff;
         if (h->front_debug) f.dbg_t0 = h->bufs[o0.out_buf].ptr, f.dbg_t1 = h->bufs[o1.out_buf].ptr;
         HIP_TRY(launch_front_fused(f, h->num_cus, st));
-        ++launches[1];
+        ++launches[5];
+        flops[5] += 2.0 * B * (h->S_h / 2) * (h->S_w / 2) * o0.cout * 27.0 + op_flops(o1) + op_flops(o2);
         first_op = 3;
     }
     for (size_t oi = first_op; oi < h->ops.size(); ++oi) {
@@ -968,7 +990,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         if (h->use_c2f && (oi == 3 || oi == 4)) continue; // folded into the fused C2f tail launched at op 5
         if (op.folded) continue;                          // runs in the epilogue of the op that names it as tail_op
         if (h->use_c2f && oi == 5) {
-            if (mark(1)) return 1;
+            if (mark(5)) return 1;
             const Op &m1 = h->ops[3], &m2 = h->ops[4];
             const Buf &cb = h->bufs[op.in_buf];
             C2fArgs c;
@@ -980,7 +1002,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             c.out = h->bufs[op.out_buf].ptr, c.out_ld = h->bufs[op.out_buf].C, c.out_coff = op.out_coff;
             c.zeros = h->zero_page;
             HIP_TRY(launch_c2f_fused(c, h->num_cus, main_st));
-            ++launches[1];
+            ++launches[5];
+            flops[5] += op_flops(m1) + op_flops(m2) + op_flops(op);
             continue;
         }
         st = main_st;
@@ -1001,6 +1024,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
             HIP_TRY(launch_stem(a, h->is_f16, st));
             ++launches[0];
+            flops[0] += 2.0 * B * a.Ho * a.Wo * op.cout * 27.0;
         } else if (op.kind == OP_POOL) {
             if (mark(2)) return 1;
             const Buf &b = h->bufs[op.in_buf];
@@ -1010,7 +1034,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             HIP_TRY(launch_sppf_pool(a, h->is_f16, st));
             ++launches[2];
         } else {
-            if (mark(1)) return 1;
+            const int kid = op.halo == 2 ? 6 : (op.halo ? 4 : 1);
+            if (mark(kid)) return 1;
             const Buf &ib = h->bufs[op.in_buf];
             const Buf &ob = h->bufs[op.out_buf];
             ConvArgs a;
@@ -1094,7 +1119,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             } else {
                 HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
             }
-            ++launches[1];
+            ++launches[kid];
+            flops[kid] += op_flops(op) + (op.halo && op.tail_op >= 0 ? op_flops(h->ops[op.tail_op]) : 0.0);
             if (two_lanes && op.signal_feat >= 0) HIP_TRY(hipEventRecord(h->feat_ev[op.signal_feat], main_st));
         }
     }
@@ -1107,7 +1133,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st)) return 1;
     ++launches[3];
     if (h->profiling) {
-        if (nev < 16) {
+        if (nev < wtk_yolo::kProfEvents) {
             HIP_TRY(hipEventRecord(h->ev[nev], st));
             ev_class[nev] = -1;
             ++nev;
@@ -1118,7 +1144,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
             h->prof_ms[ev_class[i]] += ms;
         }
-        for (int i = 0; i < 4; ++i) h->prof_launches[i] += launches[i];
+        for (int i = 0; i < wtk_yolo::kProfKernels; ++i) h->prof_launches[i] += launches[i], h->prof_flops[i] += flops[i];
     }
     return 0;
 }

@@ -51,7 +51,7 @@ SYMBOLS = [
     "wtk_mlp_create", "wtk_mlp_destroy", "wtk_mlp_forward", "wtk_mlp_forward_host", "wtk_mlp_predict_track",
     "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
-    "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
+    "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_yolo_get_kernel_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
 ]
 
 
@@ -92,6 +92,7 @@ def load() -> C.CDLL:
     lib.wtk_yolo_set_profiling.argtypes = [vp, i32]
     lib.wtk_yolo_debug_tensor.argtypes = [vp, i32, i32, vp, C.c_size_t, vp]
     lib.wtk_yolo_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.wtk_yolo_get_kernel_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.wtk_crop_views.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     _lib = lib
     return lib
@@ -306,4 +307,16 @@ class HipYolo:
             ms, n = C.c_double(), C.c_int64()
             _check(load().wtk_yolo_get_profile(self._h, i, C.byref(ms), C.byref(n)), "wtk_yolo_get_profile")
             out[nme] = dict(total_ms=ms.value, launches=n.value)
+        return out
+
+    KERNELS = ["stem_mfma_kernel", "conv_igemm_kernel", "sppf_pool_kernel", "head", "conv3x3_halo_kernel",
+               "front_fused_kernel+c2f32_fused_kernel", "conv3x3_c32_kernel"]
+
+    def get_kernel_profile(self) -> dict:
+        """Per-kernel device time, launches and algorithmic FLOPs of the profiled forwards (wtk_yolo_get_kernel_profile)."""
+        out = {}
+        for i, nme in enumerate(self.KERNELS):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            _check(load().wtk_yolo_get_kernel_profile(self._h, i, C.byref(ms), C.byref(n), C.byref(fl)), "wtk_yolo_get_kernel_profile")
+            out[nme] = dict(total_ms=ms.value, launches=n.value, flops=fl.value)
         return out
