@@ -954,10 +954,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     };
     long long launches[wtk_yolo::kProfKernels] = {};
     double flops[wtk_yolo::kProfKernels] = {};
-    auto op_flops = [&](const Op &o) { // algorithmic: 2 x output pixels x cout x (cin x k x k)
-        const Buf &ob = h->bufs[o.out_buf];
-        return 2.0 * B * ob.h * ob.w * o.cout * (double)(o.cin * o.k * o.k);
-    };
+    auto op_flops = [&](const Op &o) { return 2.0 * B * o.macs_per_image; }; // algorithmic: 2 x output pixels x cout x (cin x k x k)
 
     // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
     // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
@@ -982,7 +979,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         if (h->front_debug) f.dbg_t0 = h->bufs[o0.out_buf].ptr, f.dbg_t1 = h->bufs[o1.out_buf].ptr;
         HIP_TRY(launch_front_fused(f, h->num_cus, st));
         ++launches[5];
-        flops[5] += 2.0 * B * (h->S_h / 2) * (h->S_w / 2) * o0.cout * 27.0 + op_flops(o1) + op_flops(o2);
+        flops[5] += op_flops(o0) + op_flops(o1) + op_flops(o2);
         first_op = 3;
     }
     for (size_t oi = first_op; oi < h->ops.size(); ++oi) {
@@ -1024,7 +1021,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
             HIP_TRY(launch_stem(a, h->is_f16, st));
             ++launches[0];
-            flops[0] += 2.0 * B * a.Ho * a.Wo * op.cout * 27.0;
+            flops[0] += op_flops(op);
         } else if (op.kind == OP_POOL) {
             if (mark(2)) return 1;
             const Buf &b = h->bufs[op.in_buf];
