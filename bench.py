@@ -224,7 +224,7 @@ def main():
                    "parallelism": f"frame-sharded x{world}, one RCCL all-gather of [B,4] tracks per step" if world > 1 else "single GPU"},
         "roofline": roofline,
     }
-    if rank == 0 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:  # the CPU baseline is reported at N=1 only
         out["cpu_baseline"] = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, args.cpu_frames, args.batch, golden)
     if rank == 0:
         print(json.dumps(out), flush=True)
