@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""MFMA utilisation per kernel and per op from one rocprofv3 --pmc pass of bench.py (tools/gpu_sessions/mfma_util.sh:
+SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE, single stream).
+
+  util_nominal = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch duration x 2.4 GHz)   (= achieved / 2.5 PFLOP/s for fp16)
+  util_active  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)             (against the cycles the chip ran; the
+                 guide notes GRBM_GUI_ACTIVE reads high on dispatches shorter than ~0.3 ms, so this one is a lower bound)
+  SQ_WAIT_ANY / SQ_WAIT_INST_ANY are shares of SQ_WAVE_CYCLES (wave parked in s_waitcnt / barrier; issue stall).
+
+  python tools/mfma_util_from_pmc.py gpurun_out/pf_mfma/p_counter_collection.csv > profiles/r01_pmc_mfma_util.txt
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.layer_profile import adapt_plan, plan  # noqa: E402
+from tools.pmc_report import load  # noqa: E402
+
+SIMDS = 256 * 4
+
+
+def kernel_of(name: str) -> str:
+    for k in ("conv3x3_halo", "conv_igemm", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma"):
+        if k in name:
+            return k
+    return "head"
+
+
+def line(label, e):
+    busy, dur = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), e["dur"] * 1e-9
+    gui = e.get("GRBM_GUI_ACTIVE", 0.0) / 8
+    wc = max(e.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+    return (f"{label:<28}{e['dur'] * 1e-3:9.1f}{e.get('SQ_INSTS_MFMA', 0.0):12.4g}{100 * busy / (SIMDS * dur * 2.4e9):11.1f}"
+            f"{100 * busy / (SIMDS * gui) if gui else 0:11.1f}{100 * e.get('SQ_WAIT_ANY', 0.0) / wc:11.1f}{100 * e.get('SQ_WAIT_INST_ANY', 0.0) / wc:11.1f}")
+
+
+def main():
+    run = load(sys.argv[1])
+    ops = adapt_plan(plan(), [e["name"] for e in run])
+    hdr = f"{'':<28}{'us':>9}{'MFMA inst':>12}{'util_nom%':>11}{'util_act%':>11}{'WAIT_ANY%':>11}{'WAIT_INST%':>11}"
+    print("# per kernel (sums over one 64-frame forward, fp16, 640x640)")
+    print(hdr)
+    agg = {}
+    for e in run:
+        a = agg.setdefault(kernel_of(e["name"]), {"dur": 0})
+        for k, v in e.items():
+            if k != "name":
+                a[k] = a.get(k, 0) + v
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["dur"]):
+        print(line(k + "_kernel" if k != "head" else k, a))
+    tot = {"dur": 0}
+    for a in agg.values():
+        for k, v in a.items():
+            tot[k] = tot.get(k, 0) + v
+    print(line("TOTAL", tot))
+    print("\n# per op")
+    print(hdr)
+    for (op, *_), e in zip(ops, run):
+        print(line(op, e))
+
+
+if __name__ == "__main__":
+    main()
