@@ -19,9 +19,9 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(din, in.data(), in.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), CO * 4, hipMemcpyHostToDevice));
     wtk::HaloArgs a{};
     a.in = din, a.in_ld = C, a.N = N, a.H = HW, a.W = HW, a.Cin = C, a.Cout = CO, a.CoutPad = CO, a.w = dw, a.bias = db, a.out = dout, a.out_ld = CO, a.act = 1, a.Kpad = 9 * C, a.zeros = dz, a.slabs = 3;
-    wtk::halo_geometry(HW, HW, wtk::halo_rows_max(CO, 3), &a.S, &a.pitch, &a.strips, &a.blocks_per_strip);
+    wtk::halo_geometry_stacked(N, HW, HW, wtk::halo_rows_max(CO, 3), &a.S, &a.pitch, &a.strips, &a.blocks_per_strip);
     const int bn = wtk::halo_cout_tile(CO);
-    const long long blocks = (long long)N * a.strips * a.blocks_per_strip * (CO / bn);
+    const long long blocks = (long long)a.strips * a.blocks_per_strip * (CO / bn);
     CK(hipMalloc(&dst, blocks * 8 * 4 * 8)); CK(hipMemset(dst, 0, blocks * 8 * 4 * 8));
     a.dbg_stamps = dst;
     for (int i = 0; i < 5; ++i) CK(wtk::launch_conv3x3_halo(a, 1, nullptr));

@@ -8,8 +8,15 @@
 //   * the image is walked in column strips of S <= 85 px; inside a strip, pixels of the zero-padded
 //     window (pitch = S + 2 columns) are numbered flat, o = y*pitch + x, so the input of output o for
 //     tap (kh, kw) is simply window[o + kh*pitch + kw]: a 1-D shift.  A block owns 256 consecutive flat
-//     outputs (2 of every `pitch` are border junk and are dropped in the epilogue); its window is the
+//     outputs (the border columns are junk and are dropped in the epilogue); its window is the
 //     contiguous run of 256 + 2*pitch + 2 window pixels, each 128 bytes (64 fp16 / 32 fp32 channels);
+//   * the N images of a strip are STACKED vertically with one shared zero row between neighbours (the row
+//     below image n is the row above image n+1), so the flat index runs over N*(H+1) rows and a block
+//     boundary need not fall on an image boundary: a 20x20 map no longer rounds 440 outputs up to two
+//     256-pixel blocks per image.  A map that fits one strip also shares ONE zero column between the
+//     right border of a row and the left border of the next (pitch = W + 1).  Together: 13 % fewer
+//     blocks on 20x20 maps, 6 % on 40x40 (time follows the executed MFMAs once two forward passes share
+//     the chip);
 //   * an MFMA pixel tile is 16 consecutive flat outputs = 16 consecutive window rows, so with the
 //     row&7 XOR swizzle every ds_read_b128 fragment read is conflict-free for ANY tap offset;
 //   * per tap only the [BN][64ch] weight slab is streamed (double buffered, LDS-DMA); the next channel
@@ -112,6 +119,58 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     }
 }
 
+// Stacked geometry (header comment).  Window row `flat` (relative to the strip) -> input pixel: stacked row rho = flat / pitch
+// holds image n = rho / (H+1), input row iy = rho % (H+1) - 1 (-1: the shared zero row); column ix = xs + flat % pitch - 1.
+__device__ __forceinline__ bool halo_in_coords(const HaloArgs &a, int flat, int xs, int &n, int &iy, int &ix) {
+    const int rho = (int)fdiv((unsigned)flat, a.d_pitch);
+    const int cc = flat - rho * a.pitch;
+    n = (int)fdiv((unsigned)rho, a.d_h1);
+    iy = rho - n * (a.H + 1) - 1;
+    ix = xs + cc - 1;
+    return n < a.N && iy >= 0 && (unsigned)ix < (unsigned)a.W;
+}
+// Flat output index -> (image, row, column inside the strip); false for the junk row / junk columns / past the last image
+__device__ __forceinline__ bool halo_out_coords(const HaloArgs &a, int o, int xs, int &n, int &y, int &x) {
+    const int q = (int)fdiv((unsigned)o, a.d_pitch);
+    x = o - q * a.pitch;
+    n = (int)fdiv((unsigned)q, a.d_h1);
+    y = q - n * (a.H + 1);
+    return n < a.N && y < a.H && x < a.S && xs + x < a.W;
+}
+
+// Per-lane byte offsets of a wave's window pieces (wave w stages pieces w, w+8, ...: 8 rows x 8 chunks of 16 B each).  The 8 x KMAX
+// rows of a wave are evaluated ONCE — lane L works out row L&7 of piece L>>3 — and handed to the lanes that need them with
+// ds_bpermute, instead of every lane redoing the divisions for each of its pieces: the ~250 VALU instructions this took per
+// block sat in front of the block's first LDS-DMA request (stamped: 0.5 us of a 10-18 us block).
+template <typename T, int KMAX>
+__device__ __forceinline__ void halo_piece_offsets(const HaloArgs &a, int o0, int xs, int n_base, int halo_rows, int wave, int lane, unsigned (&hoff)[KMAX],
+                                                   unsigned &hvalid) {
+    static_assert(KMAX <= 8, "one lane per (piece, row)");
+    constexpr int CE = ElemH<T>::CE;
+    const int hr_e = (wave + 8 * (lane >> 3)) * 8 + (lane & 7);
+    int pn, iy, ix;
+    const bool ok_e = halo_in_coords(a, o0 + hr_e, xs, pn, iy, ix) && hr_e < halo_rows;
+    const unsigned row_e = ok_e ? (unsigned)(((((long long)(pn - n_base) * a.H + iy) * a.W + ix) * a.in_ld) * (long long)sizeof(T)) : 0xffffffffu;
+    const unsigned lc_term = (unsigned)((((lane & 7) ^ ((lane >> 3) & 7)) * CE) * (int)sizeof(T)); // logical chunk landing on this lane's slot
+    hvalid = 0;
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) {
+        const unsigned v = (unsigned)__builtin_amdgcn_ds_bpermute((q * 8 + (lane >> 3)) * 4, (int)row_e);
+        const bool ok = v != 0xffffffffu;
+        hoff[q] = ok ? v + lc_term : 0u;
+        hvalid |= ok ? (1u << q) : 0u;
+    }
+}
+// Output pixel of a wave's flat outputs o_first + L (L < 64), evaluated once per lane: pixel index (n*H + y)*W + xs + x, or -1 for
+// junk rows / columns; `col` = xs + x.  The lanes of pixel tile j fetch theirs with ds_bpermute from lane j*16 + (lane & 15).
+__device__ __forceinline__ void halo_out_pixel(const HaloArgs &a, int o_first, int xs, int lane, int &pix_e, int &col_e) {
+    int n, y, x;
+    const bool ok = halo_out_coords(a, o_first + lane, xs, n, y, x);
+    col_e = xs + x;
+    pix_e = ok ? (n * a.H + y) * a.W + col_e : -1;
+}
+__device__ __forceinline__ int lane_fetch(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane * 4, v); }
+
 // HROWS: window rows one LDS buffer holds.  NWB: weight slabs in the ring.  With NWB == 3 the slab of tap g+2 is
 // requested while tap g is multiplied and a COUNTED s_waitcnt vmcnt leaves it in flight across the tap barrier
 // (raw s_barrier): a slab has two full taps to arrive instead of one.  PMC on the two-slab kernel showed every wave
@@ -157,21 +216,19 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // launch-invariant divisors go through FastDiv: a runtime integer division is ~40 instructions, and the ~25 of them this
     // kernel used to execute before its first LDS-DMA request cost every block 1.3-1.9 us (stamped) of an 11-33 us life
     const int nct = a.CoutPad / BN;
-    unsigned t = fdiv((unsigned)L, a.d_nct);
+    const unsigned t = fdiv((unsigned)L, a.d_nct);
     const int n0 = (L - (int)t * nct) * BN;
-    unsigned tq = fdiv(t, a.d_bps);
-    const int rb = (int)(t - tq * (unsigned)a.blocks_per_strip);
-    t = tq;
-    tq = fdiv(t, a.d_strips);
-    const int strip = (int)(t - tq * (unsigned)a.strips);
-    const int n = (int)tq;
+    const int rb = (int)fdiv(t, a.d_strips); // row blocks major, strips minor: the strips of a row block share input rows (L2)
+    const int strip = (int)t - rb * a.strips;
     const int o0 = rb * BMT;
     const int xs = strip * a.S;
     const int pitch = a.pitch;
     const int halo_rows = BMT + 2 * pitch + 2;
     const int halo_pieces = (halo_rows + 7) >> 3;
+    // piece offsets are 32-bit and relative to the first image the window touches
+    const int n_base = (int)fdiv(fdiv((unsigned)o0, a.d_pitch), a.d_h1);
 
-    const T *in = reinterpret_cast<const T *>(a.in) + (long long)n * a.H * a.W * a.in_ld + a.in_coff;
+    const T *in = reinterpret_cast<const T *>(a.in) + (long long)n_base * a.H * a.W * a.in_ld + a.in_coff;
     const T *wgt = reinterpret_cast<const T *>(a.w);
     const char *zero_page = reinterpret_cast<const char *>(a.zeros);
 
@@ -182,20 +239,8 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // depend on the channel chunk, so each piece's per-lane byte offset inside the image is computed once.
     constexpr int kMaxPiecesPerWave = (HROWS / 8 + 7) / 8;
     unsigned hoff[kMaxPiecesPerWave];
-    unsigned hvalid = 0;
-#pragma unroll
-    for (int q = 0; q < kMaxPiecesPerWave; ++q) {
-        const int piece = wave + 8 * q;
-        const int hr = piece * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ (hr & 7); // logical chunk landing on this lane's physical slot
-        const int flat = o0 + hr;
-        const int r = (int)fdiv((unsigned)flat, a.d_pitch);
-        const int cc = flat - r * pitch;
-        const int iy = r - 1, ix = xs + cc - 1;
-        const bool ok = hr < halo_rows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        hoff[q] = ok ? (unsigned)((((long long)iy * a.W + ix) * a.in_ld + lc * CE) * (long long)sizeof(T)) : 0u;
-        hvalid |= ok ? (1u << q) : 0u;
-    }
+    unsigned hvalid;
+    halo_piece_offsets<T, kMaxPiecesPerWave>(a, o0, xs, n_base, halo_rows, wave, lane, hoff, hvalid);
     const char *img = reinterpret_cast<const char *>(in);
     auto issue_halo_piece = [&](char *buf, int q, int c) { // q static after unrolling
         const int piece = wave + 8 * q;
@@ -375,7 +420,15 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         }
     } stamp_on_exit{a.dbg_stamps + ((long long)blockIdx.x * 8 + wave) * 4, st_t0, st_t1, st_t2, a.dbg_stamps != nullptr && lane == 0};
 #endif
-    // ---- epilogue (the bias is already inside the accumulators)
+    // ---- epilogue (the bias is already inside the accumulators).  Output pixels: one evaluation per lane, fetched per pixel tile
+    // (before any lane leaves: ds_bpermute reads from active lanes only)
+    int pix_e, col_e;
+    halo_out_pixel(a, o0 + wave_p * WP, xs, lane, pix_e, col_e);
+    int pixj[TAIL ? 1 : TP], colj[TAIL ? 1 : TP]; // the fused-tail variants have no padded couts: they fetch inside their loops
+    if constexpr (!TAIL) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) pixj[j] = lane_fetch(j * 16 + lr, pix_e), colj[j] = lane_fetch(j * 16 + lr, col_e);
+    }
     if (cb + NV > a.Cout) return;
     // ---- fused 1x1 tail (fp16, 64-cout tile: the wave owns ALL 64 output channels of its pixels).  The Detect box tower's
     // last conv (1x1, 64 -> 64, no activation) consumes this conv's output and nothing else does: instead of writing the
@@ -439,11 +492,8 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         _Float16 *tout = reinterpret_cast<_Float16 *>(a.tail_out);
 #pragma unroll
         for (int j = 0; j < TPH; ++j) {
-            const int o = o0 + wave_p * WP + (wave_c * TPH + j) * 16 + lr;
-            const int y = (int)fdiv((unsigned)o, a.d_pitch);
-            const int x = o - y * pitch;
-            if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
-            const long long pix = ((long long)n * a.H + y) * a.W + xs + x;
+            const long long pix = lane_fetch((wave_c * TPH + j) * 16 + lr, pix_e);
+            if (pix < 0) continue;
             float v2[8];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -502,11 +552,8 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             _Float16 *tout = reinterpret_cast<_Float16 *>(a.tail_out);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const int o = o0 + wave_p * WP + j * 16 + lr;
-                const int y = (int)fdiv((unsigned)o, a.d_pitch);
-                const int x = o - y * pitch;
-                if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
-                const long long pix = ((long long)n * a.H + y) * a.W + xs + x;
+                const long long pix = lane_fetch(j * 16 + lr, pix_e);
+                if (pix < 0) continue;
                 float v2[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -522,10 +569,9 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     const T *res = reinterpret_cast<const T *>(a.res);
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        const int o = o0 + wave_p * WP + j * 16 + lr;
-        const int y = (int)fdiv((unsigned)o, a.d_pitch);
-        const int x = o - y * pitch;
-        if (y >= a.H || x >= a.S || xs + x >= a.W) continue;
+        const long long pix = pixj[TAIL ? 0 : j];
+        const int col = colj[TAIL ? 0 : j];
+        if (pix < 0) continue;
         float v[NV];
 #pragma unroll
         for (int i = 0; i < TC; ++i)
@@ -535,7 +581,6 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = silu_h(v[i]);
         }
-        const long long pix = ((long long)n * a.H + y) * a.W + xs + x;
         if (res) {
             float rv[NV];
             load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
@@ -543,13 +588,13 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             for (int i = 0; i < NV; ++i) v[i] += rv[i];
         }
         store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
-        if (out2) {
-            const int H2 = a.H * 2, W2 = a.W * 2;
+        if (out2) { // 2x nearest upsample: pixel (n, 2y+dy, 2X+dx) of the [2H][2W] map = 4*pix - 2X + 2W*dy + dx
+            const int W2 = a.W * 2;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const long long pix2 = ((long long)n * H2 + (2 * y + dy)) * W2 + (2 * (xs + x) + dx);
+                    const long long pix2 = 4 * pix - 2 * col + W2 * dy + dx;
                     store_run_h<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
                 }
         }
@@ -593,15 +638,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
     const int halo_rows = kBM + 2 * pitch + 2;
     const int nct = a.CoutPad / BN;
     const int nchunks = a.Cin / CCH; // even (launcher)
-    const int total = a.N * a.strips * a.blocks_per_strip * nct;
+    const int total = a.strips * a.blocks_per_strip * nct;
     const int G = gridDim.x; // multiple of 8: a block's tiles stay on one XCD label
     const T *wgt = reinterpret_cast<const T *>(a.w);
     const char *zero_page = reinterpret_cast<const char *>(a.zeros);
 
     // per-tile context.  Two copies (current / next) of plain scalars and small arrays: everything stays in registers.
     struct Tile {
-        int n, o0, xs, n0;
-        const char *img;   // image base of the input view
+        int o0, xs, n0;
+        const char *img;   // base of the first image the window touches (input view)
         const char *wtile; // weight rows of this cout tile
         unsigned hoff[kMaxPiecesPerWave];
         unsigned hvalid;
@@ -611,32 +656,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
         // XCD-aware bijective remap of the virtual block id (as conv3x3_halo_kernel, with nwg = total tiles)
         const int xcd = v & 7, q8 = total >> 3, r8 = total & 7;
         const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
-        unsigned t = fdiv((unsigned)L, a.d_nct);
+        const unsigned t = fdiv((unsigned)L, a.d_nct);
         tc.n0 = (L - (int)t * nct) * BN;
-        unsigned tq = fdiv(t, a.d_bps);
-        const int rb = (int)(t - tq * (unsigned)a.blocks_per_strip);
-        t = tq;
-        tq = fdiv(t, a.d_strips);
-        const int strip = (int)(t - tq * (unsigned)a.strips);
-        tc.n = (int)tq;
+        const int rb = (int)fdiv(t, a.d_strips); // row blocks major, strips minor (as conv3x3_halo_kernel)
+        const int strip = (int)t - rb * a.strips;
         tc.o0 = rb * kBM;
         tc.xs = strip * a.S;
-        tc.img = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.in) + (long long)tc.n * a.H * a.W * a.in_ld + a.in_coff);
+        const int n_base = (int)fdiv(fdiv((unsigned)tc.o0, a.d_pitch), a.d_h1);
+        tc.img = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.in) + (long long)n_base * a.H * a.W * a.in_ld + a.in_coff);
         tc.wtile = reinterpret_cast<const char *>(wgt + (long long)tc.n0 * a.Kpad);
-        tc.hvalid = 0;
-#pragma unroll
-        for (int q = 0; q < kMaxPiecesPerWave; ++q) {
-            const int piece = wave + 8 * q;
-            const int hr = piece * 8 + (lane >> 3);
-            const int lc = (lane & 7) ^ (hr & 7);
-            const int flat = tc.o0 + hr;
-            const int r = (int)fdiv((unsigned)flat, a.d_pitch);
-            const int cc = flat - r * pitch;
-            const int iy = r - 1, ix = tc.xs + cc - 1;
-            const bool ok = hr < halo_rows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            tc.hoff[q] = ok ? (unsigned)((((long long)iy * a.W + ix) * a.in_ld + lc * CE) * (long long)sizeof(T)) : 0u;
-            tc.hvalid |= ok ? (1u << q) : 0u;
-        }
+        halo_piece_offsets<T, kMaxPiecesPerWave>(a, tc.o0, tc.xs, n_base, halo_rows, wave, lane, tc.hoff, tc.hvalid);
         const int cb = tc.n0 + wave_c * WC + lg * NV;
 #pragma unroll
         for (int i = 0; i < NV; ++i) tc.bias[i] = a.bias[cb + i];
@@ -763,13 +792,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
         }
         // ---- epilogue of the finished tile
         const int cb = cur.n0 + wave_c * WC + lg * NV;
+        int pix_e, col_e; // output pixels: one evaluation per lane, fetched per pixel tile (all lanes active here)
+        halo_out_pixel(a, cur.o0 + wave_p * WP, cur.xs, lane, pix_e, col_e);
+        int pixj[TP], colj[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) pixj[j] = lane_fetch(j * 16 + lr, pix_e), colj[j] = lane_fetch(j * 16 + lr, col_e);
         if (cb + NV <= a.Cout) {
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const int o = cur.o0 + wave_p * WP + j * 16 + lr;
-                const int y = (int)fdiv((unsigned)o, a.d_pitch);
-                const int x = o - y * pitch;
-                if (y >= a.H || x >= a.S || cur.xs + x >= a.W) continue;
+                const long long pix = pixj[j];
+                if (pix < 0) continue;
                 float vv[NV];
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
@@ -779,7 +811,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 #pragma unroll
                     for (int i = 0; i < NV; ++i) vv[i] = silu_h(vv[i]);
                 }
-                const long long pix = ((long long)cur.n * a.H + y) * a.W + cur.xs + x;
                 if (res) {
                     float rv[NV];
                     load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
@@ -788,12 +819,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
                 }
                 store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, vv);
                 if (out2) {
-                    const int H2 = a.H * 2, W2 = a.W * 2;
+                    const int W2 = a.W * 2;
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx) {
-                            const long long pix2 = ((long long)cur.n * H2 + (2 * y + dy)) * W2 + (2 * (cur.xs + x) + dx);
+                            const long long pix2 = 4 * pix - 2 * colj[j] + W2 * dy + dx;
                             store_run_h<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, vv);
                         }
                 }
@@ -808,13 +839,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 }
 
 template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int num_cus, hipStream_t stream) {
-    const long long tiles = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
+    const long long tiles = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (tiles <= 0 || tiles > 0x3fffffffLL || num_cus < 8) return hipErrorInvalidValue;
     if (kBM + 2 * a.pitch + 2 > HROWS || (a.Cin / (8 * ElemH<T>::CE)) % 2 != 0) return hipErrorInvalidValue;
     a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
     a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
     a.d_strips = make_fastdiv((unsigned)a.strips);
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
+    a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
     const long long cap = num_cus / 8 * 8; // one block per CU (156-160 KB of LDS); a multiple of 8 keeps a block's tiles on its XCD label
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL((conv3x3_halo_pkernel<T, BN, HROWS>), dim3(grid), dim3(512), 0, stream, a);
@@ -822,13 +854,14 @@ template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int nu
 }
 
 template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
-    const long long blocks = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / BN);
+    const long long blocks = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (BMT + 2 * a.pitch + 2 > HROWS || (long long)a.blocks_per_strip * BMT < (long long)a.H * a.pitch) return hipErrorInvalidValue;
+    if (BMT + 2 * a.pitch + 2 > HROWS || (long long)a.blocks_per_strip * BMT < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
     a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
     a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
     a.d_strips = make_fastdiv((unsigned)a.strips);
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
+    a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT, TAIL>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
@@ -850,6 +883,14 @@ void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, 
     *blocks_per_strip = (H * *pitch + bm - 1) / bm;
 }
 
+void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm) {
+    const int smax = (rows_max - kBM - 2) / 2 - 2; // 256 + 2*(S+2) + 2 <= rows_max (the same strips for both block sizes)
+    *strips = (W + smax - 1) / smax;
+    *S = (W + *strips - 1) / *strips;
+    *pitch = *strips == 1 ? *S + 1 : *S + 2; // one strip: the zero column right of a row is the one left of the next row
+    *blocks_per_strip = (int)(((long long)N * (H + 1) * *pitch + bm - 1) / bm);
+}
+
 int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : (cout_stored % 192 == 0 ? 192 : 64); }
 
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream) {
@@ -858,12 +899,13 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     const int bn = halo_cout_tile(a.Cout);
     if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % (bn == 192 ? 24 : 16) != 0) return hipErrorInvalidValue;
     if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
-    if (a.pitch != a.S + 2 || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W) return hipErrorInvalidValue;
+    if (a.pitch != (a.strips == 1 ? a.S + 1 : a.S + 2) || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W || (a.strips == 1 && a.S != a.W))
+        return hipErrorInvalidValue;
     if (a.tail_w && (!is_f16 || (bn != 64 && bn != 128) || a.Cout != bn || a.CoutPad != bn || a.res || a.out2 || !a.tail_bias || !a.tail_out ||
                      a.tail_kpad < bn || a.tail_kpad % 8 || a.tail_ld % 8 || a.tail_coff % 8 || a.slabs == 2))
         return hipErrorInvalidValue; // the fused 1x1 tail exists for the fp16 64-cout (-> 64) and 128-cout (-> 32) three-slab variants only
     const int bm = a.bm == 128 ? 128 : kBM;
-    if (a.blocks_per_strip * bm < a.H * a.pitch) return hipErrorInvalidValue;
+    if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % ce || a.res_coff % ce)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % ce || a.out2_coff % ce)) return hipErrorInvalidValue;
     const int nchunks = a.Cin / cch;
@@ -871,7 +913,7 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     // slabs only leaves room for 352-row windows: the planner then cuts wide maps into strips of <= 45 columns.
     // persistent form only where a block gets to walk several tiles (measured: -5..-8 % at 6-7 tiles per CU, -1..2 % at 1.75, but
     // +4 % when every block has exactly one tile: its per-tile bookkeeping then buys nothing)
-    const long long tiles = (long long)a.N * a.strips * a.blocks_per_strip * (a.CoutPad / bn);
+    const long long tiles = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / bn);
     if (a.slabs != 2 && !a.tail_w && bm == kBM && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
         if (is_f16) return bn == 128 ? launch_hp<_Float16, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<_Float16, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
         return bn == 128 ? launch_hp<float, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<float, 192, kHaloRowsSmall>(a, a.persist_cus, stream);

@@ -1098,14 +1098,17 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
                 const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
-                halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
-                if (op.halo == 1 && h->halo_slabs == 3) {
-                    // small maps: with 256-pixel blocks a 20x20 map gives 2 blocks per image; halve the blocks when that
-                    // leaves at least half of the CUs without work
-                    const long long tiles = (long long)B * g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout));
-                    if (h->halo_small_blocks && 2 * tiles <= h->num_cus) {
-                        g.bm = 128;
-                        halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
+                if (op.halo == 2) {
+                    halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
+                } else {
+                    halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
+                    if (h->halo_slabs == 3) {
+                        // small maps: halve the blocks when 256-pixel blocks leave at least half of the CUs without work
+                        const long long tiles = (long long)g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout));
+                        if (h->halo_small_blocks && 2 * tiles <= h->num_cus) {
+                            g.bm = 128;
+                            halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
+                        }
                     }
                 }
                 g.zeros = h->zero_page;

@@ -7,30 +7,26 @@
 namespace wtk {
 
 // Unsigned division by a launch-invariant divisor (Granlund-Montgomery / libdivide branch-free form):
-// q = (t + ((n - t) >> 1)) >> sh with t = umulhi(n, mul).  Exact for every 32-bit n; ~5 VALU ops instead of
-// the ~25-instruction software division hipcc emits for n / d with a runtime d.
+// q = (t + ((n - t) >> sh1)) >> sh2 with t = umulhi(n, mul) (Granlund-Montgomery; sh1 = min(l, 1), sh2 = max(l - 1, 0),
+// l = ceil(log2 d)).  Exact for every 32-bit n and every d >= 1, branch-free (d = 1: mul = 1, both shifts 0 -> q = n); ~5 ops
+// instead of the ~25-instruction software division hipcc emits for n / d with a runtime d.
 struct FastDiv {
-    unsigned mul, sh, d;
+    unsigned mul, sh1, sh2;
 };
 inline FastDiv make_fastdiv(unsigned d) {
     FastDiv f;
-    f.d = d;
-    if (d <= 1) {
-        f.mul = 0;
-        f.sh = 0;
-        return f;
-    }
+    if (d == 0) d = 1;
     unsigned l = 0;
     while ((1ull << l) < d) ++l; // ceil(log2 d)
     const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
     f.mul = (unsigned)m;
-    f.sh = l - 1;
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
     return f;
 }
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
-    if (f.d == 1) return n;
     const unsigned t = __umulhi(n, f.mul);
-    return (t + ((n - t) >> 1)) >> f.sh;
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
 // Pins an fp32 value in a VGPR (no instruction).  hipcc folds "(half)(a * b)" into v_fma_mixlo_f16, which rounds the exact
@@ -131,11 +127,14 @@ struct HaloArgs {
     int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
-    FastDiv d_bps, d_strips, d_pitch, d_nct; // filled by the launchers
+    FastDiv d_bps, d_strips, d_pitch, d_nct, d_h1; // filled by the launchers (d_h1: H + 1, conv3x3_halo.hip's stacked rows)
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
 int halo_rows_max(int cout_stored, int slabs); // window rows the kernel variant for this Cout can hold
-void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256);
+void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256); // per image (conv3x3_c32)
+// conv3x3_halo.hip: the N images of a strip are stacked vertically with ONE shared zero row between neighbours, and a map that
+// fits one strip shares ONE zero column between the right border of a row and the left border of the next (pitch = W + 1)
+void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256);
 int halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
 // thin fp16 layers (Cin = 32, Cout <= 96): conv3x3_c32.hip
