@@ -211,10 +211,16 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
                 // T1 outside the image is m.0.cv2's zero padding
                 const bool inside = (unsigned)(y0 - 1 + oy) < (unsigned)a.H && (unsigned)(x0 - 1 + ox) < (unsigned)a.W;
                 half8 hv;
+                {
+                    float t[8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)silu_cf(acc[q][i][r]);
+                        for (int r = 0; r < 4; ++r) t[i * 4 + r] = acc[q][i][r];
+                    wtk_silu_scaled_run<8>(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (_Float16)t[e];
+                }
                 uint4 bits = __builtin_bit_cast(uint4, hv);
                 const uint32_t m = inside ? 0xffffffffu : 0u;
                 bits.x &= m, bits.y &= m, bits.z &= m, bits.w &= m;
@@ -253,10 +259,16 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
                 bfrag[j] = *reinterpret_cast<const half8 *>(bcur + row64(rb, lg));
                 const half8 res = bfrag[j];
                 half8 hv;
+                {
+                    float t[8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)pin_f32(silu_cf(acc[j][i][r]) + (float)res[i * 4 + r]);
+                        for (int r = 0; r < 4; ++r) t[i * 4 + r] = acc[j][i][r];
+                    wtk_silu_scaled_run<8>(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (_Float16)pin_f32(t[e] + (float)res[e]);
+                }
                 const int p = (2 * wave + j) * 16 + lr;
                 *reinterpret_cast<half8 *>(mbuf + row64(p, lg)) = hv;
             }
@@ -306,10 +318,16 @@ __global__ __launch_bounds__(512, 2) void c2f32_fused_kernel(const C2fArgs a) {
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
                         half8 hv;
+                        {
+                            float t[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int idx = c2 * 8 + e;
-                            hv[e] = (_Float16)silu_cf(acc[idx >> 2][j][idx & 3]);
+                            for (int e = 0; e < 8; ++e) {
+                                const int idx = c2 * 8 + e;
+                                t[e] = acc[idx >> 2][j][idx & 3];
+                            }
+                            wtk_silu_scaled_run<8>(t);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)t[e];
                         }
                         *reinterpret_cast<half8 *>(o + c2 * 8) = hv;
                     }

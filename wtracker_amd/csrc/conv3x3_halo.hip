@@ -184,6 +184,11 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Every kernel argument the set-up needs, requested in ONE batch: hipcc otherwise loads them lazily in 4-5 dependent rounds of
+    // s_load + s_waitcnt (~0.2 us each) in front of the block's first LDS-DMA request.
+    asm volatile("" ::"s"(a.in), "s"(a.w), "s"(a.bias), "s"(a.zeros), "s"(a.in_ld), "s"(a.in_coff), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Cin), "s"(a.CoutPad),
+                 "s"(a.Kpad), "s"(a.S), "s"(a.pitch), "s"(a.strips), "s"(a.d_strips.mul), "s"(a.d_strips.sh1), "s"(a.d_strips.sh2), "s"(a.d_pitch.mul),
+                 "s"(a.d_pitch.sh1), "s"(a.d_pitch.sh2), "s"(a.d_nct.mul), "s"(a.d_nct.sh1), "s"(a.d_nct.sh2), "s"(a.d_h1.mul), "s"(a.d_h1.sh1), "s"(a.d_h1.sh2), "s"(a.grid));
     constexpr int CE = ElemH<T>::CE;
     constexpr int CCH = 8 * CE; // channels per 128-byte chunk
     // BN = 64: 8(P) x 1(C) waves of 32 px x 64 cout; BN = 128 / 192: 4(P) x 2(C) waves of 64 px x 64 / 96 cout
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     const int lr = lane & 15, lg = lane >> 4;
 
     // ---- block -> (cout tile, row block, strip, image); XCD-aware bijective remap
-    const int nwg = gridDim.x;
+    const int nwg = a.grid;
     int L;
     {
         const int bid = blockIdx.x;
@@ -578,8 +583,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
         if (a.act) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = silu_h(v[i]);
+            wtk_silu_scaled_run<NV>(v);
         }
         if (res) {
             float rv[NV];
@@ -612,6 +616,10 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int BN, int HROWS>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a) {
+    asm volatile("" ::"s"(a.in), "s"(a.w), "s"(a.bias), "s"(a.zeros), "s"(a.in_ld), "s"(a.in_coff), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Cin), "s"(a.CoutPad),
+                 "s"(a.Kpad), "s"(a.S), "s"(a.pitch), "s"(a.strips), "s"(a.d_strips.mul), "s"(a.d_strips.sh1), "s"(a.d_strips.sh2), "s"(a.d_pitch.mul),
+                 "s"(a.d_pitch.sh1), "s"(a.d_pitch.sh2), "s"(a.d_nct.mul), "s"(a.d_nct.sh1), "s"(a.d_nct.sh2), "s"(a.d_h1.mul), "s"(a.d_h1.sh1), "s"(a.d_h1.sh2), "s"(a.grid),
+                 "s"(a.blocks_per_strip)); // one batch of scalar loads (see conv3x3_halo_kernel)
     constexpr int CE = ElemH<T>::CE;
     constexpr int CCH = 8 * CE;
     constexpr int WAVES_C = 2, WAVES_P = 4;
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
     const int nct = a.CoutPad / BN;
     const int nchunks = a.Cin / CCH; // even (launcher)
     const int total = a.strips * a.blocks_per_strip * nct;
-    const int G = gridDim.x; // multiple of 8: a block's tiles stay on one XCD label
+    const int G = a.grid; // multiple of 8: a block's tiles stay on one XCD label
     const T *wgt = reinterpret_cast<const T *>(a.w);
     const char *zero_page = reinterpret_cast<const char *>(a.zeros);
 
@@ -808,8 +816,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[i * 4 + r] = acc[i][j][r];
                 if (a.act) {
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) vv[i] = silu_h(vv[i]);
+                    wtk_silu_scaled_run<NV>(vv);
                 }
                 if (res) {
                     float rv[NV];
@@ -849,6 +856,7 @@ template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int nu
     a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
     const long long cap = num_cus / 8 * 8; // one block per CU (156-160 KB of LDS); a multiple of 8 keeps a block's tiles on its XCD label
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    a.grid = (int)grid;
     hipLaunchKernelGGL((conv3x3_halo_pkernel<T, BN, HROWS>), dim3(grid), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
@@ -862,6 +870,7 @@ template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT =
     a.d_strips = make_fastdiv((unsigned)a.strips);
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
     a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
+    a.grid = (int)blocks;
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT, TAIL>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }

@@ -344,8 +344,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r]; // bias already inside
                 if (a.act) {
-#pragma unroll
-                    for (int e = 0; e < NV; ++e) v[e] = silu_f(v[e]);
+                    wtk_silu_scaled_run<NV>(v);
                 }
                 const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
                 if (res) {

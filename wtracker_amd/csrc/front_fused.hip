@@ -281,10 +281,16 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
                 // silu_ff pins its fp32 product, so rounding is product -> fp32 -> fp16 as in the stand-alone kernels;
                 // pixels outside the stem map are model.1's zero padding: mask the packed halves (4 selects, not 8)
                 half8 hv;
+                {
+                    float t[8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[i * 4 + r] = (_Float16)silu_ff(acc[i][r]);
+                        for (int r = 0; r < 4; ++r) t[i * 4 + r] = acc[i][r];
+                    wtk_silu_scaled_run<8>(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (_Float16)t[e];
+                }
                 {
                     uint4 bits = __builtin_bit_cast(uint4, hv);
                     const uint32_t m = inside ? 0xffffffffu : 0u;
@@ -336,10 +342,16 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
                     half8 hv;
+                    {
+                        float t[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int idx = c2 * 8 + e; // cout lg*16 + idx = tile idx>>2, row idx&3
-                        hv[e] = (_Float16)silu_ff(acc[idx >> 2][j][idx & 3]);
+                        for (int e = 0; e < 8; ++e) {
+                            const int idx = c2 * 8 + e; // cout lg*16 + idx = tile idx>>2, row idx&3
+                            t[e] = acc[idx >> 2][j][idx & 3];
+                        }
+                        wtk_silu_scaled_run<8>(t);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)t[e];
                     }
                     const int c = 2 * lg + c2;
                     *reinterpret_cast<half8 *>(pobuf + p * 128 + ((c ^ (p & 7)) << 4)) = hv;
@@ -383,12 +395,17 @@ __global__ __launch_bounds__(512, 2) void front_fused_kernel(const FrontArgs a) 
                 const int oy = oy0 + 2 * wave + j, ox = ox0 + lr;
                 pend_ptr[j] = (oy < a.Ho && ox < a.Wo) ? out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.out_ld + a.out_coff + lg * 16 : nullptr;
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    float t[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int idx = c2 * 8 + e;
-                        pend[j][c2][e] = (_Float16)silu_ff(acc[idx >> 2][j][idx & 3]);
+                        t[e] = acc[idx >> 2][j][idx & 3];
                     }
+                    wtk_silu_scaled_run<8>(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pend[j][c2][e] = (_Float16)t[e];
+                }
             }
         }
         STAMP(6);

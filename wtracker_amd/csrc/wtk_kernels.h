@@ -50,6 +50,24 @@ __device__ __forceinline__ float wtk_silu_scaled(float a) {
     return wtk_pin_f32(a * __builtin_amdgcn_rcpf(1.0f + e));
 }
 
+// SiLU of a run of values, two at a time: the add and the multiply go through v_pk_add_f32 / v_pk_mul_f32 (two IEEE fp32
+// operations per instruction — the same results as the scalar form), so a pair costs 2 v_exp + 2 v_rcp + 2 packed ops instead of
+// 2 v_exp + 2 v_rcp + 4 scalar ops in epilogues whose only work is this.
+typedef float wtk_f2 __attribute__((ext_vector_type(2)));
+template <int NV> __device__ __forceinline__ void wtk_silu_scaled_run(float (&v)[NV]) {
+    static_assert(NV % 2 == 0, "pairs");
+#pragma unroll
+    for (int i = 0; i < NV; i += 2) {
+        const wtk_f2 a = {v[i], v[i + 1]};
+        const wtk_f2 e = {__builtin_amdgcn_exp2f(-a.x), __builtin_amdgcn_exp2f(-a.y)};
+        const wtk_f2 d = e + (wtk_f2){1.0f, 1.0f};
+        const wtk_f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        const wtk_f2 y = a * r;
+        v[i] = wtk_pin_f32(y.x);
+        v[i + 1] = wtk_pin_f32(y.y);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip).  Activations are NHWC; a tensor argument is a
 // *channel-slice view* (base pointer, pixel stride `ld` in elements, first channel `coff`), so
@@ -127,6 +145,7 @@ struct HaloArgs {
     int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
+    int grid; // blocks of the launch (filled by the launchers: reading gridDim.x costs the set-up one more scalar-load round trip)
     FastDiv d_bps, d_strips, d_pitch, d_nct, d_h1; // filled by the launchers (d_h1: H + 1, conv3x3_halo.hip's stacked rows)
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
