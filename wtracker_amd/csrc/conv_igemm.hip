@@ -204,6 +204,13 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
             int n, ho, wo;
+            if (K1 && !UP && a.tile_w == 0) {
+                // 1x1 / stride 1 over a linear pixel range: input pixel index = output pixel index m, no (n, ho, wo) needed.  The two
+                // divisions per staged row this used to spend sit inside the MFMA loop of the previous tile (K = 128: two K steps per tile)
+                const long long m = (long long)ptile * BM + r0 + RPP * r;
+                pbase[r] = m < a.M ? m * a.in_ld + a.in_coff + lchunk * CE : -1;
+                continue;
+            }
             const bool ok = pixel_coords(ptile, r0 + RPP * r, n, ho, wo);
             if (K1) {
                 pbase[r] = ok ? (((long long)n * a.H + ho) * a.W + wo) * a.in_ld + a.in_coff + lchunk * CE : -1;
@@ -336,8 +343,15 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         if (cb + NV <= a.Cout) { // padded output channels (Cout < CoutPad) are never stored
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                int n, ho, wo;
-                if (!pixel_coords(ptile, wave_p * WP + j * 16 + lr, n, ho, wo)) continue;
+                int n = 0, ho = 0, wo = 0;
+                long long pix;
+                if (a.tile_w == 0 && !out2) { // linear pixel range: the output pixel index is m itself
+                    pix = (long long)ptile * BM + wave_p * WP + j * 16 + lr;
+                    if (pix >= a.M) continue;
+                } else {
+                    if (!pixel_coords(ptile, wave_p * WP + j * 16 + lr, n, ho, wo)) continue;
+                    pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+                }
                 float v[NV];
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
@@ -346,7 +360,6 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
                 if (a.act) {
                     wtk_silu_scaled_run<NV>(v);
                 }
-                const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
                 if (res) {
                     float rv[NV];
                     load_run<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
@@ -445,6 +458,7 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     const long long resident = per_cu * g_num_cus;
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (k1 && (a.Ho != a.H || a.Wo != a.W)) return hipErrorInvalidValue; // the 1x1 loader reads input pixel m for output pixel m
     if (a.in2) {
         if constexpr (BM == 128 && BN == 128) {
             if (!k1) return hipErrorInvalidValue;
