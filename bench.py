@@ -218,7 +218,8 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: full sim loop, YOLOv8s (nc=1, seeded synthetic weights) + ResMLP(imaging-100ms_pred-40ms_moving-50ms, reference weights)",
+        "config": {"workload": ("BASELINE configs[2]" if args.size == 640 else f"BASELINE configs[4] per-GPU shape ({args.size}x{args.size})")
+                               + ": full sim loop, YOLOv8s (nc=1, seeded synthetic weights) + ResMLP(imaging-100ms_pred-40ms_moving-50ms, reference weights)",
                    "frame": f"{args.size}x{args.size} uint8 gray, resident in HBM", "batch_per_gpu": args.batch, "lanes_per_gpu": args.lanes,
                    "global_batch": args.batch * world, "timing_ms": [100, 40, 50], "conf": 0.1,
                    "parallelism": f"frame-sharded x{world}, one RCCL all-gather of [B,4] tracks per step" if world > 1 else "single GPU"},
