@@ -342,10 +342,12 @@ def test_fused_kernels_equal_layer_by_layer(hip_lib, monkeypatch, H, W, C):
     rng = np.random.default_rng(H * 7 + W + C)
     frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
     outs = []
-    for no_front, no_c2f, no_tail in (("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("0", "0", "1"), ("0", "0", "0")):
+    for no_front, no_c2f, no_tail, no_wide in (("1", "1", "1", "1"), ("0", "1", "1", "1"), ("1", "0", "1", "1"), ("0", "0", "1", "1"), ("0", "0", "0", "1"),
+                                               ("1", "1", "1", "0"), ("0", "0", "0", "0")):
         monkeypatch.setenv("WTK_NO_FUSED_FRONT", no_front)
         monkeypatch.setenv("WTK_NO_FUSED_C2F", no_c2f)
         monkeypatch.setenv("WTK_NO_FUSED_TAIL", no_tail)  # Detect box tower: last 1x1 inside the 3x3's epilogue
+        monkeypatch.setenv("WTK_NO_WIDE_1X1", no_wide)    # 1x1 convs: 256 x 128 tile / three-stage ring instead of conv_igemm_kernel
         det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
         res = det.predict_host(frames, conf=0.05)
         outs.append((res, det.debug_head(B), det.debug_tensor(3, B)))  # conv 3 = model.2.cv2

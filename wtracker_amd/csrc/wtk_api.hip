@@ -369,6 +369,7 @@ struct wtk_yolo {
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
+    int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
     int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
     int num_cus = 0;
@@ -630,6 +631,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
+    if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -1116,6 +1118,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     HIP_TRY(launch_conv3x3_c32(g, st));
                 else
                     HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
+            } else if (h->use_wide && conv1x1_wide_eligible(a, h->is_f16)) {
+                HIP_TRY(launch_conv1x1_wide(a, st));
             } else {
                 HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
             }

@@ -111,6 +111,9 @@ int conv_cfg_bn(int cfg);
 // is_f16: 1 -> _Float16 storage + v_mfma_f32_16x16x32_f16; 0 -> fp32 + v_mfma_f32_16x16x4_f32
 hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t stream);
 hipError_t conv_init_attributes();
+// fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
+bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
+hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input window (conv3x3_halo.hip).
