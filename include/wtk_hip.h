@@ -166,7 +166,7 @@ int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors);
 int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled);
 int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches);
 /* The same measurement per kernel (source file) of the forward pass, with the algorithmic FLOPs (2 x MACs) its launches
- * executed: kernel_id 0 stem_mfma_kernel, 1 conv_igemm_kernel, 2 sppf_pool_kernel, 3 head kernels, 4 conv3x3_halo_kernel
+ * executed: kernel_id 0 stem_mfma_kernel, 1 conv_igemm_kernel + conv1x1_wide_kernel, 2 sppf_pool_kernel, 3 head kernels, 4 conv3x3_halo_kernel
  * (including its fused 1x1 tails), 5 front_fused_kernel + c2f32_fused_kernel, 6 conv3x3_c32_kernel.  Class 1 of
  * wtk_yolo_get_profile is the sum of ids 1, 4, 5 and 6.  (Build-side instrumentation for bench.py's roofline object; the
  * reference has no counterpart.) */

@@ -456,7 +456,7 @@ def test_kernel_profile_accounts_for_every_conv_mac(hip_lib, dtype, scale):
         np.testing.assert_array_equal(a, b)
     total = sum(k["flops"] for k in kp.values())
     assert total == pytest.approx(2.0 * det.macs_per_frame * B * steps, rel=1e-9)
-    conv_ids = ["conv_igemm_kernel", "conv3x3_halo_kernel", "front_fused_kernel+c2f32_fused_kernel", "conv3x3_c32_kernel"]
+    conv_ids = ["conv_igemm_kernel+conv1x1_wide_kernel", "conv3x3_halo_kernel", "front_fused_kernel+c2f32_fused_kernel", "conv3x3_c32_kernel"]
     assert cp["conv"]["launches"] == sum(kp[k]["launches"] for k in conv_ids)
     assert cp["conv"]["total_ms"] == pytest.approx(sum(kp[k]["total_ms"] for k in conv_ids), rel=1e-9)
     assert all(k["total_ms"] > 0 for k in kp.values() if k["launches"])

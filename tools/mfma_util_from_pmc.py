@@ -21,7 +21,7 @@ SIMDS = 256 * 4
 
 
 def kernel_of(name: str) -> str:
-    for k in ("conv3x3_halo", "conv_igemm", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma"):
+    for k in ("conv3x3_halo", "conv_igemm", "conv1x1_wide", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma"):
         if k in name:
             return k
     return "head"

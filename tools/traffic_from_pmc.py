@@ -45,7 +45,10 @@ def main():
             n += 1
         kn = rf["Kernel_Name"]
         key = next((k for k in ("conv3x3_halo", "conv_igemm", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma") if k in kn), "head")
-        key = {"front_fused": "front_fused_kernel+c2f32_fused_kernel", "c2f32_fused": "front_fused_kernel+c2f32_fused_kernel", "head": "head"}.get(key, key + "_kernel")
+        if "conv1x1_wide" in kn:
+            key = "conv_igemm"
+        key = {"front_fused": "front_fused_kernel+c2f32_fused_kernel", "c2f32_fused": "front_fused_kernel+c2f32_fused_kernel", "head": "head",
+               "conv_igemm": "conv_igemm_kernel+conv1x1_wide_kernel"}.get(key, key + "_kernel")
         e = per_kernel.setdefault(key, {"launches": 0, "hbm_bytes_per_forward": 0.0})
         e["launches"] += 1
         e["hbm_bytes_per_forward"] += b

@@ -1118,7 +1118,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     HIP_TRY(launch_conv3x3_c32(g, st));
                 else
                     HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
-            } else if (h->use_wide && conv1x1_wide_eligible(a, h->is_f16)) {
+            } else if (h->use_wide && conv1x1_wide_eligible(a, h->is_f16) && a.CoutPad >= 256 && ((a.M + 255) / 256) * (a.CoutPad / 128) >= 384) {
                 HIP_TRY(launch_conv1x1_wide(a, st));
             } else {
                 HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));

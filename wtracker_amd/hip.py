@@ -309,7 +309,7 @@ class HipYolo:
             out[nme] = dict(total_ms=ms.value, launches=n.value)
         return out
 
-    KERNELS = ["stem_mfma_kernel", "conv_igemm_kernel", "sppf_pool_kernel", "head", "conv3x3_halo_kernel",
+    KERNELS = ["stem_mfma_kernel", "conv_igemm_kernel+conv1x1_wide_kernel", "sppf_pool_kernel", "head", "conv3x3_halo_kernel",
                "front_fused_kernel+c2f32_fused_kernel", "conv3x3_c32_kernel"]
 
     def get_kernel_profile(self) -> dict:
