@@ -176,6 +176,11 @@ def main():
         if os.path.exists(tpath) and args.size == 640 and args.dtype == "fp16":
             tj = json.load(open(tpath))
 
+        uj = None
+        upath = os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")
+        if os.path.exists(upath) and args.size == 640 and args.dtype == "fp16" and args.batch == 64:
+            uj = json.load(open(upath))
+
         def kernel_line(name, k):
             avg_ms = k["total_ms"] / max(k["launches"], 1)
             flop_per_launch = k["flops"] / max(k["launches"], 1)
@@ -183,7 +188,13 @@ def main():
             tr = None
             if tj and name in tj.get("per_kernel", {}):
                 tr = tj["per_kernel"][name]["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]
-            return {"kernel": name, "achieved": ach, "frac": ach / peak, "traffic": tr, "launches_per_step": k["launches"] / prof_steps,
+            extra = {}
+            if tr is not None and avg_ms > 0:  # HBM side of the same kernel: PMC bytes per launch / live launch duration, against ~8 TB/s
+                extra["hbm_gbps"] = tr / (avg_ms * 1e-3) / 1e9
+                extra["hbm_frac"] = extra["hbm_gbps"] / 8000.0
+            if uj and name in uj["per_kernel"]:  # MFMA-busy share from the committed PMC pass (executed MFMAs, 2.4 GHz nominal)
+                extra["mfma_util_pmc"] = uj["per_kernel"][name]["mfma_util"]
+            return {"kernel": name, "achieved": ach, "frac": ach / peak, "traffic": tr, **extra, "launches_per_step": k["launches"] / prof_steps,
                     "avg_launch_ms": avg_ms, "flop_per_launch_avg": flop_per_launch, "ms_per_step": k["total_ms"] / prof_steps}
 
         conv_kernels = {n: k for n, k in kprof.items() if k["flops"] > 0 and k["launches"] > 0}
@@ -194,7 +205,8 @@ def main():
         fam_flops = sum(k["flops"] for k in conv_kernels.values())
         fam_ach = fam_flops / (fam_ms * 1e-3) / 1e12
         roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": dom["frac"], "traffic": dom["traffic"], "launches_per_step": dom["launches_per_step"],
+                    "frac": dom["frac"], "traffic": dom["traffic"], "hbm_gbps": dom.get("hbm_gbps"), "hbm_frac": dom.get("hbm_frac"),
+                    "mfma_util_pmc": dom.get("mfma_util_pmc"), "launches_per_step": dom["launches_per_step"],
                     "avg_launch_ms": dom["avg_launch_ms"], "flop_per_launch_avg": dom["flop_per_launch_avg"],
                     "share_of_forward": dom["ms_per_step"] / sum(v["total_ms"] / prof_steps for v in prof.values()),
                     # every MFMA kernel of the forward pass together (what `value` is made of)

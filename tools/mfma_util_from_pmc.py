@@ -54,6 +54,22 @@ def main():
         for k, v in a.items():
             tot[k] = tot.get(k, 0) + v
     print(line("TOTAL", tot))
+    if len(sys.argv) > 2:  # machine-readable copy for bench.py (per kernel: MFMA-busy share of the nominal 2.4 GHz peak)
+        import json
+
+        def util(e):
+            return e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * e["dur"] * 1e-9 * 2.4e9)
+
+        names = {"conv3x3_halo": "conv3x3_halo_kernel", "front_fused": "front_fused_kernel+c2f32_fused_kernel", "c2f32_fused": "front_fused_kernel+c2f32_fused_kernel",
+                 "conv_igemm": "conv_igemm_kernel+conv1x1_wide_kernel", "conv1x1_wide": "conv_igemm_kernel+conv1x1_wide_kernel"}
+        merged = {}
+        for k, a in agg.items():
+            m = merged.setdefault(names.get(k, k), {"dur": 0})
+            for kk, v in a.items():
+                m[kk] = m.get(kk, 0) + v
+        json.dump({"definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch duration x 2.4 GHz), rocprofv3 --pmc, single stream, one 64-frame forward",
+                   "per_kernel": {k: {"mfma_util": util(a), "mfma_instructions": a.get("SQ_INSTS_MFMA", 0.0), "wait_any_share": a.get("SQ_WAIT_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 1.0), 1.0)}
+                                  for k, a in merged.items()}, "whole_forward": util(tot)}, open(sys.argv[2], "w"), indent=1)
     print("\n# per op")
     print(hdr)
     for (op, *_), e in zip(ops, run):
