@@ -55,6 +55,88 @@ template <int VAR, int D> __global__ __launch_bounds__(1024) void dma_kernel(con
     if (lane == 0) out[blockIdx.x * 16 + wave] = t1 - t0;
 }
 
+// Interference: waves 0..WD-1 request pieces as above (variant 2, buffer form, 3 in flight), the other waves of the block keep the CU's
+// LDS busy with ds_read_b128 (MODE 1), its matrix pipes with MFMAs (MODE 2), or both (MODE 3: 8 reads + 16 MFMAs per iteration, the
+// conv kernels' mix) until the requesters are done.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int MODE> __global__ __launch_bounds__(1024) void dma_interf_kernel(const char *src, long long region, int stride, int iters, int WD, unsigned long long *out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ int done;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    if (wave < WD) {
+        const char *base = src + (long long)blockIdx.x % 8 * region;
+        const unsigned loff = (unsigned)((lane >> 3) * stride + (lane & 7) * 16);
+        const unsigned piece_bytes = 8u * stride;
+        const unsigned pieces = (unsigned)(region / piece_bytes);
+        rsrc_t rs;
+        const unsigned long long b = (unsigned long long)base;
+        rs.x = (int)(b & 0xffffffffu), rs.y = (int)((b >> 32) & 0xffff), rs.z = (int)region, rs.w = 0x00020000;
+        char *dst0 = lds + wave * 4 * 1024;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        unsigned p = (unsigned)wave % pieces;
+        for (int it = 0; it < iters; ++it) {
+            char *dst = dst0 + (it & 3) * 1024;
+            const unsigned ldsaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dst;
+            const unsigned off = p * piece_bytes + loff;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(off), "s"(rs), "s"(ldsaddr) : "memory");
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            p = (p + (unsigned)WD) % pieces;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            out[blockIdx.x * 16 + wave] = t1 - t0;
+            atomicAdd(&done, 1);
+        }
+    } else {
+        // busy waves: read 8 KiB regions of LDS above the requesters' slots; bounded (iters * 64 iterations at most)
+        const char *rb = lds + 64 * 1024 + (wave - WD) * 2048;
+        floatx4 acc[4] = {};
+        half8 fa = {}, fb = {};
+        uint4 sink = {0, 0, 0, 0};
+        for (int it = 0; it < iters * 64; ++it) {
+            if (MODE & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 v;
+                    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)(rb + ((j & 1) * 1024) + lane * 16);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // (keeps a few reads in flight; the last ones are collected below)
+                    sink.x ^= v.x;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (MODE & 2) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[j & 3], 0, 0, 0);
+            }
+            if ((it & 15) == 15 && *reinterpret_cast<volatile int *>(&done) >= WD) break;
+        }
+        if (sink.x == 0x12345678u || acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 1.2345f) out[0] = 1; // keep the work alive
+    }
+}
+
+template <int MODE> int run_interf(const char *src, long long region, int stride, int wd, int wb, unsigned long long *dout, int ncu) {
+    const int iters = 2000;
+    const size_t shm = 64 * 1024 + (size_t)wb * 2048;
+    CK(hipFuncSetAttribute((const void *)dma_interf_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((dma_interf_kernel<MODE>), dim3(ncu), dim3((wd + wb) * 64), shm, nullptr, src, region, stride, iters, wd, dout);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(ncu * 16);
+    CK(hipMemcpy(st.data(), dout, st.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0; int n = 0;
+    for (int b = 0; b < ncu; ++b) for (int w = 0; w < wd; ++w) { cyc += (double)st[b * 16 + w]; ++n; }
+    cyc /= n;
+    std::printf("requesters %d + busy waves %d (%s): %6.1f B/clk/CU, %5.0f cycles per piece per requesting wave\n", wd, wb,
+                MODE == 1 ? "ds_read_b128" : MODE == 2 ? "MFMA" : MODE == 3 ? "8 ds_read_b128 + 16 MFMA" : "idle", (double)wd * iters * 1024 / cyc, cyc / iters);
+    return 0;
+}
+
 template <int VAR, int D> int run(const char *src, long long region, int stride, int waves, unsigned long long *dout, int ncu) {
     const int iters = 2000;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -88,6 +170,11 @@ int main(int argc, char **argv) {
         run<1, 3>(src, region, stride, waves, dout, ncu);
         run<2, 3>(src, region, stride, waves, dout, ncu);
         run<3, 3>(src, region, stride, waves, dout, ncu);
+    }
+    for (int wd : {4, 8}) {
+        run_interf<1>(src, region, stride, wd, 8, dout, ncu);
+        run_interf<2>(src, region, stride, wd, 8, dout, ncu);
+        run_interf<3>(src, region, stride, wd, 8, dout, ncu);
     }
     run<0, 1>(src, region, stride, 8, dout, ncu);
     run<0, 7>(src, region, stride, 8, dout, ncu);
