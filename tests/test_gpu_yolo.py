@@ -348,6 +348,7 @@ def test_fused_kernels_equal_layer_by_layer(hip_lib, monkeypatch, H, W, C):
         monkeypatch.setenv("WTK_NO_FUSED_C2F", no_c2f)
         monkeypatch.setenv("WTK_NO_FUSED_TAIL", no_tail)  # Detect box tower: last 1x1 inside the 3x3's epilogue
         monkeypatch.setenv("WTK_NO_WIDE_1X1", no_wide)    # 1x1 convs: 256 x 128 tile / three-stage ring instead of conv_igemm_kernel
+        monkeypatch.setenv("WTK_NO_IGEMM_TAIL", no_wide)  # model.4.cv1 inside the epilogue of model.3 (same switch position as the wide kernel)
         det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
         res = det.predict_host(frames, conf=0.05)
         outs.append((res, det.debug_head(B), det.debug_tensor(3, B)))  # conv 3 = model.2.cv2

@@ -6,7 +6,7 @@ import numpy as np
 from wtracker_amd import hip, yolo_spec as ys
 
 OFF = {"WTK_NO_FUSED_FRONT": "1", "WTK_NO_FUSED_C2F": "1", "WTK_NO_FUSED_TAIL": "1", "WTK_MATERIALIZE_UPSAMPLE": "1",
-       "WTK_HALO_SLABS": "2", "WTK_HALO_PERSIST": "0", "WTK_HALO_SMALL_BLOCKS": "0", "WTK_NO_WIDE_1X1": "1"}
+       "WTK_HALO_SLABS": "2", "WTK_HALO_PERSIST": "0", "WTK_HALO_SMALL_BLOCKS": "0", "WTK_NO_WIDE_1X1": "1", "WTK_NO_IGEMM_TAIL": "1"}
 w = ys.synthetic_weights("s", 1, seed=5)
 depth, width, maxch = ys.SCALES["s"]
 bad = 0

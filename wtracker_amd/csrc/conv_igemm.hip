@@ -93,7 +93,8 @@ template <int NV> __device__ __forceinline__ void store_run(float *p, const floa
 // LDS-DMA loads carry the non-temporal hint (measured: +8..17 % on the HBM-bound 1x1 layers, -15..25 % when a
 // second cout tile re-reads the rows from L2 — hence only for CoutPad == BN).
 // UP (K1 only): two-source input, channels [0, in2_split) come from a half-resolution tensor (see ConvArgs::in2).
-template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT, bool UP = false>
+// TAIL: fused 1x1 tail (ConvArgs::tail_w), fp16 128x128 tile only.
+template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT, bool UP = false, bool TAIL = false>
 __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 * 1024) ? 3 : 2) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int CE = Elem<T>::CE;
     constexpr int BKE = 8 * CE; // K elements per step = one 128-byte row
@@ -331,15 +332,92 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     load_bias(0);
     arm_acc();
 
+    // fused tail: this wave's slice of the tail weights (64 couts x 128 k as 4 k-steps x 4 cout tiles of MFMA A fragments)
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 w2f[TAIL ? 4 : 1][TAIL ? 4 : 1];
+    if constexpr (TAIL) {
+        static_assert(sizeof(T) == 2 && BM == 128 && BN == 128 && WAVES_P == 2 && WAVES_C == 2 && TP == 4 && TC == 4, "fused tail: fp16, 128x128 tile");
+        const _Float16 *w2 = reinterpret_cast<const _Float16 *>(a.tail_w);
+        const int arow = wave_c * 64 + (lr >> 2) * 16 + (lr & 3); // + 4t: the lane ends up owning couts wave_c*64 + lg*16 .. +15
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w2f[ks][t] = *reinterpret_cast<const h8 *>(w2 + (long long)(arow + 4 * t) * a.tail_kpad + ks * 32 + lg * 8);
+    }
+
     // ---- epilogue of one finished tile: lane (pixel lr of tile j, group lg) owns couts cb .. cb+NV-1
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
     const T *res = reinterpret_cast<const T *>(a.res);
-    auto epilogue = [&](int i) __attribute__((always_inline)) {
+    auto epilogue = [&](int i, char *cur) __attribute__((always_inline)) {
         const int tile = t_begin + i * t_stride;
         const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
         const int cb = (tile - ptile * nct) * BN + wave_c * WC + lg * NV;
         if (nct > 1 && i + 1 < my_tiles) load_bias(i + 1); // with one cout tile every tile has the same bias
+        if constexpr (TAIL) {
+            // ---- fused 1x1 tail (128 -> 128).  A wave holds 64 pixels x ONE HALF of this conv's channels: the two cout-waves of a
+            // pixel group exchange their SiLU'd fp16 tiles through the stage buffer that was just multiplied, then each of them
+            // computes ITS half of the tail's couts for the group's 64 pixels over all 128 channels (k-steps 0,1 from the low-channel
+            // tile, 2,3 from the high one: the K order of the stand-alone 1x1 kernel, same fp16 rounding of the intermediate:
+            // bit-identical).  The wave's 64 x 128 slice of the tail weights stays in 64 VGPRs for the whole kernel (w2f): fetching
+            // it per tile cost as much as the stand-alone 1x1 launch it replaces (a vector load holds its wave ~110 cycles).
+            __syncthreads(); // every wave is done reading `cur`
+            char *mine = cur + wave * 8192;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = j * 16 + lr;
+                float v[NV];
+#pragma unroll
+                for (int t = 0; t < TC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r];
+                if (a.act) wtk_silu_scaled_run<NV>(v);
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    h8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[c2 * 8 + e];
+                    *reinterpret_cast<h8 *>(mine + p * 128 + (((2 * lg + c2) ^ (p & 7)) << 4)) = hv;
+                }
+            }
+            __syncthreads();
+            {
+                const float4 *bp = reinterpret_cast<const float4 *>(a.tail_bias + wave_c * 64 + lg * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 b = bp[t];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][j] = (floatx4){b.x, b.y, b.z, b.w};
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const char *src = cur + (wave_p * 2 + (ks >> 1)) * 8192;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = j * 16 + lr;
+                    const h8 pf = *reinterpret_cast<const h8 *>(src + p * 128 + ((((ks & 1) * 4 + lg) ^ (p & 7)) << 4));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks][t], pf, acc[t][j], 0, 0, 0);
+                }
+            }
+            _Float16 *tout = reinterpret_cast<_Float16 *>(a.tail_out);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int n, ho, wo;
+                if (!pixel_coords(ptile, wave_p * WP + j * 16 + lr, n, ho, wo)) continue;
+                const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+                float v2[NV];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v2[t * 4 + r] = acc[t][j][r];
+                if (a.tail_act) wtk_silu_scaled_run<NV>(v2);
+                store_run<NV>(tout + pix * a.tail_ld + a.tail_coff + wave_c * 64 + lg * 16, v2);
+            }
+            arm_acc();
+            return;
+        }
         if (cb + NV <= a.Cout) { // padded output channels (Cout < CoutPad) are never stored
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
@@ -386,9 +464,9 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     // multiplied and, at a tile's last K step, its epilogue runs — so the next tile's loads hide behind it.
     const int total_stages = my_tiles * nk;
     int cp_ks = 0, cp_i = 0;
-    auto after_compute = [&]() __attribute__((always_inline)) {
+    auto after_compute = [&](char *cur) __attribute__((always_inline)) {
         if (++cp_ks == nk) {
-            epilogue(cp_i);
+            epilogue(cp_i, cur);
             cp_ks = 0;
             ++cp_i;
         }
@@ -406,7 +484,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem0, 0);
         compute_half(smem0, 1);
 #endif
-        after_compute();
+        after_compute(smem0);
         __syncthreads();
         if (s + 1 >= total_stages) break;
 #if WTK_IGEMM_ORDER == 1
@@ -418,7 +496,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem1, 0);
         compute_half(smem1, 1);
 #endif
-        after_compute();
+        after_compute(smem1);
         __syncthreads();
     }
 }
@@ -459,6 +537,17 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     if (k1 && (a.Ho != a.H || a.Wo != a.W)) return hipErrorInvalidValue; // the 1x1 loader reads input pixel m for output pixel m
+    if (a.tail_w) {
+        if constexpr (BM == 128 && BN == 128 && sizeof(T) == 2) {
+            if (k1 || a.in2 || a.res || a.out2 || a.Cout != BN || a.CoutPad != BN || !a.tail_bias || !a.tail_out || a.tail_kpad < BN || a.tail_kpad % 8 || a.tail_ld % 8 ||
+                a.tail_coff % 8)
+                return hipErrorInvalidValue; // built for the strided 3x3 -> 1x1 (128 -> 128) pair only
+            hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, false, false, false, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (a.in2) {
         if constexpr (BM == 128 && BN == 128) {
             if (!k1) return hipErrorInvalidValue;

@@ -783,6 +783,27 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             h->ops[first_op].wait_feat = i;
         }
     }
+    // A strided 3x3 conv (128 couts, implicit GEMM, fp16) whose ONLY reader is the 1x1 conv 128 -> 128 right behind it (model.3 ->
+    // model.4.cv1 in YOLOv8s): the 1x1 runs in the 3x3's epilogue, its input never reaches HBM.  WTK_NO_IGEMM_TAIL=1 switches it off.
+    if (!P.failed && h->is_f16 && !(std::getenv("WTK_NO_IGEMM_TAIL") && std::getenv("WTK_NO_IGEMM_TAIL")[0] == '1')) {
+        for (size_t i = 0; i + 1 < h->ops.size(); ++i) {
+            Op &c3 = h->ops[i], &c1 = h->ops[i + 1];
+            if (c3.kind != OP_CONV || c1.kind != OP_CONV || c3.halo || c3.k != 3 || c3.stride != 2 || c3.cfg != CFG_128x128 || c3.cout != 128 || c3.cout_pad != 128 ||
+                !c3.act || c3.res_buf >= 0 || c3.out2_buf >= 0 || c3.in2_buf >= 0 || c3.tail_op >= 0 || c3.folded)
+                continue;
+            if (c1.k != 1 || c1.stride != 1 || c1.cin != 128 || c1.cout != 128 || c1.cout_pad != 128 || c1.in_buf != c3.out_buf || c1.in_coff != c3.out_coff ||
+                c1.res_buf >= 0 || c1.out2_buf >= 0 || c1.in2_buf >= 0 || c1.folded || c1.tail_op >= 0 || h->bufs[c3.out_buf].C != 128)
+                continue;
+            bool other_reader = false;
+            for (size_t j = 0; j < h->ops.size(); ++j) {
+                const Op &o = h->ops[j];
+                if (j != i + 1 && (o.in_buf == c3.out_buf || o.res_buf == c3.out_buf || o.in2_buf == c3.out_buf)) other_reader = true;
+            }
+            if (other_reader) continue;
+            c3.tail_op = (int)i + 1;
+            c1.folded = 1;
+        }
+    }
     if (P.failed) {
         wtk_yolo_destroy(h);
         return 1;
@@ -1118,13 +1139,18 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     HIP_TRY(launch_conv3x3_c32(g, st));
                 else
                     HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
+            } else if (op.tail_op >= 0) { // implicit GEMM with the 1x1 behind it fused into its epilogue
+                const Op &t = h->ops[op.tail_op];
+                a.tail_w = t.w, a.tail_bias = t.bias, a.tail_kpad = t.Kpad, a.tail_act = t.act;
+                a.tail_out = h->bufs[t.out_buf].ptr, a.tail_ld = h->bufs[t.out_buf].C, a.tail_coff = t.out_coff;
+                HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
             } else if (h->use_wide && conv1x1_wide_eligible(a, h->is_f16) && a.CoutPad >= 256 && ((a.M + 255) / 256) * (a.CoutPad / 128) >= 384) {
                 HIP_TRY(launch_conv1x1_wide(a, st));
             } else {
                 HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
             }
             ++launches[kid];
-            flops[kid] += op_flops(op) + (op.halo && op.tail_op >= 0 ? op_flops(h->ops[op.tail_op]) : 0.0);
+            flops[kid] += op_flops(op) + (op.tail_op >= 0 ? op_flops(h->ops[op.tail_op]) : 0.0);
             if (two_lanes && op.signal_feat >= 0) HIP_TRY(hipEventRecord(h->feat_ev[op.signal_feat], main_st));
         }
     }

@@ -102,6 +102,13 @@ struct ConvArgs {
     int ptiles;  // pixel tiles (filled by launch_conv)
     FastDiv d_howo, d_wo, d_tilew, d_tilesx, d_tpi, d_nct; // filled by launch_conv
     const void *zeros; // >= 16 zero bytes in device memory (source of padded / out-of-range chunks)
+    // optional fused 1x1 tail (fp16, 128x128 tile, Cout == CoutPad == 128, no residual / second output): the conv whose ONLY reader
+    // is a 1x1 conv 128 -> 128 hands its SiLU'd fp16 tile over through LDS and the block multiplies it by tail_w right away;
+    // `out` is then not written (model.3 -> model.4.cv1: 105 MB written and read back per 64 frames otherwise)
+    const void *tail_w;     // packed [128][tail_kpad]
+    const float *tail_bias; // [128]
+    void *tail_out;
+    int tail_kpad, tail_ld, tail_coff, tail_act;
 };
 
 // Tile configurations (pixels x couts), all 4 waves / 256 threads
