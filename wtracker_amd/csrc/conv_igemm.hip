@@ -89,6 +89,31 @@ template <int NV> __device__ __forceinline__ void store_run(float *p, const floa
     for (int i = 0; i < NV; i += 4) *reinterpret_cast<float4 *>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
 }
 
+// LDS-DMA requests in buffer form (SGPR resource + wave-uniform byte offset + per-lane 32-bit offset) from inline asm: 5-10 % less
+// wave time per request than the flat form (tools/lds_dma_rate.hip), no 64-bit address arithmetic and no zero-page select per row
+// (a lane offset of 0xffffffff is out of range and lands zeros).  hipcc does not see these requests: every barrier that publishes a
+// stage is preceded by an explicit s_waitcnt vmcnt(0).  The two-source (UP) loader keeps the builtin form.
+#ifndef WTK_IGEMM_BUFFER_DMA
+#define WTK_IGEMM_BUFFER_DMA 1
+#endif
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base) {
+    const unsigned long long b = (unsigned long long)base;
+    rsrc_t r;
+    r.x = (int)(unsigned)(b & 0xffffffffu);
+    r.y = (int)(unsigned)((b >> 32) & 0xffffu);
+    r.z = (int)0xffffff00u;
+    r.w = 0x00020000;
+    return r;
+}
+template <bool NTL> __device__ __forceinline__ void dma_buf(const rsrc_t &rs, unsigned voff, unsigned soff, char *lds_dst) {
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds_dst;
+    if constexpr (NTL)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen nt lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds) : "memory");
+}
+
 // K1: 1x1 stride-1 conv (no tap walk).  NT: the pixel operand is read by exactly one cout tile, so its
 // LDS-DMA loads carry the non-temporal hint (measured: +8..17 % on the HBM-bound 1x1 layers, -15..25 % when a
 // second cout tile re-reads the rows from L2 — hence only for CoutPad == BN).
@@ -198,13 +223,47 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     int phi0[PR], pwi0[PR];
     const char *wslab = nullptr; // wave-uniform
     int kc = 0, tap = 0, ld_ks = 0, ld_i = 0;
+    constexpr bool BUF = WTK_IGEMM_BUFFER_DMA && !UP;
+    unsigned poff[PR]; // BUF: byte offset of the row's (first) input pixel from the tile's resource base (0xffffffff: no pixel)
+    rsrc_t in_rs = {0, 0, 0, 0}, w_rs = {0, 0, 0, 0};
     auto setup_loader = [&](int i) __attribute__((always_inline)) {
         const int tile = t_begin + i * t_stride;
         const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
         const int n0 = (tile - ptile * nct) * BN;
+        int nb = 0; // BUF: image of the tile's first pixel (wave-uniform); offsets are relative to it
+        if constexpr (BUF) {
+            if (K1 && a.tile_w == 0) {
+                in_rs = make_rsrc(in + (long long)ptile * BM * a.in_ld + a.in_coff);
+            } else {
+                int hb, wb;
+                pixel_coords(ptile, 0, nb, hb, wb);
+                nb = __builtin_amdgcn_readfirstlane(nb);
+                in_rs = make_rsrc(in + (long long)nb * a.H * a.W * a.in_ld + a.in_coff);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
             int n, ho, wo;
+            if constexpr (BUF) {
+                if (K1 && a.tile_w == 0) {
+                    const long long m = (long long)ptile * BM + r0 + RPP * r;
+                    poff[r] = m < a.M ? (unsigned)(((r0 + RPP * r) * a.in_ld + lchunk * CE) * (int)sizeof(T)) : 0xffffffffu;
+                    continue;
+                }
+                const bool okb = pixel_coords(ptile, r0 + RPP * r, n, ho, wo);
+                if (K1) {
+                    poff[r] = okb ? (unsigned)((((((n - nb) * a.H + ho) * a.W + wo) * a.in_ld) + lchunk * CE) * (int)sizeof(T)) : 0xffffffffu;
+                } else if (okb) {
+                    phi0[r] = ho * a.stride - a.pad;
+                    pwi0[r] = wo * a.stride - a.pad;
+                    poff[r] = (unsigned)((((n - nb) * a.H + phi0[r]) * a.W + pwi0[r]) * a.in_ld * (int)sizeof(T)); // may wrap below 0: only used with an in-range tap
+                } else {
+                    phi0[r] = -(1 << 28);
+                    pwi0[r] = -(1 << 28);
+                    poff[r] = 0;
+                }
+                continue;
+            }
             if (K1 && !UP && a.tile_w == 0) {
                 // 1x1 / stride 1 over a linear pixel range: input pixel index = output pixel index m, no (n, ho, wo) needed.  The two
                 // divisions per staged row this used to spend sit inside the MFMA loop of the previous tile (K = 128: two K steps per tile)
@@ -227,6 +286,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
             }
         }
         wslab = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.w) + (long long)n0 * a.Kpad);
+        if constexpr (BUF) w_rs = make_rsrc(wslab);
         kc = lchunk * CE;
         tap = 0;
         if (!K1)
@@ -238,7 +298,26 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     };
     auto issue_stage = [&](char *pt) __attribute__((always_inline)) {
         char *wt = pt + BM * 128;
-        if (K1) {
+        if constexpr (BUF) {
+            const unsigned so = (unsigned)(ld_ks * (BKE * (int)sizeof(T))); // wave-uniform K offset of the step
+            if (K1) {
+                const bool k_ok = kc < a.Cin; // K tail of the last step is zero
+#pragma unroll
+                for (int r = 0; r < PR; ++r) dma_buf<NT>(in_rs, k_ok ? poff[r] : 0xffffffffu, so, pt + (RPP * r + 8 * wave) * 128);
+            } else {
+                const int kh = a.KW == 3 ? (tap * 11) >> 5 : tap / a.KW, kw = tap - kh * a.KW; // tap/3 for tap < 32
+                const bool tap_ok = tap < ntaps;
+                const unsigned delta = (unsigned)((((kh * a.W + kw) * a.in_ld) + kc) * (int)sizeof(T));
+#pragma unroll
+                for (int r = 0; r < PR; ++r) {
+                    const int hi = phi0[r] + kh, wi = pwi0[r] + kw;
+                    const bool ok = tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                    dma_buf<false>(in_rs, ok ? poff[r] + delta : 0xffffffffu, 0u, pt + (RPP * r + 8 * wave) * 128);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i) dma_buf<false>(w_rs, wvoff[i], so, wt + (RPP * i + 8 * wave) * 128);
+        } else if (K1) {
             const bool k_ok = kc < a.Cin; // K tail of the last step is zero
             if (UP && ld_ks * BKE < a.in2_split) { // block-uniform: in2_split is a multiple of the K step
 #pragma unroll
@@ -268,11 +347,13 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
                                                  (__attribute__((address_space(3))) void *)(pt + (RPP * r + 8 * wave) * 128), 16, 0, 0);
             }
         }
-        const char *ub = wslab + (size_t)ld_ks * (BKE * sizeof(T));
+        if constexpr (!BUF) {
+            const char *ub = wslab + (size_t)ld_ks * (BKE * sizeof(T));
 #pragma unroll
-        for (int i = 0; i < WR; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + wvoff[i]),
-                                             (__attribute__((address_space(3))) void *)(wt + (RPP * i + 8 * wave) * 128), 16, 0, 0);
+            for (int i = 0; i < WR; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + wvoff[i]),
+                                                 (__attribute__((address_space(3))) void *)(wt + (RPP * i + 8 * wave) * 128), 16, 0, 0);
+        }
         // advance the loader; crossing into the next tile recomputes the row table
         kc += BKE;
         if (!K1)
@@ -361,6 +442,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
             // tile, 2,3 from the high one: the K order of the stand-alone 1x1 kernel, same fp16 rounding of the intermediate:
             // bit-identical).  The wave's 64 x 128 slice of the tail weights stays in 64 VGPRs for the whole kernel (w2f): fetching
             // it per tile cost as much as the stand-alone 1x1 launch it replaces (a vector load holds its wave ~110 cycles).
+            if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads(); // every wave is done reading `cur`
             char *mine = cur + wave * 8192;
 #pragma unroll
@@ -473,6 +555,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     };
     setup_loader(0);
     issue_stage(smem0);
+    if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads(); // drains the LDS-DMA (vmcnt(0)) and publishes the tile
     for (int s = 0; s < total_stages; s += 2) {
 #if WTK_IGEMM_ORDER == 1
@@ -485,6 +568,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem0, 1);
 #endif
         after_compute(smem0);
+        if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s + 1 >= total_stages) break;
 #if WTK_IGEMM_ORDER == 1
@@ -497,6 +581,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem1, 1);
 #endif
         after_compute(smem1);
+        if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }
