@@ -223,29 +223,31 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     int phi0[PR], pwi0[PR];
     const char *wslab = nullptr; // wave-uniform
     int kc = 0, tap = 0, ld_ks = 0, ld_i = 0;
-    constexpr bool BUF = WTK_IGEMM_BUFFER_DMA && !UP;
+    constexpr bool BUF = WTK_IGEMM_BUFFER_DMA;
     unsigned poff[PR]; // BUF: byte offset of the row's (first) input pixel from the tile's resource base (0xffffffff: no pixel)
-    rsrc_t in_rs = {0, 0, 0, 0}, w_rs = {0, 0, 0, 0};
+    unsigned poff2[UP ? PR : 1]; // ... of the half-resolution pixel (ho/2, wo/2) in in2
+    rsrc_t in_rs = {0, 0, 0, 0}, in2_rs = {0, 0, 0, 0}, w_rs = {0, 0, 0, 0};
     auto setup_loader = [&](int i) __attribute__((always_inline)) {
         const int tile = t_begin + i * t_stride;
         const int ptile = (int)fdiv((unsigned)tile, a.d_nct);
         const int n0 = (tile - ptile * nct) * BN;
         int nb = 0; // BUF: image of the tile's first pixel (wave-uniform); offsets are relative to it
         if constexpr (BUF) {
-            if (K1 && a.tile_w == 0) {
+            if (K1 && !UP && a.tile_w == 0) {
                 in_rs = make_rsrc(in + (long long)ptile * BM * a.in_ld + a.in_coff);
             } else {
                 int hb, wb;
                 pixel_coords(ptile, 0, nb, hb, wb);
                 nb = __builtin_amdgcn_readfirstlane(nb);
                 in_rs = make_rsrc(in + (long long)nb * a.H * a.W * a.in_ld + a.in_coff);
+                if (UP) in2_rs = make_rsrc(in2 + (long long)nb * (a.H >> 1) * (a.W >> 1) * a.in2_ld + a.in2_coff);
             }
         }
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
             int n, ho, wo;
             if constexpr (BUF) {
-                if (K1 && a.tile_w == 0) {
+                if (K1 && !UP && a.tile_w == 0) {
                     const long long m = (long long)ptile * BM + r0 + RPP * r;
                     poff[r] = m < a.M ? (unsigned)(((r0 + RPP * r) * a.in_ld + lchunk * CE) * (int)sizeof(T)) : 0xffffffffu;
                     continue;
@@ -253,6 +255,8 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
                 const bool okb = pixel_coords(ptile, r0 + RPP * r, n, ho, wo);
                 if (K1) {
                     poff[r] = okb ? (unsigned)((((((n - nb) * a.H + ho) * a.W + wo) * a.in_ld) + lchunk * CE) * (int)sizeof(T)) : 0xffffffffu;
+                    if (UP)
+                        poff2[r] = okb ? (unsigned)((((((n - nb) * (a.H >> 1) + (ho >> 1)) * (a.W >> 1) + (wo >> 1)) * a.in2_ld) + lchunk * CE) * (int)sizeof(T)) : 0xffffffffu;
                 } else if (okb) {
                     phi0[r] = ho * a.stride - a.pad;
                     pwi0[r] = wo * a.stride - a.pad;
@@ -302,8 +306,13 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
             const unsigned so = (unsigned)(ld_ks * (BKE * (int)sizeof(T))); // wave-uniform K offset of the step
             if (K1) {
                 const bool k_ok = kc < a.Cin; // K tail of the last step is zero
+                if (UP && ld_ks * BKE < a.in2_split) { // block-uniform: in2_split is a multiple of the K step; low-resolution rows are shared by 4 pixels: no nt
 #pragma unroll
-                for (int r = 0; r < PR; ++r) dma_buf<NT>(in_rs, k_ok ? poff[r] : 0xffffffffu, so, pt + (RPP * r + 8 * wave) * 128);
+                    for (int r = 0; r < PR; ++r) dma_buf<false>(in2_rs, poff2[r], so, pt + (RPP * r + 8 * wave) * 128);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) dma_buf<NT>(in_rs, k_ok ? poff[r] : 0xffffffffu, so, pt + (RPP * r + 8 * wave) * 128);
+                }
             } else {
                 const int kh = a.KW == 3 ? (tap * 11) >> 5 : tap / a.KW, kw = tap - kh * a.KW; // tap/3 for tap < 32
                 const bool tap_ok = tap < ntaps;
