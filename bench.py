@@ -87,7 +87,7 @@ def main():
     from wtracker_amd import yolo_spec as ys
     from wtracker_amd.pipeline import TrackPipeline
 
-    if _build.needs_build() and rank == 0:
+    if world == 1 and _build.needs_build():
         _build.build(verbose=False)
     if args.backend != "nccl" and torch.cuda.device_count() <= local_rank:
         local_rank = 0  # rehearsal: ranks share the one visible GPU
@@ -102,6 +102,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # only rank 0 (re)builds a stale library; nobody loads it before that is done
+        if rank == 0 and _build.needs_build():
+            _build.build(verbose=False)
         dist.barrier()
     if hip.device_count() <= local_rank:
         raise SystemExit("no HIP device visible: the product path has no CPU fallback")
