@@ -1,14 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the YOLOv8s + ResMLP sim-loop hot path on MI355X (BASELINE.json metric).
 
-One "step" = one super-batch: every rank runs the detector (63 conv layers in ~50 launches: fused front,
-fused C2f tail, implicit-GEMM and window-kernel convs with fused Detect tails, SPPF pool, head select) on its `--batch` synthetic 640x640 frames that are already resident in HBM, the [B,4]
-track slices are all-gathered (N > 1 only), and the ResMLP movement vectors of the cycles that became
-computable are produced (wtracker_amd/pipeline.py).  Prints ONE JSON line on rank 0.
+One "step" = one super-batch: every rank runs the detector (63 conv layers in ~50 launches: fused front, fused C2f tail,
+implicit-GEMM and window-kernel convs with fused Detect tails, SPPF pool, head select) on its `--batch` synthetic 640x640
+frames that are already resident in HBM, the [B,4] track slices are all-gathered (N > 1 only), and the ResMLP movement
+vectors of the cycles that became computable are produced (wtracker_amd/pipeline.py).  Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
+
+What the line carries (everything measured inside this one command):
+  value / ms_per_step   fp16 mode (BASELINE.md §4 allows it with an accuracy report): `--repeats` timed windows of EXACTLY
+                        `--steps` steps each, every window bracketed by barrier + device synchronisation, MAX over ranks per
+                        window; value = frames of one window / MEDIAN window; `windows` holds min / median / max
+  roofline              dominant kernel, algorithmic FLOPs / live HIP-event launch time (wtk_yolo_get_kernel_profile)
+  fp32                  the same workload in the reference's precision (yolo/yolo_train_config.yaml:51 `half: False`),
+                        its own value / windows / roofline against the fp32 matrix peak                       (N = 1 only)
+  parity                survivor-index match rate and IoU distribution of BOTH modes against the fp32 CPU restatement on
+                        the CPU leg's frames, computed outside the timed regions                               (N = 1 only)
+  cpu_baseline          oracle/ (kind "port") timed on the host cores at B = 64, 15 and 1                      (N = 1 only)
+Fields that cannot be measured from inside the process (HBM bytes and MFMA-busy share come from rocprofv3 PMC passes) are
+read from profiles/*.json ONLY when that file was collected on exactly these kernel sources (`src_sha`), and then carry a
+`provenance` entry; otherwise they are null.
 """
 from __future__ import annotations
 
@@ -26,36 +40,68 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0
+PROFILE_ROUND = "r02"
 
 
-def cpu_baseline(weights, dims, size: int, n_frames: int, batch: int, folded_path: str) -> dict:
-    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload.  Thread count:
-    the torch-CPU conv stack peaks near 32 threads on the GPU box's host (8: 14.8, 16: 18.3, 32: 19.2,
-    64: 11.4, 128: 5.9 frames/s measured with tools/cpu_threads_probe.py), so min(cores, 32) is used."""
+def cpu_baseline(weights, dims, size: int, folded_path: str, frames64: np.ndarray, conf: float) -> tuple:
+    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload, at the three batch sizes of
+    BASELINE.md §4: 64 (the benched super-batch), 15 (the reference's real cycle batch, yolo_controller.py:108-109) and 1
+    (provide_movement_vector, yolo_controller.py:96-98).  Thread count: the torch-CPU conv stack peaks near 32 threads on the
+    GPU box's host (8: 14.8, 16: 18.3, 32: 19.2, 64: 11.4, 128: 5.9 frames/s measured with tools/cpu_threads_probe.py), so
+    min(cores, 32) is used.  Returns (json object, oracle outputs on `frames64` = the checker for the parity object)."""
     from oracle import resmlp_oracle
     from oracle import yolo_oracle as yo
-    from wtracker_amd import frames as fr
 
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     model = yo.YoloOracle(weights, dims)
-    frames, _ = fr.synthetic_frames(min(n_frames, 2 * batch), size, seed=1)
     st = resmlp_oracle.load_state(folded_path)
-    yo.predict(model, list(frames[:2]), imgsz=size)  # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    while done < n_frames:
-        b = min(batch, n_frames - done)
-        off = done % max(len(frames) - b + 1, 1)
-        yo.predict(model, list(frames[off : off + b]), imgsz=size)
-        done += b
-    # ResMLP over the sample's cycles (one sample per 9 frames)
-    x = np.zeros((max(n_frames // 9, 1), 28), dtype=np.float32)
-    resmlp_oracle.forward(st, x)
-    dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} synthetic {size}x{size} frames in batches of {batch}, torch-CPU fp32 restatement "
-                      f"(oracle/yolo_oracle.py) + numpy ResMLP, {cores} threads, {dt:.1f} s"}
+
+    def timed(frames, batch, warm_batches):
+        for i in range(warm_batches):
+            yo.predict(model, list(frames[:batch]), imgsz=size, conf=conf)
+        outs = []
+        t0 = time.perf_counter()
+        for i in range(0, len(frames), batch):
+            outs.append(yo.predict(model, list(frames[i : i + batch]), imgsz=size, conf=conf))
+        resmlp_oracle.forward(st, np.zeros((max(len(frames) // 9, 1), 28), dtype=np.float32))  # one ResMLP sample per 9-frame cycle
+        dt = time.perf_counter() - t0
+        return dt, outs
+
+    dt64, outs = timed(frames64, 64, 1)
+    checker = tuple(np.concatenate([o[k] for o in outs]) for k in range(3))
+    dt15, _ = timed(frames64[:60], 15, 1)
+    dt1, _ = timed(frames64[:24], 1, 2)
+    by_batch = {"64": {"value": len(frames64) / dt64, "frames": len(frames64), "seconds": dt64},
+                "15": {"value": 60 / dt15, "frames": 60, "seconds": dt15},
+                "1": {"value": 24 / dt1, "frames": 24, "seconds": dt1}}
+    obj = {"value": by_batch["64"]["value"], "unit": "frames/s", "cores": cores, "kind": "port", "by_batch": by_batch,
+           "sample": f"{len(frames64)} synthetic {size}x{size} frames in batches of 64 (value), 60 in batches of 15, 24 one at a time; torch-CPU fp32 "
+                     f"restatement (oracle/yolo_oracle.py) + numpy ResMLP, {cores} threads, {dt64 + dt15 + dt1:.1f} s"}
+    return obj, checker
+
+
+class Workload:
+    """One precision mode of the benched workload on this rank: `lanes` detector handles, the ResMLP, the pipeline."""
+
+    def __init__(self, args, dtype, lanes, weights, dims3, folded, local_rank, rank, world, group, dev, n_steps):
+        from wtracker_amd import hip
+        from wtracker_amd.pipeline import TrackPipeline
+
+        width, depth, maxch = dims3
+        self.dets = [hip.HipYolo(weights, (args.size, args.size), args.batch, dtype=dtype, nc=1, width=width, depth=depth,
+                                 max_channels=maxch, device=local_rank) for _ in range(lanes)]
+        self.mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
+        # 60 fps, 100/40/50 ms timing (BASELINE config 3): imaging 6, pred 3, moving 3 frames
+        self.pipe = TrackPipeline(self.dets, self.mlp, folded, args.batch, n_steps * args.batch * world, imaging_frame_num=6,
+                                  pred_frame_num=3, cycle_frame_num=9, conf=args.conf, rank=rank, world=world, group=group, device=dev)
+        self.dtype, self.lanes = dtype, lanes
+
+    def close(self):
+        for d in self.dets:
+            d.close()
+        self.mlp.close()
 
 
 def main():
@@ -63,12 +109,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=10, help="timed windows of --steps steps each (median reported)")
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config 3: 64)")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"], help="precision of the headline value")
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
-    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel-class HIP-event timing")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline / parity sample (0 = skip both)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing (no roofline object)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision sub-object")
+    ap.add_argument("--conf", type=float, default=0.1)
     ap.add_argument("--lanes", type=int, default=2, help="forward passes in flight per GPU (each lane = own workspace + HIP stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box, where every rank then shares cuda:0)")
@@ -82,18 +131,22 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
 
-    from wtracker_amd import _build, hip, resmlp
+    from wtracker_amd import _build, hip, metrics, resmlp
     from wtracker_amd import frames as fr
     from wtracker_amd import yolo_spec as ys
-    from wtracker_amd.pipeline import TrackPipeline
 
-    if world == 1 and _build.needs_build():
-        _build.build(verbose=False)
+    # The library is built BEFORE any rendezvous: at N = 1 a stale library is rebuilt here; at N > 1 every rank
+    # refuses to run on a stale one (a half-written .so must never be loaded by a sibling rank) — __graft_entry__.build() first.
+    if not os.environ.get("WTK_HIP_LIB") and _build.needs_build():
+        if world == 1:
+            _build.build(verbose=False)
+        else:
+            raise SystemExit("libwtk_hip.so is missing or older than its sources: run `python __graft_entry__.py` before a multi-rank bench")
     if args.backend != "nccl" and torch.cuda.device_count() <= local_rank:
         local_rank = 0  # rehearsal: ranks share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    group = None
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -102,22 +155,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-        # only rank 0 (re)builds a stale library; nobody loads it before that is done
-        if rank == 0 and _build.needs_build():
-            _build.build(verbose=False)
-        dist.barrier()
     if hip.device_count() <= local_rank:
         raise SystemExit("no HIP device visible: the product path has no CPU fallback")
 
     scale, nc = "s", 1
     weights = ys.synthetic_weights(scale, nc, seed=0)
     depth, width, maxch = ys.SCALES[scale]
-    dets = [hip.HipYolo(weights, (args.size, args.size), args.batch, dtype=args.dtype, nc=nc, width=width, depth=depth,
-                        max_channels=maxch, device=local_rank) for _ in range(args.lanes)]
-    det = dets[0]
     golden = os.path.join(ROOT, "tests", "golden", "resmlp_100ms.npz")
     folded = resmlp.load_npz(golden)  # ResMLP(imaging-100ms_pred-40ms_moving-50ms): the reference's shipped weights
-    mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
 
     # synthetic frames, resident in HBM before the timed region; every rank draws its own seed
     pool = max(args.pool // args.batch, 1) * args.batch
@@ -125,80 +170,89 @@ def main():
     frames = torch.from_numpy(frames_np).to(dev)
     n_pool_batches = pool // args.batch
 
-    total_steps = args.warmup + args.steps
-    total_frames = total_steps * args.batch * world
-    # 60 fps, 100/40/50 ms timing (BASELINE config 3): imaging 6, pred 3, moving 3 frames
-    pipe = TrackPipeline(dets, mlp, folded, args.batch, total_frames, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9,
-                         conf=0.1, rank=rank, world=world, group=group, device=dev)
-
-    def run(s: int):
-        b = s % n_pool_batches
-        pipe.step(s, frames[b * args.batch : (b + 1) * args.batch])
-
-    def fence():
+    def fence(pipe):
         pipe.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
-            import torch.distributed as dist
-
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for s in range(args.warmup):
-        run(s)
-    fence()
-    t0 = time.perf_counter()
-    for s in range(args.warmup, total_steps):
-        run(s)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    def measure(dtype: str, lanes: int, repeats: int, profile: bool) -> dict:
+        """Warm-up, `repeats` timed windows of args.steps steps, then (optionally) the per-kernel profile pass."""
+        prof_steps = max(min(args.steps, 10), 1) if profile else 0
+        n_steps = args.warmup + repeats * args.steps + 2 * prof_steps + lanes
+        wl = Workload(args, dtype, lanes, weights, (width, depth, maxch), folded, local_rank, rank, world, None, dev, n_steps)
+        pipe = wl.pipe
 
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        def run(s: int):
+            b = s % n_pool_batches
+            pipe.step(s, frames[b * args.batch : (b + 1) * args.batch])
 
-    # ---- per-kernel-class device time with HIP events on the launch stream (same workload, rank 0)
-    roofline = None
-    if not args.no_profile:
-        fence()
-        det.set_profiling(True)
-        prof_steps = max(min(args.steps, 10), 1)
-        for s in range(prof_steps):
-            run((args.warmup + s) // args.lanes * args.lanes)  # lane 0 = the profiled handle
-        fence()
-        prof = det.get_profile()
-        kprof = det.get_kernel_profile()
-        det.set_profiling(False)
-        peak = PEAK_TFLOPS[args.dtype]
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE x2 + WRITE_SIZE,
-        # tools/traffic_from_pmc.py); only valid for the configuration it was collected on
-        tj = None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-        if os.path.exists(tpath) and args.size == 640 and args.dtype == "fp16":
-            tj = json.load(open(tpath))
+        s = 0
+        for _ in range(args.warmup):
+            run(s)
+            s += 1
+        fence(pipe)
+        win = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run(s)
+                s += 1
+            fence(pipe)
+            win.append(time.perf_counter() - t0)
+        if world > 1:
+            t = torch.tensor(win, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # a window ends when the slowest rank is done
+            win = [float(v) for v in t.cpu()]
+        med = float(np.median(win))
+        frames_per_window = args.steps * args.batch * world
+        res = {"dtype": dtype, "value": frames_per_window / med, "unit": "frames/s", "ms_per_step": med / args.steps * 1e3,
+               "windows": {"n": repeats, "steps_each": args.steps, "median_ms": med * 1e3, "min_ms": min(win) * 1e3, "max_ms": max(win) * 1e3,
+                           "first_ms": win[0] * 1e3, "value_best": frames_per_window / min(win), "value_worst": frames_per_window / max(win)}}
+        if profile:
+            # per-kernel device time with HIP events on the launch stream: one stream, one event pair around every run of launches
+            # of the same kernel (wtk_yolo_get_kernel_profile); lane 0's handle is the profiled one
+            det = wl.dets[0]
+            s = (s + lanes - 1) // lanes * lanes
+            det.set_profiling(True)
+            for i in range(prof_steps):
+                run(s + i * lanes)  # steps congruent to 0 mod lanes run on lane 0
+            fence(pipe)
+            res["roofline"] = roofline_object(det.get_profile(), det.get_kernel_profile(), prof_steps, dtype)
+            det.set_profiling(False)
+        wl.close()
+        return res
 
-        uj = None
-        upath = os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")
-        if os.path.exists(upath) and args.size == 640 and args.dtype == "fp16" and args.batch == 64:
-            uj = json.load(open(upath))
+    def committed(name: str):
+        """profiles/<round>_<name>.json if it was collected on exactly the kernel sources of this build, else None."""
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")
+        if not os.path.exists(path) or args.size != 640 or args.batch != 64:
+            return None, None
+        j = json.load(open(path))
+        if j.get("src_sha") != _build.source_sha():
+            return None, None
+        return j, {"file": os.path.relpath(path, ROOT), "src_sha": j["src_sha"], "collected": j.get("collected", "rocprofv3 --pmc, separate passes"),
+                   "note": "not measured in this run; valid for these kernel sources only"}
+
+    def roofline_object(prof: dict, kprof: dict, prof_steps: int, dtype: str) -> dict:
+        peak = PEAK_TFLOPS[dtype]
+        tj, tprov = committed("conv_traffic") if dtype == "fp16" else (None, None)
+        uj, uprov = committed("pmc_mfma_util") if dtype == "fp16" else (None, None)
 
         def kernel_line(name, k):
             avg_ms = k["total_ms"] / max(k["launches"], 1)
             flop_per_launch = k["flops"] / max(k["launches"], 1)
             ach = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            tr = None
-            if tj and name in tj.get("per_kernel", {}):
-                tr = tj["per_kernel"][name]["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]
-            extra = {}
-            if tr is not None and avg_ms > 0:  # HBM side of the same kernel: PMC bytes per launch / live launch duration, against ~8 TB/s
-                extra["hbm_gbps"] = tr / (avg_ms * 1e-3) / 1e9
-                extra["hbm_frac"] = extra["hbm_gbps"] / 8000.0
-            if uj and name in uj["per_kernel"]:  # MFMA-busy share from the committed PMC pass (executed MFMAs, 2.4 GHz nominal)
-                extra["mfma_util_pmc"] = uj["per_kernel"][name]["mfma_util"]
-            return {"kernel": name, "achieved": ach, "frac": ach / peak, "traffic": tr, **extra, "launches_per_step": k["launches"] / prof_steps,
-                    "avg_launch_ms": avg_ms, "flop_per_launch_avg": flop_per_launch, "ms_per_step": k["total_ms"] / prof_steps}
+            tr = tj["per_kernel"][name]["hbm_bytes_per_launch_avg"] if tj and name in tj.get("per_kernel", {}) else None
+            e = {"kernel": name, "achieved": ach, "frac": ach / peak, "traffic": tr, "launches_per_step": k["launches"] / prof_steps,
+                 "avg_launch_ms": avg_ms, "flop_per_launch_avg": flop_per_launch, "ms_per_step": k["total_ms"] / prof_steps}
+            if tr is not None and avg_ms > 0:  # HBM side of the same kernel: PMC bytes per launch / live launch duration
+                e["hbm_gbps"] = tr / (avg_ms * 1e-3) / 1e9
+                e["hbm_frac"] = e["hbm_gbps"] / HBM_PEAK_GBPS
+            if uj and name in uj["per_kernel"]:  # MFMA-busy share (executed MFMAs, 2.4 GHz nominal)
+                e["mfma_util_pmc"] = uj["per_kernel"][name]["mfma_util"]
+            return e
 
         conv_kernels = {n: k for n, k in kprof.items() if k["flops"] > 0 and k["launches"] > 0}
         lines = sorted((kernel_line(n, k) for n, k in conv_kernels.items()), key=lambda e: -e["ms_per_step"])
@@ -207,27 +261,33 @@ def main():
         fam_launches = sum(k["launches"] for k in conv_kernels.values())
         fam_flops = sum(k["flops"] for k in conv_kernels.values())
         fam_ach = fam_flops / (fam_ms * 1e-3) / 1e12
-        roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": dom["frac"], "traffic": dom["traffic"], "hbm_gbps": dom.get("hbm_gbps"), "hbm_frac": dom.get("hbm_frac"),
-                    "mfma_util_pmc": dom.get("mfma_util_pmc"), "launches_per_step": dom["launches_per_step"],
-                    "avg_launch_ms": dom["avg_launch_ms"], "flop_per_launch_avg": dom["flop_per_launch_avg"],
-                    "share_of_forward": dom["ms_per_step"] / sum(v["total_ms"] / prof_steps for v in prof.values()),
-                    # every MFMA kernel of the forward pass together (what `value` is made of)
-                    "conv_family": {"achieved": fam_ach, "frac": fam_ach / peak, "launches_per_step": fam_launches / prof_steps,
-                                    "avg_launch_ms": fam_ms / fam_launches, "flop_per_launch_avg": fam_flops / fam_launches,
-                                    "traffic": (tj["hbm_bytes_per_launch_avg"] * args.batch / tj["batch"]) if tj else None},
-                    "kernels": lines,
-                    "class_ms_per_step": {k: v["total_ms"] / prof_steps for k, v in prof.items()}}
+        prov = {}
+        if tprov:
+            prov["traffic, hbm_gbps, hbm_frac"] = tprov
+        if uprov:
+            prov["mfma_util_pmc"] = uprov
+        return {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
+                "traffic": dom["traffic"], "hbm_gbps": dom.get("hbm_gbps"), "hbm_frac": dom.get("hbm_frac"), "mfma_util_pmc": dom.get("mfma_util_pmc"),
+                "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"], "flop_per_launch_avg": dom["flop_per_launch_avg"],
+                "share_of_forward": dom["ms_per_step"] / sum(v["total_ms"] / prof_steps for v in prof.values()),
+                "timing": f"HIP events on the launch stream, {prof_steps} single-stream forwards of this run",
+                # every MFMA kernel of the forward pass together (what `value` is made of)
+                "conv_family": {"achieved": fam_ach, "frac": fam_ach / peak, "launches_per_step": fam_launches / prof_steps,
+                                "avg_launch_ms": fam_ms / fam_launches, "flop_per_launch_avg": fam_flops / fam_launches,
+                                "traffic": tj["hbm_bytes_per_launch_avg"] if tj else None},
+                "kernels": lines, "class_ms_per_step": {k: v["total_ms"] / prof_steps for k, v in prof.items()},
+                "provenance": prov or None}
 
-    frames_done = args.steps * args.batch * world
+    head = measure(args.dtype, args.lanes, args.repeats, not args.no_profile)
+
     out = {
         "metric": f"frames/sec YOLOv8s+ResMLP sim loop @{args.size}x{args.size}",
-        "value": frames_done / dt,
+        "value": head["value"],
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -236,17 +296,37 @@ def main():
         "config": {"workload": ("BASELINE configs[2]" if args.size == 640 else f"BASELINE configs[4] per-GPU shape ({args.size}x{args.size})")
                                + ": full sim loop, YOLOv8s (nc=1, seeded synthetic weights) + ResMLP(imaging-100ms_pred-40ms_moving-50ms, reference weights)",
                    "frame": f"{args.size}x{args.size} uint8 gray, resident in HBM", "batch_per_gpu": args.batch, "lanes_per_gpu": args.lanes,
-                   "global_batch": args.batch * world, "timing_ms": [100, 40, 50], "conf": 0.1,
+                   "global_batch": args.batch * world, "timing_ms": [100, 40, 50], "conf": args.conf,
                    "parallelism": f"frame-sharded x{world}, one RCCL all-gather of [B,4] tracks per step" if world > 1 else "single GPU"},
-        "roofline": roofline,
+        "windows": head["windows"],
+        "roofline": head.get("roofline"),
     }
-    if rank == 0 and world == 1 and args.cpu_frames > 0:  # the CPU baseline is reported at N=1 only
-        out["cpu_baseline"] = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, args.cpu_frames, args.batch, golden)
+
+    if world == 1:
+        # ---- the reference's precision, same workload, same command (fewer windows: a window is 6x longer)
+        if args.dtype == "fp16" and not args.no_fp32:
+            f32 = measure("fp32", args.lanes, max(min(args.repeats, 3), 1), not args.no_profile)
+            out["fp32"] = {k: f32[k] for k in ("dtype", "value", "unit", "ms_per_step", "windows")}
+            out["fp32"]["roofline"] = f32.get("roofline")
+            out["fp32"]["note"] = "reference precision (ultralytics half: False): exact-fp32 v_mfma_f32_16x16x4_f32 through the same kernels"
+        # ---- CPU baseline (oracle, kind 'port') + parity of both modes against it on the same frames, outside any timed region
+        if args.cpu_frames > 0:
+            n = max(args.cpu_frames // 64, 1) * 64
+            sample = fr.diverse_frames(n, args.size, seed=2000)
+            out["cpu_baseline"], (xo, co, ao) = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, golden, sample, args.conf)
+            par = {"checker": "oracle/yolo_oracle.py (fp32 torch-CPU restatement; parity unpinned: no ultralytics, no trained weights)",
+                   "frames": f"{n} synthetic {args.size}x{args.size} frames from {n // 4} seeded tracks, conf {args.conf}",
+                   "floors_asserted_in_tests": "tests/test_gpu_configs.py: fp16 index match >= 0.93, matched IoU min >= 0.99 (256 frames); fp32 index match == 1"}
+            for dtype in ("fp16", "fp32"):
+                det = hip.HipYolo(weights, (args.size, args.size), 64, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=local_rank)
+                res = [det.predict_host(sample[i : i + 64], conf=args.conf) for i in range(0, n, 64)]
+                det.close()
+                xg, cg, ag = (np.concatenate([r[k] for r in res]) for k in range(3))
+                par[dtype] = metrics.accuracy_report(xg, ag, xo, ao, cg, co)
+            out["parity"] = par
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
-
         dist.barrier()
         dist.destroy_process_group()
 

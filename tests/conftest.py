@@ -14,6 +14,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """test_a_gpu_two_ranks.py starts rank processes and must do so before this process has touched the GPU: keep it first."""
+    items.sort(key=lambda it: 0 if "test_a_gpu_two_ranks" in it.nodeid else 1)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

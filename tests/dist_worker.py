@@ -1,0 +1,75 @@
+"""Rank process of tests/test_a_gpu_two_ranks.py (not a test module): runs wtracker_amd.pipeline.TrackPipeline as one of
+WORLD_SIZE ranks over `--backend` (gloo: every rank shares cuda:0 on a one-GPU box; nccl: one GPU per rank) and writes its
+view of the run (track, moves, valid) to --out.  Launched as a fresh child before anything in the parent touches the GPU."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16"):
+    """Shared by the rank processes and by the single-rank comparison run in the test."""
+    import torch
+
+    from wtracker_amd import hip, resmlp
+    from wtracker_amd import yolo_spec as ys
+    from wtracker_amd.pipeline import TrackPipeline
+
+    folded = resmlp.load_npz(os.path.join(ROOT, "tests", "golden", "resmlp_100ms.npz"))
+    w = ys.synthetic_weights(scale, 1, seed=0)
+    depth, width, maxch = ys.SCALES[scale]
+    dets = [hip.HipYolo(w, (size, size), batch, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch, device=device.index or 0)
+            for _ in range(lanes)]
+    mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=device.index or 0)
+    total = steps * batch * world
+    pipe = TrackPipeline(dets, mlp, folded, batch, total, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9, conf=0.1,
+                         rank=rank, world=world, group=group, device=device)
+    frames = torch.from_numpy(frames_np).to(device)
+    for s in range(steps):
+        f0, f1 = pipe.plan.local_range(s, rank)
+        pipe.step(s, frames[f0:f1])
+    pipe.synchronize()
+    torch.cuda.synchronize(device)
+    out = dict(track=pipe.track.cpu().numpy(), moves=pipe.moves.cpu().numpy(), valid=pipe.valid.cpu().numpy())
+    for d in dets:
+        d.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--backend", default="gloo")
+    args = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from wtracker_amd import frames as fr
+
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    dev = torch.device("cuda", local if args.backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    frames_np, _ = fr.synthetic_frames(args.steps * args.batch * world, 128, seed=4)
+    out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes)
+    np.savez(args.out, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""GPU: the multi-rank branch of wtracker_amd.pipeline.TrackPipeline as a driver-run test.
+
+Two rank processes (gloo rendezvous on 127.0.0.1, both on cuda:0 — a one-GPU box cannot run RCCL between two devices) run
+the REAL pipeline: detector on each rank's interleaved share, `all_gather_into_tensor` of the [B,4] slices into the
+device-resident track from two lane streams, ResMLP over the cycles that became computable.  Every rank must end with the
+track, validity flags and moves of a single-rank run over the same frames.
+
+The children are started as fresh processes BEFORE this process has touched the GPU (conftest.py moves this module to
+the front of the collection, and the test checks that nothing initialised HIP yet); the comparison run follows."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
+    import torch
+
+    assert not torch.cuda.is_initialized(), "this test must run before anything touches the GPU in this process"
+    world, B, steps = 2, 32, 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--out", str(tmp_path / f"rank{r}.npz"),
+               "--batch", str(B), "--steps", str(steps), "--lanes", "2", "--backend", "gloo"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+
+    # single-rank run of the same 2*B*steps frames in this process (first GPU use of the parent)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import run_pipeline
+    from wtracker_amd import frames as fr
+
+    frames_np, _ = fr.synthetic_frames(steps * B * world, 128, seed=4)
+    one = run_pipeline(frames_np, B * world, steps, 0, 1, None, torch.device("cuda", 0), lanes=1)
+    assert np.isfinite(one["track"]).any() and one["valid"].sum() >= 10
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_array_equal(z["track"], one["track"])  # NaN rows compare equal position-wise
+        np.testing.assert_array_equal(z["valid"], one["valid"])
+        np.testing.assert_array_equal(z["moves"], one["moves"])

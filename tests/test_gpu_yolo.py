@@ -61,6 +61,37 @@ def test_fp32_head_logits_and_boxes_match_oracle(hip_lib, scale, size, B):
     np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
 
 
+def _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, net_hw, hw, conf):
+    """fp16 mode against the fp32 oracle, with NO escape for frames whose survivor differs: (1) the selection the
+    GPU made from ITS OWN logits is bit-exact in index vs the oracle's selection logic on those logits; (2) every
+    frame whose survivor differs from the fp32 oracle's is counted, and must be explained by the measured logit
+    error eps = max|cls_gpu - cls_oracle|: an arg-max under a perturbation of at most eps can only move to an
+    anchor whose oracle logit lies within 2 eps of the oracle's best; (3) matched survivors have IoU > F16_IOU_MIN.
+    Returns the number of mismatching frames (the rate itself is asserted at BASELINE scale in test_gpu_configs.py)."""
+    cls_o_np, box_o_np = cls_o.numpy(), box_o.numpy()
+    eps = float(np.abs(cls_g - cls_o_np).max())
+    assert eps < F16_LOGIT_ATOL and np.abs(box_g - box_o_np).max() < F16_LOGIT_ATOL
+    xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), net_hw, hw, conf=conf)
+    np.testing.assert_array_equal(anchor, anchor_s)
+    np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=2e-2)
+    xywh_o, _, anchor_o = yo.postprocess(box_o, cls_o, net_hw, hw, conf=conf)
+    thr = float(np.log(conf / (1 - conf)))
+    best_o = cls_o_np.max(axis=2)  # [B,A]
+    mismatches = 0
+    for n in range(len(anchor)):
+        if anchor[n] == anchor_o[n]:
+            if anchor[n] >= 0:
+                assert _iou_xywh(xywh[n], xywh_o[n]) > F16_IOU_MIN
+            continue
+        mismatches += 1
+        top = best_o[n].max()
+        if anchor[n] >= 0 and anchor_o[n] >= 0:
+            assert top - best_o[n, anchor[n]] <= 2 * eps, (n, anchor[n], anchor_o[n], top - best_o[n, anchor[n]], eps)
+        else:  # a NaN row on one side only: the oracle's best score sits within eps of the threshold
+            assert abs(top - thr) <= eps + 1e-6, (n, top, thr, eps)
+    return mismatches
+
+
 @pytest.mark.parametrize("scale,size,B", [("s", 128, 2), ("s", 256, 3), ("n", 128, 3), ("n", 160, 2)])
 def test_fp16_matches_oracle_within_stated_tolerance(hip_lib, scale, size, B):
     oracle, det = _models(scale, size, "fp16")
@@ -68,17 +99,7 @@ def test_fp16_matches_oracle_within_stated_tolerance(hip_lib, scale, size, B):
     box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
     xywh, conf, anchor = det.predict_host(frames, conf=0.1)
     box_g, cls_g = det.debug_head(B)
-    assert np.abs(cls_g - cls_o.numpy()).max() < F16_LOGIT_ATOL
-    assert np.abs(box_g - box_o.numpy()).max() < F16_LOGIT_ATOL
-    # selection computed by the GPU from ITS OWN logits must equal the oracle's selection logic applied
-    # to the same logits (bit-exact index), and be close to the fp32 oracle's boxes
-    xywh_s, conf_s, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (size, size), hw, conf=0.1)
-    np.testing.assert_array_equal(anchor, anchor_s)
-    np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=2e-2)
-    xywh_o, _, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.1)
-    for n in range(B):
-        if anchor[n] == anchor_o[n] and anchor[n] >= 0:
-            assert _iou_xywh(xywh[n], xywh_o[n]) > F16_IOU_MIN
+    _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, (size, size), hw, 0.1)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
@@ -174,9 +195,7 @@ def test_full_size_640_matches_oracle(hip_lib, dtype, B):
         np.testing.assert_array_equal(anchor, anchor_o)
         np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=F32_BOX_ATOL)
     else:
-        assert err < F16_LOGIT_ATOL
-        xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (size, size), hw, conf=0.1)
-        np.testing.assert_array_equal(anchor, anchor_s)
+        _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, (size, size), hw, 0.1)
 
 
 def test_letterbox_360_to_384_like_the_reference_workflow(hip_lib):

@@ -29,6 +29,18 @@ def needs_build() -> bool:
     return False
 
 
+def source_sha() -> str:
+    """sha256[:16] over the kernel sources of libwtk_hip.so: the key that ties a committed rocprofv3 artefact under profiles/
+    to the build it was collected on (bench.py only quotes such a file when the key matches)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP translation unit for gfx950 and link libwtk_hip.so next to the package."""
     if not force and not needs_build():

@@ -222,8 +222,6 @@ template <bool NT> __global__ __launch_bounds__(256, 2) void conv1x1_wide_kernel
     }
 }
 
-int g_wide_cus = 0;
-
 } // namespace
 
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16) {
@@ -240,13 +238,9 @@ hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream) {
     if (tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     a.ptiles = (int)ptiles;
     a.d_nct = make_fastdiv((unsigned)(a.CoutPad / kBN));
-    if (g_wide_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        g_wide_cus = prop.multiProcessorCount;
-    }
-    const long long resident = 2LL * g_wide_cus; // 72 KB of LDS per block
+    const int cus = current_device_cus();
+    if (cus <= 0) return hipErrorUnknown;
+    const long long resident = 2LL * cus; // 72 KB of LDS per block
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     if (a.CoutPad == kBN)
         hipLaunchKernelGGL((conv1x1_wide_kernel<true>), dim3(grid), dim3(256), 0, stream, a);

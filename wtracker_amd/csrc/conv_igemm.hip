@@ -600,8 +600,6 @@ int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : ((cfg == CFG_256x64
 
 hipError_t conv_init_attributes() { return hipSuccess; } // LDS is static: nothing to raise
 
-static int g_num_cus = 0;
-
 template <typename T, int BM, int BN, int WAVES_P, int WAVES_C>
 static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     long long ptiles;
@@ -619,12 +617,8 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     a.d_tilesx = make_fastdiv((unsigned)(a.tiles_x > 0 ? a.tiles_x : 1));
     a.d_tpi = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y > 0 ? a.tiles_x * a.tiles_y : 1));
     a.d_nct = make_fastdiv((unsigned)(a.CoutPad / BN));
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        g_num_cus = prop.multiProcessorCount;
-    }
+    const int g_num_cus = current_device_cus();
+    if (g_num_cus <= 0) return hipErrorUnknown;
     constexpr int NW = WAVES_P * WAVES_C;
     const long long per_cu = NW == 8 ? 1 : ((2 * (BM + BN) * 128 <= 52 * 1024) ? 3 : 2); // LDS-limited residency
     const long long resident = per_cu * g_num_cus;

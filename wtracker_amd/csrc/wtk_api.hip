@@ -42,14 +42,37 @@ extern "C" int wtk_device_count(void) {
     return n;
 }
 
-static bool g_attr_done = false;
-static int ensure_attributes() {
-    if (g_attr_done) return 0;
+// Kernel attributes (dynamic LDS above 64 KiB) are per device: initialise them once for every device a handle is created on.
+static unsigned long long g_attr_done = 0; // bit d = device d initialised
+static int ensure_attributes(int device) {
+    if (device < 0 || device >= 64) return fail("device id out of range");
+    if (g_attr_done & (1ull << device)) return 0;
     HIP_TRY(conv_init_attributes());
     HIP_TRY(pool_init_attributes());
-    g_attr_done = true;
+    g_attr_done |= 1ull << device;
     return 0;
 }
+
+// Stream entry points launch on the handle's device whatever the caller's current device is, and leave the caller's
+// current device as they found it (PyTorch tracks the same thread-local HIP state).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define DEVICE_GUARD(h)                                                                                                        \
+    DeviceGuard _guard((h)->device);                                                                                           \
+    if (_guard.err != hipSuccess) return fail_hip("selecting the handle's device", _guard.err)
 
 static uint16_t f32_to_f16_bits(float f) {
     _Float16 h = (_Float16)f; // round-to-nearest-even, host compiler builtin
@@ -155,6 +178,7 @@ extern "C" int wtk_mlp_forward(wtk_mlp *h, const float *x_dev, int32_t batch, fl
     if (!h || !x_dev || !y_dev) return fail("wtk_mlp_forward: null argument");
     if (batch < 0) return fail("wtk_mlp_forward: negative batch");
     if (batch == 0) return 0;
+    DEVICE_GUARD(h);
     MlpArgs a = mlp_base_args(h);
     a.x = x_dev;
     a.y = y_dev;
@@ -190,6 +214,7 @@ extern "C" int wtk_mlp_predict_track(wtk_mlp *h, const float *track_dev, int32_t
     if (n_in <= 0 || n_in > kMlpMaxInputFrames || n_in * 4 != h->in_dim) return fail("wtk_mlp_predict_track: n_in*4 must equal the model's input dim");
     if (n_samples < 0 || n_frames < 0) return fail("wtk_mlp_predict_track: negative size");
     if (n_samples == 0) return 0;
+    DEVICE_GUARD(h);
     MlpArgs a = mlp_base_args(h);
     a.x = nullptr;
     a.track = track_dev;
@@ -615,7 +640,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         if (dims.c[i] % 16 != 0) return fail("wtk_yolo_create: channel widths must be multiples of 16 for this build");
     if (dims.hb % 16 || dims.hc % 16) return fail("wtk_yolo_create: head widths must be multiples of 16");
     HIP_TRY(hipSetDevice(d->device));
-    if (ensure_attributes()) return 1;
+    if (ensure_attributes(d->device)) return 1;
 
     wtk_yolo *h = new wtk_yolo();
     h->device = d->device;
@@ -1188,6 +1213,7 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     if (C != 1 && C != 3) return fail("wtk_yolo_predict: frames must have 1 (gray) or 3 (BGR) channels");
     if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
     if (H <= 0 || W <= 0) return fail("wtk_yolo_predict: bad frame size");
+    DEVICE_GUARD(h);
     hipStream_t st = (hipStream_t)stream;
     if ((H != h->S_h || W != h->S_w) && h->lb_cap == 0) { // letterbox staging image, allocated once
         HIP_TRY(hipStreamSynchronize(st));

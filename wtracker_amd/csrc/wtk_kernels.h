@@ -29,6 +29,19 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+// CU count of the CURRENT HIP device, cached per device id (a process may hold handles on several GPUs).
+inline int current_device_cus() {
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cache[dev] = prop.multiProcessorCount;
+    }
+    return cache[dev];
+}
+
 // Pins an fp32 value in a VGPR (no instruction).  hipcc folds "(half)(a * b)" into v_fma_mixlo_f16, which rounds the exact
 // product ONCE to fp16, whenever the conversion is not paired into a v_cvt_pk_f16_f32 — which depends on the surrounding
 // code.  Every SiLU of the library pins its product so that all kernels (stand-alone and fused) round product -> fp32 -> fp16

@@ -62,3 +62,15 @@ def synthetic_frames(num_frames: int, size: int = 640, seed: int = 0, colored: b
     if colored:
         frames = np.repeat(frames[..., None], 3, axis=3)
     return frames, track
+
+
+def diverse_frames(num_frames: int, size: int = 640, seed: int = 1000, per_seed: int = 4) -> np.ndarray:
+    """`num_frames` frames drawn from many tracks (`per_seed` consecutive frames per seed): consecutive frames of ONE
+    synthetic track differ by half a pixel of worm motion only, which makes a poor sample for accuracy statistics."""
+    out, n, s = [], 0, seed
+    while n < num_frames:
+        f, _ = synthetic_frames(min(per_seed, num_frames - n), size, seed=s)
+        out.append(f)
+        n += len(f)
+        s += 1
+    return np.concatenate(out)

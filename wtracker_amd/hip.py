@@ -158,7 +158,11 @@ class HipMLP:
             load().wtk_mlp_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals (load, _lib) may already be gone
+            self.close()
+        except Exception:
+            pass
 
     def forward_host(self, x: np.ndarray) -> np.ndarray:
         """x: [B, in_dim] float32 (host) -> [B, out_dim] float32 (host)."""
@@ -241,7 +245,11 @@ class HipYolo:
             load().wtk_yolo_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals (load, _lib) may already be gone
+            self.close()
+        except Exception:
+            pass
 
     def predict_host(self, frames: np.ndarray, conf: float = 0.1, iou: float = 0.7, max_det: int = 1):
         """frames: uint8 [B,H,W] or [B,H,W,C] (host).  Returns (xywh [B,4] f32 with NaN rows, conf [B], anchor [B])."""

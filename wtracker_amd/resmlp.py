@@ -14,6 +14,8 @@ from typing import Mapping, Sequence
 
 import numpy as np
 
+from .hip import WtkError
+
 BN_EPS = 1e-5  # torch.nn.BatchNorm1d default, used by MLPLayer (mlp.py:70)
 
 
@@ -40,9 +42,11 @@ class FoldedResMLP:
         return int(sum(w.shape[0] * w.shape[1] for w, _, _ in self.layers))
 
 
-def _fold(prefix: str, sd: Mapping[str, np.ndarray]):
-    """Linear at `prefix.0`, optional BatchNorm1d at `prefix.1` (present iff the layer has a nonlinearity,
-    mlp.py:69-70) -> (W', b', relu) in float64 arithmetic, cast to float32."""
+def _fold(prefix: str, sd: Mapping[str, np.ndarray], activation: str | None = None):
+    """Linear at `prefix.0`, optional BatchNorm1d at `prefix.1` -> (W', b', relu) in float64 arithmetic, cast to
+    float32.  `activation` ('relu' / 'none') is the layer's nonlinearity when the caller knows it (from_torch_module
+    reads it off the live module); None = infer it from the state dict: MLPLayer adds a BatchNorm1d exactly when it has a
+    nonlinearity and batch_norm=True (mlp.py:69-70), which is how both shipped models and the fixtures are built."""
     w = np.asarray(sd[prefix + ".0.weight"], dtype=np.float64)
     b = np.asarray(sd[prefix + ".0.bias"], dtype=np.float64)
     has_bn = (prefix + ".1.running_mean") in sd
@@ -54,22 +58,29 @@ def _fold(prefix: str, sd: Mapping[str, np.ndarray]):
         s = g / np.sqrt(var + BN_EPS)
         w = w * s[:, None]
         b = (b - mu) * s + beta
-    # both shipped models use ReLU after every MLPLayer; a layer without BN has no
-    # nonlinearity by construction (mlp.py:69)
-    return w.astype(np.float32), b.astype(np.float32), bool(has_bn)
+    if activation is None:
+        relu = bool(has_bn)  # state dict only: BN present <=> ReLU layer of the shipped models
+    elif activation in ("relu", "none"):
+        relu = activation == "relu"
+    else:
+        raise WtkError(f"ResMLP layer {prefix}: activation {activation!r} is not supported by mlp_kernel (ReLU or none only)")
+    return w.astype(np.float32), b.astype(np.float32), relu
 
 
-def fold_state_dict(sd: Mapping[str, np.ndarray], input_frames: Sequence[int], pred_frames: Sequence[int]) -> FoldedResMLP:
+def fold_state_dict(sd: Mapping[str, np.ndarray], input_frames: Sequence[int], pred_frames: Sequence[int],
+                    activations: Sequence[str] | None = None) -> FoldedResMLP:
+    """`activations`: one entry ('relu' / 'none') per MLPLayer in execution order (input, block0.l0, ...); None infers
+    ReLU from the presence of a BatchNorm (see _fold)."""
     sd = {k[4:] if k.startswith("sd::") else k: v for k, v in sd.items()}
     blocks = sorted({int(m.group(1)) for k in sd for m in [re.match(r"model\.blocks\.(\d+)\.", k)] if m})
     n_blocks = len(blocks)
     per_block = 0
     if n_blocks:
         per_block = len({int(m.group(1)) for k in sd for m in [re.match(r"model\.blocks\.0\.sequence\.(\d+)\.", k)] if m})
-    layers = [_fold("model.input.mlp_layer", sd)]
-    for b in range(n_blocks):
-        for l in range(per_block):
-            layers.append(_fold(f"model.blocks.{b}.sequence.{l}.mlp_layer", sd))
+    prefixes = ["model.input.mlp_layer"] + [f"model.blocks.{b}.sequence.{l}.mlp_layer" for b in range(n_blocks) for l in range(per_block)]
+    if activations is not None and len(activations) != len(prefixes):
+        raise WtkError(f"ResMLP: {len(activations)} activations given for {len(prefixes)} layers")
+    layers = [_fold(p, sd, None if activations is None else activations[i]) for i, p in enumerate(prefixes)]
     w = np.asarray(sd["model.output.weight"], dtype=np.float32)
     bo = np.asarray(sd["model.output.bias"], dtype=np.float32)
     layers.append((w, bo, False))
@@ -87,7 +98,18 @@ def from_torch_module(model) -> FoldedResMLP:
     """From a live `WormPredictor` (what simulate.ipynb cell 9 passes to MLPController): uses only
     `state_dict()` and `io_config.{input_frames,pred_frames}`."""
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    return fold_state_dict(sd, list(model.io_config.input_frames), list(model.io_config.pred_frames))
+    # the nonlinearity is not in the state dict: read it off every MLPLayer (`mlp_layer` = Sequential(Linear, [BN], act),
+    # mlp.py:67-73).  Anything but ReLU / Identity would be computed wrongly by the device kernel -> refuse it.
+    acts = []
+    for name, mod in model.named_modules():
+        seq = getattr(mod, "mlp_layer", None)
+        if seq is None:
+            continue
+        kind = type(list(seq.children())[-1]).__name__
+        if kind not in ("ReLU", "Identity"):
+            raise WtkError(f"ResMLP layer {name}: activation {kind} is not supported by mlp_kernel (ReLU or none only)")
+        acts.append("relu" if kind == "ReLU" else "none")
+    return fold_state_dict(sd, list(model.io_config.input_frames), list(model.io_config.pred_frames), acts or None)
 
 
 def make_training_pairs(log_path: str, input_frames: Sequence[int], pred_frames: Sequence[int]):
