@@ -183,6 +183,21 @@ int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, i
                    const int32_t *pos_xy_dev, int32_t view_w, int32_t view_h, uint8_t *views_dev,
                    void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Detector on camera views of device-resident full frames: view cropping fused with the letterbox in front of
+ * the detector, so the per-frame host crop + upload of the reference's loop disappears.
+ * Replaces: YoloController.on_camera_frame -> sim.camera_view()   yolo_controller.py:58-59
+ *           ViewController.read (copyMakeBorder REPLICATE) + _custom_view   view_controller.py:45-61,143-172
+ *           + the LetterBox resize inside YOLO.predict                    yolo_controller.py:72-78
+ * frames [n_frames][H][W][C] uint8 (DEVICE); batch row n is the w x h view of frame frame_index[n] (NULL: frame n)
+ * centred on platform position pos_xy[n] = (x, y) — rows = w, cols = h as the reference slices.  Outputs as
+ * wtk_yolo_predict, boxes in VIEW pixel coordinates (what predict() on the cropped frames returns).
+ * ------------------------------------------------------------------------------------------ */
+int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t C,
+                           const int32_t *frame_index_dev, const int32_t *pos_xy_dev, int32_t B,
+                           int32_t view_w, int32_t view_h, float conf, float iou, int32_t max_det,
+                           float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ from collections import deque
 
 import numpy as np
 
-from oracle import resmlp_oracle, yolo_oracle
+from oracle import resmlp_oracle, view_oracle, yolo_oracle
 from wtracker_amd.controllers import CsvController
 from wtracker_amd.sim import SimController
 
@@ -41,7 +41,11 @@ class OracleYoloController(SimController):
         self._camera_frames.clear()
 
     def on_camera_frame(self, sim):
-        self._camera_frames.append(sim.camera_view())
+        # the view is cut by oracle/view_oracle.py from the raw frame, NOT by the product harness' ViewController:
+        # an error in either statement of the slicing shows up as a difference in the closed-loop tests
+        v = sim.view
+        frame = v._frame_reader[v.index]
+        self._camera_frames.append(view_oracle.camera_view(frame, tuple(int(p) for p in v.position), v.camera_size))
 
     def on_cycle_end(self, sim):
         self._camera_frames.clear()

@@ -92,6 +92,31 @@ class YoloOracle:
         return torch.cat(boxes, 1).contiguous(), torch.cat(clss, 1).contiguous()
 
 
+class UnfusedYoloOracle(YoloOracle):
+    """The same graph on an UN-FUSED ultralytics-style state dict (what a real `yolov8s_trained.pt` holds): every `Conv` is
+    Conv2d(no bias) -> BatchNorm2d(eps 1e-3, running statistics) -> SiLU, the six Detect output convs are plain Conv2d with
+    bias.  Checks tools/convert_ultralytics.py end to end: nothing here folds anything."""
+
+    BN_EPS = 1e-3  # ultralytics Conv: nn.BatchNorm2d(c2, eps=0.001, momentum=0.03)
+
+    def __init__(self, state_dict: dict, dims: dict):
+        self.sd = {k: torch.as_tensor(np.asarray(v)).float() for k, v in state_dict.items()}
+        self.dims = dims
+
+    def conv(self, name, x, stride=1, act=True):
+        sd = self.sd
+        if name + ".conv.weight" in sd:
+            w = sd[name + ".conv.weight"]
+            y = F.conv2d(x, w, None, stride=stride, padding=w.shape[2] // 2)
+            y = F.batch_norm(y, sd[name + ".bn.running_mean"], sd[name + ".bn.running_var"], sd[name + ".bn.weight"], sd[name + ".bn.bias"],
+                             training=False, eps=self.BN_EPS)
+            assert act
+            return F.silu(y)
+        w = sd[name + ".weight"]
+        assert not act
+        return F.conv2d(x, w, sd[name + ".bias"], stride=stride, padding=w.shape[2] // 2)
+
+
 # ---- pre / post processing ----------------------------------------------------------------------
 def letterbox_geometry(h: int, w: int, imgsz: int, stride: int = 32):
     """ultralytics LetterBox(auto=True, center=True): (net_h, net_w, new_h, new_w, top, left)."""

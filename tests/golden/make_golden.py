@@ -19,6 +19,13 @@ Outputs
   sim_csv_bboxes.csv                    reference LoggingController(CsvController) log
   sim_moves.json                        per-cycle (dx, dy) returned by provide_movement_vector
   timing.json                           TimingConfig numbers for several (imaging, pred, moving) triples
+Round 2 (`--r2`: writes ONLY these, the fixtures above stay byte-identical):
+  bbox_utils.npz                        BoxUtils.discretize / center / round and BoxConverter.to_xywh / to_xyxy of the real
+                                        reference (wtracker/utils/bbox_utils.py:76-167,232-260) on seeded boxes with NaN rows,
+                                        negative corners, boxes hanging over the bounds and empty boxes
+  polyfit_cases.json                    per-cycle (dx, dy) of the reference PolyfitController for several PolyfitConfigs,
+                                        among them UNSORTED sample_times with non-uniform weights (polyfit_controller.py:28
+                                        sorts the times, not the weights), and the weights / sample_times the config ends up with
 """
 import hashlib
 import json
@@ -233,5 +240,80 @@ def main():
         print(k, "cycles", len(v), "last", v[-1])
 
 
+def main_r2():
+    """Round-2 fixtures: numeric outputs of the real reference only (see the module docstring)."""
+    _register_placeholders()
+    sys.path.insert(0, REF)
+    from wtracker.sim.config import ExperimentConfig, TimingConfig
+    from wtracker.sim.sim_controllers.logging_controller import LogConfig, LoggingController
+    from wtracker.sim.sim_controllers.polyfit_controller import PolyfitConfig, PolyfitController
+    from wtracker.sim.simulator import Simulator
+    from wtracker.utils.bbox_utils import BoxConverter, BoxFormat, BoxUtils
+
+    # ---- bbox utilities
+    rng = np.random.default_rng(77)
+    n = 64
+    xywh = np.stack([rng.uniform(-30, 1420, n), rng.uniform(-30, 1620, n), rng.uniform(0.0, 40, n), rng.uniform(0.0, 40, n)], axis=1)
+    xywh[3] = np.nan
+    xywh[9, 2] = np.nan
+    xywh[12] = [-5.0, -5.0, 3.0, 3.0]            # entirely outside (negative side)
+    xywh[13] = [1395.5, 1590.0, 20.0, 20.0]      # hangs over both bounds
+    xywh[14] = [10.0, 10.0, 0.0, 5.0]            # zero width
+    xywh[15] = [1400.0, 20.0, 5.0, 5.0]          # starts exactly at the bound
+    xywh[16] = [10.2, 5.7, 3.1, 4.0]
+    xywh[17] = [7.0, 8.0, 2.0, 2.0]              # integer box: floor / ceil leave it alone
+    bounds = (1600, 1400)
+    d_in = xywh.copy()
+    disc, legal = BoxUtils.discretize(d_in, bounds, BoxFormat.XYWH)  # zeroes NaN rows of d_in in place (bbox_utils.py:139-140)
+    xyxy = BoxConverter.to_xyxy(xywh.copy(), BoxFormat.XYWH)
+    yolo = BoxConverter.to_yolo(xywh.copy(), BoxFormat.XYWH)
+    np.savez(os.path.join(HERE, "bbox_utils.npz"), xywh=xywh, bounds=np.asarray(bounds), disc=disc, legal=legal, disc_input_after=d_in,
+             xyxy=xyxy, yolo=yolo, xywh_from_xyxy=BoxConverter.to_xywh(xyxy.copy(), BoxFormat.XYXY),
+             xywh_from_yolo=BoxConverter.to_xywh(yolo.copy(), BoxFormat.YOLO), center=BoxUtils.center(xywh.copy()),
+             round_xywh=BoxUtils.round(np.nan_to_num(xywh.copy(), nan=1.5), BoxFormat.XYWH),
+             disc_f32=BoxUtils.discretize(xywh.astype(np.float32), bounds, BoxFormat.XYWH)[0])
+    print("bbox_utils", disc.dtype, int(legal.sum()), "legal of", n)
+
+    # ---- PolyfitController with unsorted times / non-uniform weights
+    exp_cfg_json = json.load(open(os.path.join(REF, "experiments/exp0/exp_config.json")))
+    init_csv = os.path.join(HERE, "sim_init_bboxes.csv")
+    cases = {
+        "unsorted_weighted": dict(degree=2, sample_times=[2, -9, 0, -3, 4, -6], weights=[1, 1, 2, 3, 4, 5]),
+        "unsorted_default_weights": dict(degree=1, sample_times=[4, 0, -6], weights=None),
+        "sorted_cubic": dict(degree=3, sample_times=[-12, -9, -6, -3, 0, 2, 4, 5], weights=[0.5, 1, 1, 2, 3, 4, 5, 8]),
+    }
+    out = {}
+    for name, kw in cases.items():
+        ec = ExperimentConfig(name="exp0", num_frames=200, frames_per_sec=exp_cfg_json["frames_per_sec"],
+                              orig_resolution=tuple(exp_cfg_json["orig_resolution"]), px_per_mm=exp_cfg_json["px_per_mm"],
+                              init_position=tuple(exp_cfg_json["init_position"]))
+        tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.32, 0.32))
+        cfg = PolyfitConfig(**kw)
+        ctrl = PolyfitController(tc, cfg, init_csv)
+        rec = []
+        orig = ctrl.provide_movement_vector
+
+        def wrapped(sim, orig=orig, rec=rec):
+            dx, dy = orig(sim)
+            rec.append([int(sim.frame_number), int(dx), int(dy)])
+            return dx, dy
+
+        ctrl.provide_movement_vector = wrapped
+        tmp = tempfile.mkdtemp(prefix="wtk_golden_")
+        try:
+            lc = LogConfig(root_folder=tmp, save_mic_view=False, save_cam_view=False, save_err_view=False, save_wrm_view=False)
+            Simulator(tc, ec, LoggingController(ctrl, lc)).run()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        out[name] = dict(config=dict(degree=kw["degree"], sample_times=kw["sample_times"], weights=kw["weights"]),
+                         sample_times_after=[int(t) for t in cfg.sample_times], weights_after=[float(w) for w in cfg.weights], moves=rec)
+        print(name, "cycles", len(rec), "last", rec[-1])
+    json.dump(out, open(os.path.join(HERE, "polyfit_cases.json"), "w"))
+
+
 if __name__ == "__main__":
-    main()
+    if "--r2" in sys.argv:
+        main_r2()
+    else:
+        main()
+        main_r2()

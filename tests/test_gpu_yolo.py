@@ -252,6 +252,24 @@ def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib,
     m_g, rows_g = run(lambda tc: HipYoloController(tc, cfg))
     m_o, rows_o = run(lambda tc: OracleYoloController(tc, oracle, imgsz=128, conf=0.1))
     assert m_g == m_o and len(m_g) == 4 and any(m != (0, 0) for m in m_g)
+    # device-resident frames: no sim.camera_view() on the hot path, views cut + letterboxed on the device;
+    # identical pixels reach the detector, so moves and logged rows are bit-identical to the host-crop controller's
+    dev_frames = torch.from_numpy(frames).cuda()
+    calls = []
+
+    def make_resident(tc):
+        c = HipYoloController(tc, cfg, device_frames=dev_frames)
+        return c
+
+    import wtracker_amd.sim as simmod
+    orig_view = simmod.Simulator.camera_view
+    simmod.Simulator.camera_view = lambda self: calls.append(1) or orig_view(self)
+    try:
+        m_d, rows_d = run(make_resident)
+    finally:
+        simmod.Simulator.camera_view = orig_view
+    assert not calls, "the device-resident controller must never ask the simulator for a host crop"
+    assert m_d == m_g and rows_d == rows_g
     assert len(rows_g) == len(rows_o) == 36  # 4 full cycles; the trailing partial cycle is never logged
     for a, b in zip(rows_g, rows_o):
         assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
@@ -300,6 +318,116 @@ def test_device_view_cropping_matches_view_controller(hip_lib):
     hip.crop_views(torch.from_numpy(fc).cuda(), 6, 90, 120, 3, p_dev, 9, 9, out)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), np.stack(expect))
+
+
+@pytest.mark.parametrize("frame_shape,cam,imgsz,C", [((520, 600), (360, 360), 384, 1), ((200, 260), (96, 160), 160, 3)])
+def test_fused_view_crop_letterbox_matches_oracle_views(hip_lib, frame_shape, cam, imgsz, C):
+    """SURVEY.md §8 f1 as written: frames + platform positions -> replicate-border camera view -> cv2-style bilinear letterbox ->
+    detector, in one device pass (wtk_yolo_predict_views), at the reference's real shape (360x360 views, imgsz 384) and on a
+    non-square view (rows = w, cols = h quirk of view_controller.py:171).  Against (a) the same detector fed the HOST crops of
+    oracle/view_oracle.py: every head logit and every result bit-identical (the same pixels reach the stem); (b) the fp32
+    restatement on those crops: logits within tolerance, survivor indices equal."""
+    from oracle import view_oracle as vo
+
+    H, W = frame_shape
+    rng = np.random.default_rng(H + W + C)
+    base, _ = fr.synthetic_frames(6, max(H, W), seed=31)
+    frames = np.ascontiguousarray(base[:, :H, :W])
+    if C == 3:
+        frames = np.stack([frames, 255 - frames, rng.integers(0, 256, size=frames.shape, dtype=np.uint8)], axis=-1)
+    pos = np.array([[0, 0], [W - 1, H - 1], [W // 2, H // 2], [5, H - 3], [W - 2, 7], [W // 3, H // 3]], dtype=np.int32)
+    fidx = np.array([3, 1, 0, 5, 2, 2], dtype=np.int32)  # rows draw from the frame stack in any order, with repeats
+    views = np.stack([vo.camera_view(frames[f], tuple(int(v) for v in p), cam) for f, p in zip(fidx, pos)])
+    assert views.shape[1:3] == (cam[0], cam[1])  # rows = w, cols = h
+    net = ys.letterbox_shape(cam[0], cam[1], imgsz)
+    w = ys.synthetic_weights("n", 1, seed=0)
+    oracle = yo.YoloOracle(w, ys.model_dims(0.25, 0.33, 1024, 1))
+    det = hip.HipYolo(w, net, 8, dtype="fp32", nc=1, width=0.25, depth=0.33, max_channels=1024)
+    n = len(fidx)
+    out = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    cf = torch.empty((n,), dtype=torch.float32, device="cuda")
+    an = torch.empty((n,), dtype=torch.int32, device="cuda")
+    det.predict_views(torch.from_numpy(frames).cuda(), len(frames), H, W, C, torch.from_numpy(fidx).cuda(), torch.from_numpy(pos).cuda(), n,
+                      cam[0], cam[1], out, cf, an, conf=0.1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    box_v, cls_v = det.debug_head(n)
+    xywh_h, conf_h, anchor_h = det.predict_host(views, conf=0.1)
+    box_h, cls_h = det.debug_head(n)
+    np.testing.assert_array_equal(box_v, box_h)
+    np.testing.assert_array_equal(cls_v, cls_h)
+    np.testing.assert_array_equal(out.cpu().numpy(), xywh_h)
+    np.testing.assert_array_equal(an.cpu().numpy(), anchor_h)
+    np.testing.assert_array_equal(cf.cpu().numpy(), conf_h)
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(views), imgsz)
+        assert tuple(x.shape[2:]) == net and hw == (cam[0], cam[1])
+        box_o, cls_o = oracle.forward(x)
+    np.testing.assert_allclose(cls_v, cls_o.numpy(), rtol=1e-3, atol=F32_LOGIT_ATOL)
+    xywh_o, _, anchor_o = yo.postprocess(box_o, cls_o, net, hw, conf=0.1)
+    np.testing.assert_array_equal(anchor_h, anchor_o)
+    ok = anchor_o >= 0
+    np.testing.assert_allclose(xywh_h[ok], xywh_o[ok], rtol=0, atol=F32_BOX_ATOL)
+    # row n = frame n when no index is given
+    det.predict_views(torch.from_numpy(frames).cuda(), len(frames), H, W, C, None, torch.from_numpy(pos).cuda(), n, cam[0], cam[1], out, cf, an,
+                      conf=0.1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    views2 = np.stack([vo.camera_view(frames[i], tuple(int(v) for v in pos[i]), cam) for i in range(n)])
+    np.testing.assert_array_equal(out.cpu().numpy(), det.predict_host(views2, conf=0.1)[0])
+    with pytest.raises(hip.WtkError, match="max_batch"):
+        det.predict_views(torch.from_numpy(frames).cuda(), len(frames), H, W, C, None, torch.from_numpy(pos).cuda(), 9, cam[0], cam[1], out)
+
+
+def test_converted_unfused_checkpoint_runs_on_device(hip_lib, tmp_path):
+    """SURVEY.md §8 f3 end to end: a synthetic UN-FUSED ultralytics-style state dict (Conv2d + BatchNorm2d eps 1e-3 per Conv,
+    plain Conv2d + bias for the Detect outputs, OIHW) -> tools/convert_ultralytics.py -> WTKYOLO1 file -> YoloConfig /
+    HipYoloController on the device, against an oracle that applies conv -> BN -> SiLU explicitly on the un-fused tensors."""
+    from tools import convert_ultralytics as cu
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig
+
+    scale, nc, size = "n", 1, 160
+    folded = ys.synthetic_weights(scale, nc, seed=0)  # well-conditioned target (gains are calibrated for seed 0); un-fold it with random BN statistics
+    rng = np.random.default_rng(5)
+    sd = {}
+    for t in ys.conv_table(scale, nc):
+        w, b = folded[t["name"]]
+        w_oihw = np.ascontiguousarray(w.transpose(0, 3, 1, 2)).astype(np.float64)
+        if t["act"]:
+            g, var = rng.uniform(0.5, 1.5, t["cout"]), rng.uniform(0.5, 2.0, t["cout"])
+            mu = rng.normal(0, 0.2, t["cout"])
+            s_ = g / np.sqrt(var + cu.BN_EPS)
+            sd[t["name"] + ".conv.weight"] = torch.from_numpy((w_oihw / s_[:, None, None, None]).astype(np.float32))
+            sd[t["name"] + ".bn.weight"] = torch.from_numpy(g.astype(np.float32))
+            sd[t["name"] + ".bn.bias"] = torch.from_numpy((b + mu * s_).astype(np.float32))
+            sd[t["name"] + ".bn.running_mean"] = torch.from_numpy(mu.astype(np.float32))
+            sd[t["name"] + ".bn.running_var"] = torch.from_numpy(var.astype(np.float32))
+            sd[t["name"] + ".bn.num_batches_tracked"] = torch.tensor(7)
+        else:
+            sd[t["name"] + ".weight"] = torch.from_numpy(w_oihw.astype(np.float32))
+            sd[t["name"] + ".bias"] = torch.from_numpy(b.astype(np.float32))
+    sd["model.22.dfl.conv.weight"] = torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)
+    ck, wtk = str(tmp_path / "unfused.pt"), str(tmp_path / "converted.wtk")
+    torch.save(sd, ck)
+    cu.main([ck, wtk, "--scale", scale])
+    loaded, nc_file = ys.load_weights(wtk)
+    assert nc_file == nc and set(loaded) == set(folded)
+    frames, _ = fr.synthetic_frames(3, size, seed=14)
+    ec = ExperimentConfig("synthetic", 3, 60, (size, size), 32, (size // 2, size // 2))
+    ctrl = HipYoloController(TimingConfig(ec, 100, 40, 50, (4, 4), (0.5, 0.5)),
+                             YoloConfig(model_path=wtk, pred_kwargs={"imgsz": size, "conf": 0.1}, scale=scale, max_batch=4))
+    assert ctrl.yolo_config.dtype == "fp32"  # the reference's precision is the default
+    got = ctrl.predict(list(frames))
+    det = ctrl._model.detector((size, size), 3)
+    box_g, cls_g = det.debug_head(3)
+    oracle = yo.UnfusedYoloOracle({k: v.numpy() for k, v in sd.items()}, ys.model_dims(0.25, 0.33, 1024, nc))
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(frames), size)
+        box_o, cls_o = oracle.forward(x)
+    np.testing.assert_allclose(cls_g, cls_o.numpy(), rtol=1e-3, atol=F32_LOGIT_ATOL)
+    np.testing.assert_allclose(box_g, box_o.numpy(), rtol=1e-3, atol=F32_LOGIT_ATOL)
+    xywh_o, _, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.1)
+    assert (anchor_o >= 0).any()
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(xywh_o, dtype=np.float64), rtol=0, atol=F32_BOX_ATOL, equal_nan=True)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])

@@ -11,7 +11,7 @@ from oracle import resmlp_oracle
 from oracle.controllers_oracle import OracleMLPController
 from wtracker_amd.controllers import CsvController, OptimalController, PolyfitConfig, PolyfitController
 from wtracker_amd.resmlp import make_training_pairs
-from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger, discretize
+from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger, box_center, discretize, xyxy_to_xywh, yolo_to_xywh
 
 EXP0 = dict(name="exp0", num_frames=200, frames_per_sec=60, orig_resolution=(1600, 1400), px_per_mm=90, init_position=(1300, 1200))
 
@@ -123,3 +123,39 @@ def test_discretize():
     assert d.dtype == np.int32
     assert d.tolist() == [[10, 5, 4, 5], [0, 0, 0, 0], [0, 0, 0, 0], [1395, 1590, 5, 10]]
     assert ok.tolist() == [True, False, False, True]
+
+
+def test_box_utilities_match_reference_vectors(golden_dir):
+    """BoxUtils.discretize / center and BoxConverter.to_xywh of the REAL reference (tests/golden/bbox_utils.npz, written by
+    make_golden.py --r2 from wtracker/utils/bbox_utils.py:76-167,232-260) on boxes with NaN rows, negative corners, boxes
+    hanging over the bounds, empty boxes: bit for bit."""
+    g = np.load(os.path.join(golden_dir, "bbox_utils.npz"))
+    bounds = tuple(int(v) for v in g["bounds"])
+    d, ok = discretize(g["xywh"], bounds)
+    assert d.dtype == g["disc"].dtype == np.int32
+    np.testing.assert_array_equal(d, g["disc"])
+    np.testing.assert_array_equal(ok, g["legal"])
+    assert 10 < ok.sum() < len(ok)
+    d32, _ = discretize(g["xywh"].astype(np.float32), bounds)  # the detector's float32 boxes (no NaN row -> float32 stack)
+    np.testing.assert_array_equal(d32, g["disc_f32"])
+    finite = np.isfinite(g["xywh"]).all(axis=1)
+    np.testing.assert_array_equal(box_center(g["xywh"])[finite], g["center"][finite])
+    np.testing.assert_array_equal(xyxy_to_xywh(g["xyxy"])[finite], g["xywh_from_xyxy"][finite])
+    np.testing.assert_array_equal(yolo_to_xywh(g["yolo"])[finite], g["xywh_from_yolo"][finite])
+    # the reference zeroes NaN rows of the CALLER's array (bbox_utils.py:139-140); the harness logger reproduces the visible
+    # consequence (missed detections are logged as 0,0,0,0) without mutating its input
+    assert (g["disc_input_after"][~finite] == 0).all()
+
+
+def test_polyfit_unsorted_times_and_weights_match_reference(golden_dir):
+    """polyfit_controller.py:28 sorts sample_times but NOT weights: weight i belongs to the i-th smallest time."""
+    init = os.path.join(golden_dir, "sim_init_bboxes.csv")
+    cases = json.load(open(os.path.join(golden_dir, "polyfit_cases.json")))
+    assert set(cases) >= {"unsorted_weighted", "unsorted_default_weights", "sorted_cubic"}
+    for name, c in cases.items():
+        cfg = PolyfitConfig(**c["config"])
+        assert list(cfg.sample_times) == c["sample_times_after"] and [float(w) for w in cfg.weights] == c["weights_after"]
+        _, moves = run(lambda tc: PolyfitController(tc, cfg, init))
+        assert moves == c["moves"], name
+    assert cases["unsorted_weighted"]["sample_times_after"] == [-9, -6, -3, 0, 2, 4]
+    assert cases["unsorted_weighted"]["weights_after"] == [1, 1, 2, 3, 4, 5]

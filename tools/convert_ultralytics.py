@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Offline converter: an ultralytics YOLOv8 detection checkpoint's state dict -> WTKYOLO1 weight file
-(SURVEY.md §8 f3).  Run where `ultralytics` is installed; it cannot be exercised in this build pipeline
-(no ultralytics, no trained weights), so it is covered only by the synthetic round-trip in
-tests/test_oracle_yolo.py::test_converter_folding_round_trip.
+(SURVEY.md §8 f3).  Run where `ultralytics` is installed (to unpickle a real `yolov8s_trained.pt`), or on a plain
+state-dict file (`torch.save(model.state_dict(), path)`), which needs torch only.  No real checkpoint exists in this build
+pipeline (no ultralytics, no trained weights): it is covered by the synthetic round trips
+tests/test_oracle_yolo.py::test_converter_folding_round_trip (fold arithmetic, CPU) and
+tests/test_gpu_yolo.py::test_converted_unfused_checkpoint_runs_on_device (un-fused state dict -> this tool -> .wtk ->
+HipYoloController against an oracle that applies conv -> BatchNorm(eps 1e-3) -> SiLU explicitly).
 
     python tools/convert_ultralytics.py yolov8s_trained.pt yolov8s_worm.wtk --scale s
 
@@ -46,18 +49,21 @@ def fold_state_dict(sd: dict, scale: str, nc: int) -> dict:
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("checkpoint")
     ap.add_argument("output")
     ap.add_argument("--scale", default="s", choices=list(ys.SCALES))
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     import torch
 
     ck = torch.load(args.checkpoint, map_location="cpu", weights_only=False)
-    model = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
-    model = model.float()
-    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    if isinstance(ck, dict) and ck and all(torch.is_tensor(v) for v in ck.values()):
+        sd = {k: v.detach().float().cpu().numpy() for k, v in ck.items()}  # a plain state dict
+    else:
+        model = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+        model = model.float()
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     nc = int(sd["model.22.cv3.0.2.weight"].shape[0])
     ys.save_weights(args.output, fold_state_dict(sd, args.scale, nc), args.scale, nc)
     print(f"wrote {args.output}: scale {args.scale}, nc {nc}")

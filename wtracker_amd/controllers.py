@@ -234,17 +234,34 @@ class _YoloModel:
 
 
 class HipYoloController(SimController):
-    def __init__(self, timing_config: TimingConfig, yolo_config: YoloConfig):
+    """YoloController with the detector on the MI355X.
+
+    `device_frames` (extension): a torch uint8 CUDA tensor [F,H,W] or [F,H,W,3] holding the experiment's
+    full frames (what the sim's frame reader serves, already resident in HBM).  The controller then never calls
+    `sim.camera_view()`: per camera frame it records (frame number, platform position), and the camera views are cut
+    (replicate border) and letterboxed ON THE DEVICE in front of the detector (wtk_yolo_predict_views) — no host crop, no
+    per-cycle upload.  Without it the controller behaves exactly like the reference: host crops through `predict(frames)`."""
+
+    def __init__(self, timing_config: TimingConfig, yolo_config: YoloConfig, device_frames=None):
         super().__init__(timing_config)
         self.yolo_config = yolo_config
         self._camera_frames = deque(maxlen=timing_config.cycle_frame_num)
         self._model = yolo_config.load_model()
+        self._device_frames = device_frames
+        if device_frames is not None:
+            if not getattr(device_frames, "is_cuda", False) or str(device_frames.dtype) != "torch.uint8" or device_frames.dim() not in (3, 4):
+                raise hip.WtkError("device_frames must be a CUDA uint8 tensor [F,H,W] or [F,H,W,3]")
+            if not device_frames.is_contiguous():
+                raise hip.WtkError("device_frames must be contiguous")
 
     def on_sim_start(self, sim):
         self._camera_frames.clear()
 
     def on_camera_frame(self, sim):
-        self._camera_frames.append(sim.camera_view())
+        if self._device_frames is not None:  # (frame number, platform position): 12 bytes instead of a w x h crop
+            self._camera_frames.append((int(sim.view.index), int(sim.view.position[0]), int(sim.view.position[1]), tuple(sim.view.camera_size)))
+        else:
+            self._camera_frames.append(sim.camera_view())
 
     def on_cycle_end(self, sim):
         self._camera_frames.clear()
@@ -273,12 +290,43 @@ class HipYoloController(SimController):
             return out
         return xywh
 
+    def predict_views(self, entries) -> np.ndarray:
+        """`entries`: (frame number, position x, position y, (view_w, view_h)) tuples recorded by on_camera_frame.  Same return
+        convention as predict(): [N,4] xywh in VIEW pixels, NaN rows for frames without a detection."""
+        import torch
+
+        assert len(entries) > 0
+        fr = self._device_frames
+        kw = dict(self.yolo_config.pred_kwargs)
+        imgsz, conf, iou = int(kw.pop("imgsz", 640)), float(kw.pop("conf", 0.25)), float(kw.pop("iou", 0.7))
+        if "max_det" in kw:
+            raise TypeError("predict() got multiple values for keyword argument 'max_det'")
+        vw, vh = entries[0][3]
+        n = len(entries)
+        det = self._model.detector(yolo_spec.letterbox_shape(vw, vh, imgsz), n)  # the view's shape is (rows = w, cols = h)
+        dev = fr.device
+        meta = torch.tensor([[e[0], e[1], e[2]] for e in entries], dtype=torch.int32).to(dev)  # one small upload per call
+        idx, pos = meta[:, 0].contiguous(), meta[:, 1:3].contiguous()
+        out = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        cf = torch.empty((n,), dtype=torch.float32, device=dev)
+        an = torch.empty((n,), dtype=torch.int32, device=dev)
+        C = fr.shape[3] if fr.dim() == 4 else 1
+        with torch.cuda.device(dev):
+            det.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx, pos, n, vw, vh, out, cf, an, conf=conf, iou=iou, max_det=1,
+                              stream=torch.cuda.current_stream(dev).cuda_stream)
+        xywh, anchor = out.cpu().numpy(), an.cpu().numpy()
+        if (anchor < 0).any():
+            res = xywh.astype(np.float64)
+            res[anchor < 0] = np.nan
+            return res
+        return xywh
+
     def begin_movement_prediction(self, sim) -> None:
         pass
 
     def provide_movement_vector(self, sim) -> tuple:
         frame = self._camera_frames[-self.timing_config.pred_frame_num]
-        bbox = self.predict([frame])[0]
+        bbox = (self.predict_views([frame]) if self._device_frames is not None else self.predict([frame]))[0]
         if not np.isfinite(bbox).all():
             return 0, 0
         mid = bbox[0] + bbox[2] / 2, bbox[1] + bbox[3] / 2
@@ -286,4 +334,6 @@ class HipYoloController(SimController):
         return round(mid[0] - cam_mid[0]), round(mid[1] - cam_mid[1])
 
     def _cycle_predict_all(self, sim) -> np.ndarray:
+        if self._device_frames is not None:
+            return self.predict_views(list(self._camera_frames))
         return self.predict(self._camera_frames)

@@ -271,6 +271,63 @@ hipError_t launch_crop_views(const CropArgs &a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Camera view + letterbox fused: what ViewController.camera_view (view_controller.py:45-61,143-172)
+// followed by ultralytics' LetterBox (cv2.resize INTER_LINEAR + 114 border) produces, straight from the full frame.
+// View pixel (r, c) = frame pixel (clamp(pos_y - view_h/2 + r), clamp(pos_x - view_w/2 + c)) as in crop_views_kernel; the
+// bilinear arithmetic is letterbox_kernel's (11-bit fixed point), with the view's shape (rows, cols) as the source image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void view_letterbox_kernel(const ViewLetterboxArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.N * a.Sh * a.Sw;
+    if (idx >= total) return;
+    const int n = (int)(idx / ((long long)a.Sh * a.Sw));
+    const int rem = (int)(idx - (long long)n * a.Sh * a.Sw);
+    const int y = rem / a.Sw, x = rem - y * a.Sw;
+    uint8_t *d = a.dst + idx * a.C;
+    const int ry = y - a.top, rx = x - a.left;
+    if (ry < 0 || ry >= a.new_h || rx < 0 || rx >= a.new_w) {
+        for (int c = 0; c < a.C; ++c) d[c] = 114;
+        return;
+    }
+    const int f = a.frame_index ? a.frame_index[n] : n;
+    const uint8_t *s = a.frames + (long long)f * a.H * a.W * a.C;
+    const int oy = a.pos_xy[2 * n + 1] - a.view_h / 2, ox = a.pos_xy[2 * n] - a.view_w / 2; // view origin in frame coordinates
+    auto px = [&](int vr, int vc, int c) -> int { // view pixel through the replicate border
+        const int fy = min(max(oy + vr, 0), a.H - 1), fx = min(max(ox + vc, 0), a.W - 1);
+        return s[((long long)fy * a.W + fx) * a.C + c];
+    };
+    if (a.new_h == a.rows && a.new_w == a.cols) {
+        for (int c = 0; c < a.C; ++c) d[c] = (uint8_t)px(ry, rx, c);
+        return;
+    }
+    const float sx_scale = (float)a.cols / (float)a.new_w, sy_scale = (float)a.rows / (float)a.new_h;
+    float fx = ((float)rx + 0.5f) * sx_scale - 0.5f;
+    float fy = ((float)ry + 0.5f) * sy_scale - 0.5f;
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx;
+    fy -= (float)sy;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= a.cols - 1) { sx = a.cols - 1; fx = 0.f; }
+    if (sy < 0) { sy = 0; fy = 0.f; }
+    if (sy >= a.rows - 1) { sy = a.rows - 1; fy = 0.f; }
+    const int sx1 = min(sx + 1, a.cols - 1), sy1 = min(sy + 1, a.rows - 1);
+    const int ax1 = (int)rintf(fx * 2048.0f), ax0 = 2048 - ax1;
+    const int ay1 = (int)rintf(fy * 2048.0f), ay0 = 2048 - ay1;
+    for (int c = 0; c < a.C; ++c) {
+        const int r0 = px(sy, sx, c) * ax0 + px(sy, sx1, c) * ax1, r1 = px(sy1, sx, c) * ax0 + px(sy1, sx1, c) * ax1;
+        const int v = (((ay0 * (r0 >> 4)) >> 16) + ((ay1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        d[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+hipError_t launch_view_letterbox(const ViewLetterboxArgs &a, hipStream_t stream) {
+    if (a.N <= 0 || a.rows <= 0 || a.cols <= 0 || (a.C != 1 && a.C != 3) || a.Sh <= 0 || a.Sw <= 0) return hipErrorInvalidValue;
+    const long long total = (long long)a.N * a.Sh * a.Sw;
+    hipLaunchKernelGGL(view_letterbox_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // SPPF chained 5x5 max pools (stride 1, pad 2, implicit -inf padding as nn.MaxPool2d).
 // One block = one image x one 16-byte channel group; the whole map lives in LDS and each 5x5
 // pool runs as a separable row-max / column-max pair.  y1,y2,y3 are written back to their slices.

@@ -974,10 +974,27 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
 
 // Enqueue one forward pass (letterbox, stem, convs, pool, head) on `st`.  No allocation, no synchronisation
 // (profiling mode excepted): safe inside stream capture.
+// `vs` != nullptr: the batch rows are camera views of full frames (wtk_yolo_predict_views) — crop + letterbox in one kernel.
+struct ViewSrc {
+    const int32_t *pos_xy, *frame_index;
+    int view_w, view_h;
+};
 static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
-                        float *out_conf, int32_t *out_anchor, hipStream_t st) {
+                        float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr) {
     const uint8_t *net_in = frames_dev;
-    if (H != h->S_h || W != h->S_w) {
+    if (vs) {
+        ViewLetterboxArgs va;
+        va.frames = frames_dev, va.frame_index = vs->frame_index, va.pos_xy = vs->pos_xy, va.dst = h->lb_dev;
+        va.N = B, va.H = H, va.W = W, va.C = C;
+        va.view_w = vs->view_w, va.view_h = vs->view_h;
+        va.rows = vs->view_w, va.cols = vs->view_h; // frame[y : y + w, x : x + h], view_controller.py:171
+        va.Sh = h->S_h, va.Sw = h->S_w;
+        float g, px, py;
+        letterbox_geom(va.rows, va.cols, h->S_h, h->S_w, va.new_h, va.new_w, va.top, va.left, g, px, py);
+        HIP_TRY(launch_view_letterbox(va, st));
+        net_in = h->lb_dev;
+        H = va.rows, W = va.cols; // from here on the "image" is the view: scale_boxes maps back to view pixels
+    } else if (H != h->S_h || W != h->S_w) {
         LetterboxArgs la;
         la.src = frames_dev;
         la.dst = h->lb_dev;
@@ -1252,6 +1269,28 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     h->graphs.push_back(e);
     HIP_TRY(hipGraphLaunch(e.exec, st));
     return 0;
+}
+
+extern "C" int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t C,
+                                      const int32_t *frame_index_dev, const int32_t *pos_xy_dev, int32_t B, int32_t view_w, int32_t view_h, float conf,
+                                      float iou, int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
+    (void)iou;
+    if (!h || !frames_dev || !pos_xy_dev || !out_xywh) return fail("wtk_yolo_predict_views: null argument");
+    if (B <= 0) return fail("wtk_yolo_predict_views: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
+    if (B > h->max_batch) return fail("wtk_yolo_predict_views: batch exceeds max_batch");
+    if (C != 1 && C != 3) return fail("wtk_yolo_predict_views: frames must have 1 (gray) or 3 (BGR) channels");
+    if (max_det != 1) return fail("wtk_yolo_predict_views: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
+    if (H <= 0 || W <= 0 || view_w <= 0 || view_h <= 0 || n_frames <= 0) return fail("wtk_yolo_predict_views: bad frame / view size");
+    if (!frame_index_dev && B > n_frames) return fail("wtk_yolo_predict_views: without frame_index the batch rows are frames 0..B-1");
+    DEVICE_GUARD(h);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->lb_cap == 0) { // staging image of the network input, allocated once
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
+        h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
+    }
+    const ViewSrc vs{pos_xy_dev, frame_index_dev, view_w, view_h};
+    return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, &vs);
 }
 
 extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, int32_t B, int32_t H, int32_t W, int32_t C, float conf,

@@ -264,6 +264,22 @@ struct CropArgs {
 };
 hipError_t launch_crop_views(const CropArgs &a, hipStream_t stream);
 
+// Camera view + letterbox in ONE pass: net input pixel <- cv2-style bilinear resize of the camera view
+// (rows x cols window of the replicate-padded frame centred on the platform position) + constant-114 border.  The view is
+// never materialised: each bilinear tap is fetched from the full frame through the crop's clamp.
+struct ViewLetterboxArgs {
+    const uint8_t *frames;  // [F][H][W][C] full frames
+    const int *frame_index; // [N] frame of batch row n, or nullptr (row n = frame n)
+    const int *pos_xy;      // [N][2] platform position (x, y)
+    uint8_t *dst;           // [N][Sh][Sw][C] network input
+    int N, H, W, C;
+    int view_w, view_h;     // the (w, h) the reference passes to _custom_view
+    int rows, cols;         // view shape: rows = w, cols = h (view_controller.py:171)
+    int Sh, Sw;
+    int new_h, new_w, top, left; // letterbox geometry of a rows x cols image into Sh x Sw
+};
+hipError_t launch_view_letterbox(const ViewLetterboxArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2) on a
 // channel slice of the SPPF concat buffer; x at channels [0,c), y_k at [k*c,(k+1)*c).

@@ -52,6 +52,7 @@ SYMBOLS = [
     "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
     "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_yolo_get_kernel_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
+    "wtk_yolo_predict_views",
 ]
 
 
@@ -94,6 +95,7 @@ def load() -> C.CDLL:
     lib.wtk_yolo_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.wtk_yolo_get_kernel_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.wtk_crop_views.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
+    lib.wtk_yolo_predict_views.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -269,6 +271,15 @@ class HipYolo:
         """Device pointers / torch CUDA tensors; asynchronous on `stream`."""
         _check(load().wtk_yolo_predict(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh),
                                        _ptr(out_conf), _ptr(out_anchor), C.c_void_p(stream)), "wtk_yolo_predict")
+
+    def predict_views(self, frames_dev, n_frames: int, H: int, W: int, Cc: int, frame_index_dev, pos_xy_dev, B: int, view_w: int,
+                      view_h: int, out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1, iou: float = 0.7, max_det: int = 1,
+                      stream: int = 0):
+        """Detector on the (view_w x view_h) camera views of device-resident full frames (crop + letterbox fused on the
+        device; wtk_yolo_predict_views).  frame_index_dev [B] int32 or None, pos_xy_dev [B,2] int32; boxes in view pixels."""
+        _check(load().wtk_yolo_predict_views(self._h, _ptr(frames_dev), n_frames, H, W, Cc, _ptr(frame_index_dev), _ptr(pos_xy_dev), B,
+                                             view_w, view_h, conf, iou, max_det, _ptr(out_xywh), _ptr(out_conf), _ptr(out_anchor),
+                                             C.c_void_p(stream)), "wtk_yolo_predict_views")
 
     def debug_head(self, B: int):
         """Raw head logits of the last forward: (box [B,A,64], cls [B,A,nc]) fp32, levels concatenated."""

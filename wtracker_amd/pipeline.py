@@ -98,16 +98,20 @@ class TrackPipeline:
         self.valid = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self._steps_done = 0
 
-    def _step_on_current_stream(self, s: int, lane: int, frames_dev: torch.Tensor) -> int:
-        B, H, W = frames_dev.shape[0], frames_dev.shape[1], frames_dev.shape[2]
+    def _step_on_current_stream(self, s: int, lane: int, frames_dev: torch.Tensor, views=None) -> int:
+        H, W = frames_dev.shape[1], frames_dev.shape[2]
         C = frames_dev.shape[3] if frames_dev.dim() == 4 else 1
         det = self.dets[lane]
         st = torch.cuda.current_stream(self.device).cuda_stream
-        if self.world == 1:
-            f0, f1 = self.plan.local_range(s, 0)
-            det.predict(frames_dev, B, H, W, C, self.track[f0:f1], self.local_conf[lane], self.local_anchor[lane], conf=self.conf, stream=st)
-        else:
-            det.predict(frames_dev, B, H, W, C, self.local_xywh[lane], self.local_conf[lane], self.local_anchor[lane], conf=self.conf, stream=st)
+        f0, f1 = self.plan.local_range(s, 0)
+        out = self.track[f0:f1] if self.world == 1 else self.local_xywh[lane]  # one rank: straight into the track
+        if views is None:
+            det.predict(frames_dev, frames_dev.shape[0], H, W, C, out, self.local_conf[lane], self.local_anchor[lane], conf=self.conf, stream=st)
+        else:  # camera views of full frames: crop + letterbox on the device in front of the detector
+            frame_index, pos_xy, (vw, vh) = views
+            det.predict_views(frames_dev, frames_dev.shape[0], H, W, C, frame_index, pos_xy, self.plan.B, vw, vh, out, self.local_conf[lane],
+                              self.local_anchor[lane], conf=self.conf, stream=st)
+        if self.world > 1:
             exchange_tracks(self.track, self.local_xywh[lane], self.plan, s, self.group)
         self.det_done[lane].record(torch.cuda.current_stream(self.device))
         lo, hi = self.plan.cycles(s)
@@ -119,15 +123,17 @@ class TrackPipeline:
         self._steps_done += 1
         return hi - lo
 
-    def step(self, s: int, frames_dev: torch.Tensor) -> int:
-        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles."""
+    def step(self, s: int, frames_dev: torch.Tensor, views=None) -> int:
+        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles.
+        `views` = (frame_index [B] int32 or None, pos_xy [B,2] int32, (view_w, view_h)): `frames_dev` then holds FULL frames
+        and the batch rows are their camera views (device crop + letterbox)."""
         lane = s % len(self.dets)
         if self.streams[lane] is None:
-            return self._step_on_current_stream(s, lane, frames_dev)
+            return self._step_on_current_stream(s, lane, frames_dev, views)
         stream = self.streams[lane]
         stream.wait_stream(torch.cuda.current_stream(self.device))  # inputs produced on the caller's stream
         with torch.cuda.stream(stream):
-            return self._step_on_current_stream(s, lane, frames_dev)
+            return self._step_on_current_stream(s, lane, frames_dev, views)
 
     def synchronize(self):
         for st in self.streams:

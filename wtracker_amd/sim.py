@@ -407,6 +407,25 @@ class TrackLogger(SimController):
     def _cycle_predict_all(self, sim): return self.sim_controller._cycle_predict_all(sim)
 
 
+def box_center(xywh: np.ndarray) -> np.ndarray:
+    """(x + w / 2, y + h / 2) per row (BoxUtils.center, wtracker/utils/bbox_utils.py:76-92)."""
+    b = np.asarray(xywh)
+    return np.stack([b[..., 0] + b[..., 2] / 2, b[..., 1] + b[..., 3] / 2], axis=-1)
+
+
+def xyxy_to_xywh(xyxy: np.ndarray) -> np.ndarray:
+    """(x1, y1, x2 - x1, y2 - y1): what YoloController applies to the detector's box (BoxConverter.to_xywh from XYXY,
+    bbox_utils.py:232-253; on the device this is head_select_kernel's epilogue)."""
+    b = np.asarray(xyxy)
+    return np.stack([b[..., 0], b[..., 1], b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]], axis=-1)
+
+
+def yolo_to_xywh(cxcywh: np.ndarray) -> np.ndarray:
+    """Centre format -> corner format (BoxConverter.to_xywh from YOLO, bbox_utils.py:254-258)."""
+    b = np.asarray(cxcywh)
+    return np.stack([b[..., 0] - b[..., 2] / 2, b[..., 1] - b[..., 3] / 2, b[..., 2], b[..., 3]], axis=-1)
+
+
 def discretize(bboxes: np.ndarray, bounds: tuple) -> tuple:
     """xywh float boxes -> int32 crop windows clamped to (H, W); illegal/NaN rows zeroed
     (BoxUtils.discretize, wtracker/utils/bbox_utils.py:118-167)."""
