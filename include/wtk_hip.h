@@ -184,6 +184,35 @@ int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, i
                    void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The other predictors behind provide_movement_vector and the training-pair builder, batched over a
+ * DEVICE-resident track [n_frames][4] xywh (float32: the detector's track; float64: a loaded bboxes.csv), NaN row =
+ * missed detection.  One sample per cycle; the result is the predicted ABSOLUTE head position — the caller subtracts the
+ * camera centre and rounds in float64 on the host exactly as the reference does (the prediction itself does not depend
+ * on the platform position, so all cycles of a track are computed in one launch).
+ *
+ * wtk_track_median_centers  replaces OptimalController.provide_movement_vector  optimal_controller.py:16-32
+ *     pred[i] = per-axis median of the finite box centres of frames [(cycles[i]+1)*cycle_frame_num, +imaging_frame_num)
+ * wtk_track_polyfit         replaces PolyfitController.provide_movement_vector  polyfit_controller.py:54-84
+ *     weighted least-squares polynomial (numpy.polynomial.polynomial.polyfit semantics: column-scaled, minimum norm)
+ *     through the finite centres at frames cycles[i]*cycle_frame_num + sample_times, evaluated at t_eval
+ *     (= cycle_frame_num + imaging_frame_num // 2); sample_times / weights as PolyfitConfig.__post_init__ leaves them
+ * wtk_track_training_pairs  replaces NumpyDataset.create_from_config            neural/dataset.py:42-96
+ *     rows row0 .. row0+n_rows-1: X = boxes at row + input_frames, Y = centres at row + pred_frames, float64 -> float32,
+ *     then relative to the float32 corner of the first input box; keep[i] = 0 where the row holds a NaN (caller compacts)
+ * valid[i] = 0: no usable frame (the reference returns (0, 0) for that cycle).  pred is float64.
+ * ------------------------------------------------------------------------------------------ */
+int wtk_track_median_centers(const void *track_dev, int32_t track_is_f64, int32_t n_frames, const int32_t *cycles_dev,
+                             int32_t n_samples, int32_t cycle_frame_num, int32_t imaging_frame_num, double *pred_dev,
+                             int32_t *valid_dev, void *stream);
+int wtk_track_polyfit(const void *track_dev, int32_t track_is_f64, int32_t n_frames, const int32_t *cycles_dev,
+                      int32_t n_samples, int32_t cycle_frame_num, const int32_t *sample_times_host,
+                      const double *weights_host, int32_t n_times, int32_t degree, double t_eval, double *pred_dev,
+                      int32_t *valid_dev, void *stream);
+int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_t n_frames, int32_t row0, int32_t n_rows,
+                             const int32_t *input_frames_host, int32_t n_in, const int32_t *pred_frames_host,
+                             int32_t n_out, float *x_dev, float *y_dev, int32_t *keep_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Detector on camera views of device-resident full frames: view cropping fused with the letterbox in front of
  * the detector, so the per-frame host crop + upload of the reference's loop disappears.
  * Replaces: YoloController.on_camera_frame -> sim.camera_view()   yolo_controller.py:58-59

@@ -23,6 +23,8 @@ def _run(lanes, frames, B, steps, folded, weights):
         pipe.step(s, frames[s * B : (s + 1) * B])
     pipe.synchronize()
     torch.cuda.synchronize()
+    global _last_pipe
+    _last_pipe = pipe
     return pipe.track.cpu().numpy(), pipe.moves.cpu().numpy(), pipe.valid.cpu().numpy(), pipe.plan
 
 
@@ -53,3 +55,34 @@ def test_three_lanes_equal_one_lane_and_oracle_mlp(hip_lib, golden_dir):
             np.testing.assert_allclose(m1[i], resmlp_oracle.forward(st, b.reshape(1, -1))[0], rtol=1e-4, atol=5e-4)
             n_valid += 1
     assert n_valid >= 10 and len(plan.anchors) == (B * steps - 6) // 9 + 1
+
+
+def test_pipeline_baseline_targets_match_numpy_on_the_device_track(hip_lib, golden_dir):
+    """after an open-loop run all three predictors' outputs exist on the device without a host pass — ResMLP moves
+    (above) plus OptimalController / PolyfitController targets for every cycle, here against numpy on the same fp32 track."""
+    from numpy.polynomial import polynomial as poly
+
+    B, steps = 32, 4
+    folded = resmlp.load_npz(os.path.join(golden_dir, "resmlp_100ms.npz"))
+    f_np, _ = fr.synthetic_frames(B * steps, 128, seed=6)
+    t, _, _, plan = _run(2, torch.from_numpy(f_np).cuda(), B, steps, folded, ys.synthetic_weights("n", 1, seed=0))
+    times, weights = [-9, -6, -3, 0, 2, 4], [1, 1, 2, 3, 4, 5.0]
+    out = _last_pipe.baseline_targets(sample_times=times, weights=weights, degree=2)
+    torch.cuda.synchronize()
+    cen = np.stack([t[:, 0].astype(np.float64) + t[:, 2].astype(np.float64) / 2, t[:, 1].astype(np.float64) + t[:, 3].astype(np.float64) / 2], axis=1)
+    opt, opt_ok = (x.cpu().numpy() for x in out["optimal"])
+    pf, pf_ok = (x.cpu().numpy() for x in out["polyfit"])
+    assert len(opt) == len(plan.anchors) and opt_ok.sum() >= len(opt) - 2
+    for c in range(len(opt)):
+        w = cen[(c + 1) * 9 : (c + 1) * 9 + 6]
+        w = w[np.isfinite(w).all(axis=1)]
+        assert bool(opt_ok[c]) == (len(w) > 0)
+        if len(w):
+            np.testing.assert_array_equal(opt[c], np.median(w, axis=0))
+        f = c * 9 + np.asarray(times)
+        ok = (f >= 0) & (f < len(t))
+        ok[ok] &= np.isfinite(cen[f[ok]]).all(axis=1)
+        assert bool(pf_ok[c]) == bool(ok.any())
+        if ok.sum() >= 3:
+            coef = poly.polyfit(np.asarray(times)[ok], cen[f[ok]], deg=2, w=np.asarray(weights)[ok])
+            np.testing.assert_allclose(pf[c], poly.polyval(9 + 6 // 2, coef), rtol=0, atol=1e-6)

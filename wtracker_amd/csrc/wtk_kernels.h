@@ -347,4 +347,46 @@ struct MlpArgs {
 };
 hipError_t launch_mlp(const MlpArgs &a, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// Batched per-cycle predictors over a device track (track_ops.hip)
+// ---------------------------------------------------------------------------------------------
+constexpr int kTrackMaxWindow = 64; // imaging frames per cycle the median kernel sorts in registers
+constexpr int kTrackMaxTimes = 16;  // sample times of a polynomial fit / input or target frames of a training pair
+constexpr int kTrackMaxCoef = 8;    // polynomial degree + 1
+struct TrackMedianArgs {
+    const void *track; // [n_frames][4] xywh, float or double
+    int n_frames;
+    const int *cycles; // [n_samples] cycle numbers (device)
+    int n_samples;
+    int cycle_frame_num, imaging_frame_num;
+    double *pred; // [n_samples][2] median centre (x, y), absolute coordinates
+    int *valid;   // [n_samples] 0: no finite row in the window
+};
+hipError_t launch_track_median(const TrackMedianArgs &a, int track_f64, hipStream_t stream);
+struct TrackPolyfitArgs {
+    const void *track;
+    int n_frames;
+    const int *cycles;
+    int n_samples;
+    int cycle_frame_num;
+    int times[kTrackMaxTimes];      // frame offsets from the start of the cycle (sorted, as PolyfitConfig leaves them)
+    double weights[kTrackMaxTimes]; // weight of the i-th time
+    int n_times, degree;
+    double t_eval; // cycle_frame_num + imaging_frame_num // 2
+    double *pred;  // [n_samples][2] extrapolated centre (x, y), absolute coordinates
+    int *valid;    // [n_samples] 0: no usable sample
+};
+hipError_t launch_track_polyfit(const TrackPolyfitArgs &a, int track_f64, hipStream_t stream);
+struct TrackPairsArgs {
+    const void *track;
+    int n_frames;
+    int row0, n_rows; // candidate rows row0 .. row0 + n_rows - 1
+    int in_frames[kTrackMaxTimes], out_frames[kTrackMaxTimes];
+    int n_in, n_out;
+    float *X; // [n_rows][4 * n_in]
+    float *Y; // [n_rows][2 * n_out]
+    int *keep; // [n_rows] 1: no NaN in the row
+};
+hipError_t launch_track_pairs(const TrackPairsArgs &a, int track_f64, hipStream_t stream);
+
 } // namespace wtk

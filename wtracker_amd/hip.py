@@ -52,7 +52,7 @@ SYMBOLS = [
     "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
     "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_yolo_get_kernel_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
-    "wtk_yolo_predict_views",
+    "wtk_yolo_predict_views", "wtk_track_median_centers", "wtk_track_polyfit", "wtk_track_training_pairs",
 ]
 
 
@@ -95,6 +95,9 @@ def load() -> C.CDLL:
     lib.wtk_yolo_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.wtk_yolo_get_kernel_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.wtk_crop_views.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
+    lib.wtk_track_median_centers.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp]
+    lib.wtk_track_polyfit.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, C.c_double, vp, vp, vp]
+    lib.wtk_track_training_pairs.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.wtk_yolo_predict_views.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -131,6 +134,42 @@ def crop_views(frames_dev, N: int, H: int, W: int, Cc: int, pos_xy_dev, view_w: 
     with replicate borders.  All arguments are device tensors / pointers."""
     _check(load().wtk_crop_views(_ptr(frames_dev), N, H, W, Cc, _ptr(pos_xy_dev), view_w, view_h, _ptr(views_dev),
                                  C.c_void_p(stream)), "wtk_crop_views")
+
+
+def _track_is_f64(track_dev) -> int:
+    dt = str(getattr(track_dev, "dtype", ""))
+    if dt.endswith("float64"):
+        return 1
+    if dt.endswith("float32"):
+        return 0
+    raise WtkError("track must be a float32 or float64 device tensor [n_frames, 4]")
+
+
+def track_median_centers(track_dev, n_frames: int, cycles_dev, n_samples: int, cycle_frame_num: int, imaging_frame_num: int, pred_dev, valid_dev,
+                         stream: int = 0):
+    """OptimalController's target for every cycle in `cycles_dev` (wtk_track_median_centers); pred_dev float64 [n,2]."""
+    _check(load().wtk_track_median_centers(_ptr(track_dev), _track_is_f64(track_dev), n_frames, _ptr(cycles_dev), n_samples, cycle_frame_num,
+                                           imaging_frame_num, _ptr(pred_dev), _ptr(valid_dev), C.c_void_p(stream)), "wtk_track_median_centers")
+
+
+def track_polyfit(track_dev, n_frames: int, cycles_dev, n_samples: int, cycle_frame_num: int, sample_times: Sequence[int], weights: Sequence[float],
+                  degree: int, t_eval: float, pred_dev, valid_dev, stream: int = 0):
+    """PolyfitController's extrapolated head position for every cycle in `cycles_dev` (wtk_track_polyfit); pred_dev float64 [n,2]."""
+    st = np.ascontiguousarray(sample_times, dtype=np.int32)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    if len(st) != len(w):
+        raise WtkError("sample_times and weights differ in length")
+    _check(load().wtk_track_polyfit(_ptr(track_dev), _track_is_f64(track_dev), n_frames, _ptr(cycles_dev), n_samples, cycle_frame_num, _ptr(st), _ptr(w),
+                                    len(st), degree, float(t_eval), _ptr(pred_dev), _ptr(valid_dev), C.c_void_p(stream)), "wtk_track_polyfit")
+
+
+def track_training_pairs(track_dev, n_frames: int, row0: int, n_rows: int, input_frames: Sequence[int], pred_frames: Sequence[int], x_dev, y_dev,
+                         keep_dev, stream: int = 0):
+    """NumpyDataset.create_from_config's rows row0 .. row0+n_rows-1 (wtk_track_training_pairs); the caller drops keep == 0."""
+    xi = np.ascontiguousarray(input_frames, dtype=np.int32)
+    yi = np.ascontiguousarray(pred_frames, dtype=np.int32)
+    _check(load().wtk_track_training_pairs(_ptr(track_dev), _track_is_f64(track_dev), n_frames, row0, n_rows, _ptr(xi), len(xi), _ptr(yi), len(yi),
+                                           _ptr(x_dev), _ptr(y_dev), _ptr(keep_dev), C.c_void_p(stream)), "wtk_track_training_pairs")
 
 
 # -------------------------------------------------------------------------------------------------

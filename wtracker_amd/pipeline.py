@@ -135,6 +135,31 @@ class TrackPipeline:
         with torch.cuda.stream(stream):
             return self._step_on_current_stream(s, lane, frames_dev, views)
 
+    def baseline_targets(self, sample_times=None, weights=None, degree: int = 2):
+        """The other two predictors of the reference over the finished device track, every cycle in one launch each and no
+        host pass: OptimalController's median head position of the NEXT imaging phase
+        (optimal_controller.py:16-32) and, when `sample_times` is given, PolyfitController's weighted-fit extrapolation
+        (polyfit_controller.py:54-84).  Returns {name: (targets float64 [n_cycles,2] absolute px, valid int32 [n_cycles])} as
+        device tensors; cycle i is the cycle of self.plan.anchors[i].  Call after the last step."""
+        n = len(self.plan.anchors)
+        st = torch.cuda.current_stream(self.device)
+        for ev in self.det_done:
+            st.wait_event(ev)
+        cycles = torch.arange(n, dtype=torch.int32, device=self.device)
+        out = {}
+        tgt = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
+        ok = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        hip.track_median_centers(self.track, self.plan.total_frames, cycles, n, self.plan.cyc, self.plan.img, tgt, ok, stream=st.cuda_stream)
+        out["optimal"] = (tgt, ok)
+        if sample_times is not None:
+            w = [1.0] * len(sample_times) if weights is None else list(weights)
+            tgt2 = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
+            ok2 = torch.zeros((n,), dtype=torch.int32, device=self.device)
+            hip.track_polyfit(self.track, self.plan.total_frames, cycles, n, self.plan.cyc, sorted(sample_times), w, degree,
+                              self.plan.cyc + self.plan.img // 2, tgt2, ok2, stream=st.cuda_stream)
+            out["polyfit"] = (tgt2, ok2)
+        return out
+
     def synchronize(self):
         for st in self.streams:
             if st is not None:

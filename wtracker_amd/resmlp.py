@@ -143,3 +143,27 @@ def make_training_pairs(log_path: str, input_frames: Sequence[int], pred_frames:
     X[:, 0::4] -= x0
     X[:, 1::4] -= y0
     return X, y
+
+
+def make_training_pairs_device(track_dev, input_frames: Sequence[int], pred_frames: Sequence[int]):
+    """make_training_pairs on a DEVICE-resident track (torch CUDA tensor [N,4], float64 as loaded from a bboxes.csv or the
+    detector's float32 track): wtk_track_training_pairs builds every candidate row, the NaN rows are dropped on the device.
+    Returns (X, y) as float32 CUDA tensors — bit-identical to the reference's NumpyDataset for a float64 track."""
+    import torch
+
+    from . import hip
+
+    n = int(track_dev.shape[0])
+    xi, yi = [int(v) for v in input_frames], [int(v) for v in pred_frames]
+    row0 = abs(min(xi)) + 1
+    n_rows = max(n - max(yi) - 1 - row0, 0)
+    dev = track_dev.device
+    X = torch.empty((n_rows, 4 * len(xi)), dtype=torch.float32, device=dev)
+    y = torch.empty((n_rows, 2 * len(yi)), dtype=torch.float32, device=dev)
+    if n_rows == 0:
+        return X, y
+    keep = torch.empty((n_rows,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        hip.track_training_pairs(track_dev.contiguous(), n, row0, n_rows, xi, yi, X, y, keep, stream=torch.cuda.current_stream(dev).cuda_stream)
+    m = keep.bool()
+    return X[m], y[m]
