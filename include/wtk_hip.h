@@ -184,6 +184,24 @@ int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, i
                    void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Detector with the GENERAL greedy NMS (max_det >= 1 boxes per frame): the part of ultralytics'
+ * non_max_suppression(conf, iou, agnostic=False, max_det) that the reference's call site never reaches because it
+ * hard-wires max_det = 1 (yolo_controller.py:76; yolo/yolo_train_config.yaml:49-50,61 give iou 0.7, max_det 300, class-aware).
+ * Candidates = anchors whose best class score > conf, visited in descending score (lowest anchor index on ties); a
+ * candidate is dropped when its IoU with an already kept box of the same class exceeds `iou`.
+ * Outputs per frame, rows in descending score: out_xywh [B][max_det][4] (x, y, w, h in input-image pixels, NaN rows past the
+ * last box), out_conf [B][max_det], out_cls [B][max_det] (-1 past the last), out_anchor [B][max_det], out_count [B]; all but
+ * out_xywh may be NULL.  With max_det = 1 the first row equals wtk_yolo_predict's result.
+ * wtk_yolo_decode_nms_host: the same selection on caller-supplied head logits (test hook, as wtk_yolo_decode_host).
+ * ------------------------------------------------------------------------------------------ */
+int wtk_yolo_predict_nms(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
+                         int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls, int32_t *out_anchor,
+                         int32_t *out_count, void *stream);
+int wtk_yolo_decode_nms_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W,
+                             float conf, float iou, int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls,
+                             int32_t *out_anchor, int32_t *out_count);
+
+/* ------------------------------------------------------------------------------------------
  * The other predictors behind provide_movement_vector and the training-pair builder, batched over a
  * DEVICE-resident track [n_frames][4] xywh (float32: the detector's track; float64: a loaded bboxes.csv), NaN row =
  * missed detection.  One sample per cycle; the result is the predicted ABSOLUTE head position — the caller subtracts the
@@ -226,6 +244,22 @@ int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, int32_t n_fra
                            const int32_t *frame_index_dev, const int32_t *pos_xy_dev, int32_t B,
                            int32_t view_w, int32_t view_h, float conf, float iou, int32_t max_det,
                            float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: the path's ONLY collective, for callers that do not go through PyTorch.
+ * The reference has no distributed code; this replaces nothing — it is what lets frames be sharded over the GPUs of a node:
+ * every rank detects its n_local frames of a super-batch, one all-gather (RCCL over xGMI, 16 B per frame: latency-bound)
+ * gives every rank the whole [world * n_local][4] block in rank order = frame order (wtracker_amd/pipeline.py shows the
+ * sharding; it uses torch.distributed's RCCL communicator for the same ncclAllGather).
+ * Rendezvous: rank 0 calls wtk_comm_unique_id and hands the 128 bytes to the other ranks out of band (file, socket, MPI);
+ * every rank then calls wtk_comm_create.  librccl is loaded on the first wtk_comm_* call, not with libwtk_hip.so.
+ * ------------------------------------------------------------------------------------------ */
+#define WTK_COMM_ID_BYTES 128
+typedef struct wtk_comm wtk_comm;
+int wtk_comm_unique_id(uint8_t *id_out, size_t cap);
+int wtk_comm_create(wtk_comm **out, int32_t device, int32_t rank, int32_t world, const uint8_t *id);
+void wtk_comm_destroy(wtk_comm *c);
+int wtk_allgather_tracks(wtk_comm *c, const float *local_dev, int32_t n_local, float *all_dev, void *stream);
 
 #ifdef __cplusplus
 }

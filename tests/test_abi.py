@@ -54,6 +54,15 @@ def test_product_path_fails_loudly_without_gpu(hip_lib):
         hip.HipYolo(ys.synthetic_weights("n", 1), (64, 64), 1, width=0.25)
 
 
+def test_communicator_fails_loudly_without_gpu(hip_lib):
+    if hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(hip.WtkError, match="GPU"):
+        hip.WtkComm(0, 0, 1, bytes(hip.COMM_ID_BYTES))
+    with pytest.raises(hip.WtkError, match="128"):
+        hip.WtkComm(0, 0, 1, b"short")
+
+
 def test_no_product_module_imports_the_oracle():
     pkg = os.path.join(ROOT, "wtracker_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -86,3 +86,24 @@ def test_pipeline_baseline_targets_match_numpy_on_the_device_track(hip_lib, gold
         if ok.sum() >= 3:
             coef = poly.polyfit(np.asarray(times)[ok], cen[f[ok]], deg=2, w=np.asarray(weights)[ok])
             np.testing.assert_allclose(pf[c], poly.polyval(9 + 6 // 2, coef), rtol=0, atol=1e-6)
+
+
+def test_c_abi_communicator_single_rank_allgather(hip_lib):
+    """wtk_comm_* / wtk_allgather_tracks (the C ABI's own RCCL communicator) in the degenerate one-rank world a
+    one-GPU box allows: rendezvous token, communicator, an all-gather that must reproduce the local slice bit for bit
+    (NaN rows included), on a side stream.  RCCL refuses two ranks on one device, so N > 1 is covered by the gloo tests."""
+    uid = hip.comm_unique_id()
+    assert len(uid) == hip.COMM_ID_BYTES and any(uid)
+    comm = hip.WtkComm(0, 0, 1, uid)
+    local = torch.rand((64, 4), device="cuda")
+    local[5] = float("nan")
+    out = torch.zeros((64, 4), device="cuda")
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        comm.allgather_tracks(local, 64, out, stream=st.cuda_stream)
+    st.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), local.cpu().numpy())
+    with pytest.raises(hip.WtkError, match="rank"):
+        hip.WtkComm(0, 2, 2, uid)
+    comm.close()

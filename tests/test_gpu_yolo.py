@@ -132,6 +132,100 @@ def test_decode_and_selection_bit_exact_on_given_logits(hip_lib, dtype):
     np.testing.assert_allclose(xywh[5], [x1, y1, x2 - x1, y2 - y1], atol=1e-3)
 
 
+def _oracle_nms_rows(box, cls, net_hw, img_hw, conf, iou, max_det):
+    xywh, scores = yo.decode(torch.from_numpy(box), torch.from_numpy(cls), net_hw)
+    out = []
+    for n in range(box.shape[0]):
+        xyxy, sc, cl, idx = yo.nms(xywh[n], scores[n], conf, iou, max_det)
+        b = yo.scale_boxes(net_hw, xyxy, img_hw).numpy() if len(sc) else np.zeros((0, 4), np.float32)
+        out.append((np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1) if len(sc) else b, sc.numpy(), cl.numpy(), idx.numpy()))
+    return out
+
+
+@pytest.mark.parametrize("dtype,nc", [("fp32", 1), ("fp16", 1), ("fp32", 3)])
+def test_general_greedy_nms_on_given_logits(hip_lib, dtype, nc):
+    """SURVEY.md §8 a7 beyond the reference's max_det = 1: greedy IoU NMS on the device (wave-level arg-max + suppression sweep per kept
+    box) against the restated non_max_suppression (oracle/yolo_oracle.py: nms) on identical logits — kept anchor indices in
+    the same order, classes, counts; clusters of overlapping boxes, exact score ties, class-aware suppression, max_det cut-off,
+    frames with no candidate."""
+    size, B = 128, 5
+    _, det = _models("n", size, dtype, nc=nc)
+    A = det.anchors
+    rng = np.random.default_rng(10 + nc)
+    box = rng.normal(0, 1.0, size=(B, A, 64)).astype(np.float16).astype(np.float32)
+    cls = rng.normal(-6, 1.0, size=(B, A, nc)).astype(np.float16).astype(np.float32)
+    lw = size // 8
+    # frame 0: three clusters of neighbouring stride-8 anchors with sharp DFL peaks (boxes overlap heavily inside a cluster)
+    for cx, cy, s0 in ((3, 3, 4.0), (9, 4, 3.0), (5, 11, 2.0)):
+        for dx in range(3):
+            for dy in range(2):
+                i = (cy + dy) * lw + cx + dx
+                box[0, i] = -8.0
+                box[0, i, [3, 19, 35, 51]] = 8.0  # every side ~3 bins -> 48 px boxes, neighbours shifted by 8 px: IoU ~0.7-0.8
+                cls[0, i, 0] = s0 - 0.25 * (dx + 2 * dy)
+    # frame 1: exact score ties between far-apart anchors -> index order
+    for i in (17, 200, 90, 333):
+        cls[1, i, 0] = 2.0
+    cls[2] = -9.0                      # frame 2: nothing above conf
+    cls[3, :40, 0] = np.linspace(3, 1, 40).astype(np.float16)   # frame 3: 40 candidates in a row (max_det cut-off)
+    if nc > 1:                         # frame 4: the same box under two classes is kept twice (class-aware)
+        box[4, 100] = box[4, 101] = 0.0
+        cls[4, 100, 0] = 4.0
+        cls[4, 101, 2] = 3.5
+    else:
+        cls[4, 100, 0] = 4.0
+    for max_det, iou in ((300, 0.7), (5, 0.45), (1, 0.7)):
+        xywh, cf, kc, an, cnt = det.decode_nms_host(box, cls, size, size, max_det, conf=0.25, iou=iou)
+        want = _oracle_nms_rows(box, cls, (size, size), (size, size), 0.25, iou, max_det)
+        for n in range(B):
+            bw, sw, cw, iw = want[n]
+            assert cnt[n] == len(iw), (n, max_det, cnt[n], len(iw))
+            np.testing.assert_array_equal(an[n, : cnt[n]], iw)
+            np.testing.assert_array_equal(kc[n, : cnt[n]], cw)
+            np.testing.assert_allclose(cf[n, : cnt[n]], sw, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(xywh[n, : cnt[n]], bw, rtol=0, atol=1e-3)
+            assert np.isnan(xywh[n, cnt[n] :]).all() and (an[n, cnt[n] :] == -1).all() and (kc[n, cnt[n] :] == -1).all()
+        assert cnt[2] == 0
+        if max_det == 300:
+            assert 3 <= cnt[0] < 18 and cnt[3] > 5  # clusters collapse, a row of neighbours does not fully
+            if nc > 1:
+                assert {100, 101} <= set(an[4, : cnt[4]].tolist())
+        if max_det == 1:  # first row == the thresholded arg-max path
+            x1, c1, a1 = det.decode_host(box, cls, size, size, conf=0.25)
+            np.testing.assert_array_equal(a1, an[:, 0])
+            np.testing.assert_array_equal(x1, xywh[:, 0])
+
+
+def test_general_nms_through_the_network(hip_lib):
+    """wtk_yolo_predict_nms end to end (fp32, scale n): kept anchors / classes / counts equal to the restatement's NMS on the oracle's logits."""
+    size, B, max_det = 160, 3, 20
+    oracle, det = _models("n", size, "fp32", nc=2)
+    frames, _ = fr.synthetic_frames(B, size, seed=17)
+    box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
+    out = torch.full((B, max_det, 4), -1.0, device="cuda")
+    cf = torch.zeros((B, max_det), device="cuda")
+    kc = torch.zeros((B, max_det), dtype=torch.int32, device="cuda")
+    an = torch.zeros((B, max_det), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    conf = 0.02
+    det.predict_nms(torch.from_numpy(frames).cuda(), B, size, size, 1, max_det, out, cf, kc, an, cnt, conf=conf, iou=0.5,
+                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = _oracle_nms_rows(box_o.numpy(), cls_o.numpy(), (size, size), hw, conf, 0.5, max_det)
+    total = 0
+    for n in range(B):
+        bw, sw, cw, iw = want[n]
+        k = int(cnt[n])
+        assert k == len(iw)
+        np.testing.assert_array_equal(an[n, :k].cpu().numpy(), iw)
+        np.testing.assert_array_equal(kc[n, :k].cpu().numpy(), cw)
+        np.testing.assert_allclose(out[n, :k].cpu().numpy(), bw, rtol=0, atol=F32_BOX_ATOL)
+        total += k
+    assert total > B  # more than one box per frame somewhere
+    with pytest.raises(hip.WtkError, match="max_det"):
+        det.predict_nms(torch.from_numpy(frames).cuda(), B, size, size, 1, 0, out)
+
+
 def test_gray_and_bgr_inputs_agree_and_channel_order(hip_lib):
     size, B = 128, 2
     oracle, det = _models("n", size, "fp32")
@@ -168,7 +262,7 @@ def test_api_errors(hip_lib):
     frames, _ = fr.synthetic_frames(3, 128, seed=1)
     with pytest.raises(hip.WtkError, match="max_batch"):
         det.predict_host(frames)
-    with pytest.raises(hip.WtkError, match="max_det"):
+    with pytest.raises(hip.WtkError, match="wtk_yolo_predict_nms"):  # the controller entry point stays at the reference's max_det = 1
         det.predict_host(frames[:1], max_det=2)
     with pytest.raises(hip.WtkError, match="empty batch"):
         det.predict_host(frames[:0])

@@ -8,7 +8,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwtk_hip.so")
-SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip"]
+SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
 HEADERS = ["wtk_kernels.h", os.path.join("..", "..", "include", "wtk_hip.h")]
 
 
@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -31,6 +31,7 @@ static int fail_hip(const char *what, hipError_t e) {
         if (_e != hipSuccess) return fail_hip(#expr, _e);                                                                      \
     } while (0)
 
+int wtk_set_error(const std::string &msg) { return fail(msg); } // for the other translation units (comm.hip)
 extern "C" const char *wtk_last_error(void) { return g_err.c_str(); }
 extern "C" int wtk_abi_version(void) { return WTK_ABI_VERSION; }
 extern "C" int wtk_device_count(void) {
@@ -438,6 +439,9 @@ struct wtk_yolo {
     void *zero_page = nullptr;
     float *o_xywh = nullptr, *o_conf = nullptr;
     int *o_anchor = nullptr;
+    // scratch of the general NMS (max_det > 1), allocated at its first use
+    float *nms_score = nullptr, *nms_box = nullptr;
+    int *nms_cls = nullptr;
     // profiling
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
@@ -661,6 +665,9 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     for (void *p : h->dev_allocs) (void)hipFree(p);
     (void)hipFree(h->frames_dev);
     (void)hipFree(h->lb_dev);
+    (void)hipFree(h->nms_score);
+    (void)hipFree(h->nms_box);
+    (void)hipFree(h->nms_cls);
     for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; ++i)
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
@@ -999,7 +1006,14 @@ static void letterbox_geom(int H, int W, int Sh, int Sw, int &new_h, int &new_w,
     pad_y = (float)std::nearbyint((Sh - H * (double)gain) / 2.0 - 0.1);
 }
 
-static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xywh, float *out_conf, int *out_anchor, hipStream_t st) {
+// outputs of the general NMS path (max_det >= 1 rows per image)
+struct NmsOut {
+    float iou;
+    int max_det;
+    int *out_cls, *out_count;
+};
+static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xywh, float *out_conf, int *out_anchor, hipStream_t st,
+                    const NmsOut *nms = nullptr) {
     HeadArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int i = 0; i < 3; ++i) {
@@ -1019,7 +1033,26 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
     a.out_xywh = out_xywh;
     a.out_conf = out_conf;
     a.out_anchor = out_anchor;
+    if (nms) {
+        NmsArgs q;
+        q.h = a;
+        q.iou = nms->iou, q.max_det = nms->max_det;
+        q.scratch_score = h->nms_score, q.scratch_cls = h->nms_cls, q.scratch_box = h->nms_box;
+        q.out_xywh = out_xywh, q.out_conf = out_conf, q.out_anchor = out_anchor, q.out_cls = nms->out_cls, q.out_count = nms->out_count;
+        HIP_TRY(launch_head_nms(q, h->is_f16, st));
+        return 0;
+    }
     HIP_TRY(launch_head(a, h->is_f16, st));
+    return 0;
+}
+
+static int ensure_nms_scratch(wtk_yolo *h, hipStream_t st) {
+    if (h->nms_score) return 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t n = (size_t)h->max_batch * h->anchors;
+    HIP_TRY(hipMalloc(&h->nms_score, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->nms_cls, n * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->nms_box, n * 4 * sizeof(float)));
     return 0;
 }
 
@@ -1031,7 +1064,7 @@ struct ViewSrc {
     int view_w, view_h;
 };
 static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
-                        float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr) {
+                        float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr, const NmsOut *nms = nullptr) {
     const uint8_t *net_in = frames_dev;
     if (vs) {
         ViewLetterboxArgs va;
@@ -1253,7 +1286,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         HIP_TRY(hipStreamWaitEvent(main_st, h->side_done, 0));
     }
     if (mark(3)) return 1;
-    if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st)) return 1;
+    if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st, nms)) return 1;
     ++launches[3];
     if (h->profiling) {
         if (nev < wtk_yolo::kProfEvents) {
@@ -1279,7 +1312,7 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     if (B <= 0) return fail("wtk_yolo_predict: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
     if (B > h->max_batch) return fail("wtk_yolo_predict: batch exceeds max_batch");
     if (C != 1 && C != 3) return fail("wtk_yolo_predict: frames must have 1 (gray) or 3 (BGR) channels");
-    if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
+    if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it); wtk_yolo_predict_nms takes max_det > 1");
     if (H <= 0 || W <= 0) return fail("wtk_yolo_predict: bad frame size");
     DEVICE_GUARD(h);
     hipStream_t st = (hipStream_t)stream;
@@ -1320,6 +1353,28 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     h->graphs.push_back(e);
     HIP_TRY(hipGraphLaunch(e.exec, st));
     return 0;
+}
+
+extern "C" int wtk_yolo_predict_nms(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
+                                    int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls, int32_t *out_anchor, int32_t *out_count,
+                                    void *stream) {
+    if (!h || !frames_dev || !out_xywh) return fail("wtk_yolo_predict_nms: null argument");
+    if (B <= 0) return fail("wtk_yolo_predict_nms: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
+    if (B > h->max_batch) return fail("wtk_yolo_predict_nms: batch exceeds max_batch");
+    if (C != 1 && C != 3) return fail("wtk_yolo_predict_nms: frames must have 1 (gray) or 3 (BGR) channels");
+    if (max_det < 1 || max_det > 30000) return fail("wtk_yolo_predict_nms: max_det must be in [1, 30000]");
+    if (!(iou >= 0.f && iou <= 1.f)) return fail("wtk_yolo_predict_nms: iou must be in [0, 1]");
+    if (H <= 0 || W <= 0) return fail("wtk_yolo_predict_nms: bad frame size");
+    DEVICE_GUARD(h);
+    hipStream_t st = (hipStream_t)stream;
+    if ((H != h->S_h || W != h->S_w) && h->lb_cap == 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
+        h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
+    }
+    if (ensure_nms_scratch(h, st)) return 1;
+    const NmsOut nms{iou, max_det, out_cls, out_count};
+    return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, nullptr, &nms);
 }
 
 extern "C" int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t C,
@@ -1426,11 +1481,53 @@ extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B,
     return 0;
 }
 
+static int upload_head_logits(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B);
+
+extern "C" int wtk_yolo_decode_nms_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf, float iou,
+                                        int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls, int32_t *out_anchor, int32_t *out_count) {
+    if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch || max_det < 1) return fail("wtk_yolo_decode_nms_host: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (upload_head_logits(h, box_host, cls_host, B)) return 1;
+    if (ensure_nms_scratch(h, nullptr)) return 1;
+    const size_t rows = (size_t)B * max_det;
+    float *d_xywh = nullptr, *d_conf = nullptr;
+    int *d_cls = nullptr, *d_anchor = nullptr, *d_count = nullptr;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc(&d_xywh, rows * 16)) != hipSuccess || (e = hipMalloc(&d_conf, rows * 4)) != hipSuccess || (e = hipMalloc(&d_cls, rows * 4)) != hipSuccess ||
+        (e = hipMalloc(&d_anchor, rows * 4)) != hipSuccess || (e = hipMalloc(&d_count, (size_t)B * 4)) != hipSuccess) {
+        (void)hipFree(d_xywh), (void)hipFree(d_conf), (void)hipFree(d_cls), (void)hipFree(d_anchor), (void)hipFree(d_count);
+        return fail_hip("wtk_yolo_decode_nms_host: hipMalloc", e);
+    }
+    const NmsOut nms{iou, max_det, d_cls, d_count};
+    int rc = run_head(h, B, H, W, conf, d_xywh, d_conf, d_anchor, nullptr, &nms);
+    if (!rc) {
+        if ((e = hipMemcpy(out_xywh, d_xywh, rows * 16, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("wtk_yolo_decode_nms_host: copy", e);
+        if (!rc && out_conf && (e = hipMemcpy(out_conf, d_conf, rows * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
+        if (!rc && out_cls && (e = hipMemcpy(out_cls, d_cls, rows * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
+        if (!rc && out_anchor && (e = hipMemcpy(out_anchor, d_anchor, rows * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
+        if (!rc && out_count && (e = hipMemcpy(out_count, d_count, (size_t)B * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
+    }
+    (void)hipFree(d_xywh), (void)hipFree(d_conf), (void)hipFree(d_cls), (void)hipFree(d_anchor), (void)hipFree(d_count);
+    return rc;
+}
+
 extern "C" int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf,
                                     float *out_xywh, float *out_conf, int32_t *out_anchor) {
     if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch) return fail("wtk_yolo_decode_host: bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (upload_head_logits(h, box_host, cls_host, B)) return 1;
+    if (run_head(h, B, H, W, conf, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;
+    HIP_TRY(hipMemcpy(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost));
+    if (out_conf) HIP_TRY(hipMemcpy(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost));
+    if (out_anchor) HIP_TRY(hipMemcpy(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// scatter concatenated [B][A][.] fp32 logits into the per-level head buffers (storage dtype): the test hook behind the two
+// decode entry points
+static int upload_head_logits(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B) {
     // scatter the concatenated [B][A][.] logits into the per-level head buffers (storage dtype)
     const int A = h->anchors;
     size_t a0 = 0;
@@ -1454,9 +1551,5 @@ extern "C" int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host, const fl
         }
         a0 += Al;
     }
-    if (run_head(h, B, H, W, conf, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;
-    HIP_TRY(hipMemcpy(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost));
-    if (out_conf) HIP_TRY(hipMemcpy(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost));
-    if (out_anchor) HIP_TRY(hipMemcpy(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost));
     return 0;
 }

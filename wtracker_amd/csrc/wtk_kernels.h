@@ -312,6 +312,23 @@ struct HeadArgs {
 };
 hipError_t launch_head(const HeadArgs &a, int is_f16, hipStream_t stream);
 
+// General greedy IoU NMS (ultralytics non_max_suppression, class-aware, best class per anchor) for max_det >= 1: HeadArgs plus
+// the per-image scratch and the multi-row outputs.  out_* rows beyond count[n] are NaN / 0 / -1.
+struct NmsArgs {
+    HeadArgs h;        // logits, geometry, conf; h.out_* unused
+    float iou;
+    int max_det;
+    float *scratch_score; // [N][A]   candidate score, -inf once dead / never a candidate
+    int *scratch_cls;     // [N][A]   best class of the anchor
+    float *scratch_box;   // [N][A][4] net-space xyxy of the candidates
+    float *out_xywh;      // [N][max_det][4] image pixels
+    float *out_conf;      // [N][max_det]
+    int *out_cls;         // [N][max_det] or null
+    int *out_anchor;      // [N][max_det] or null
+    int *out_count;       // [N] or null
+};
+hipError_t launch_head_nms(const NmsArgs &a, int is_f16, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // ResMLP (mlp.hip)
 // ---------------------------------------------------------------------------------------------

@@ -53,6 +53,8 @@ SYMBOLS = [
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
     "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_yolo_get_kernel_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
     "wtk_yolo_predict_views", "wtk_track_median_centers", "wtk_track_polyfit", "wtk_track_training_pairs",
+    "wtk_yolo_predict_nms", "wtk_yolo_decode_nms_host",
+    "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
 ]
 
 
@@ -98,6 +100,13 @@ def load() -> C.CDLL:
     lib.wtk_track_median_centers.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp, vp]
     lib.wtk_track_polyfit.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, C.c_double, vp, vp, vp]
     lib.wtk_track_training_pairs.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.wtk_yolo_predict_nms.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
+    lib.wtk_yolo_decode_nms_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp]
+    lib.wtk_comm_unique_id.argtypes = [vp, C.c_size_t]
+    lib.wtk_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
+    lib.wtk_comm_destroy.argtypes = [vp]
+    lib.wtk_comm_destroy.restype = None
+    lib.wtk_allgather_tracks.argtypes = [vp, vp, i32, vp, vp]
     lib.wtk_yolo_predict_views.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -134,6 +143,43 @@ def crop_views(frames_dev, N: int, H: int, W: int, Cc: int, pos_xy_dev, view_w: 
     with replicate borders.  All arguments are device tensors / pointers."""
     _check(load().wtk_crop_views(_ptr(frames_dev), N, H, W, Cc, _ptr(pos_xy_dev), view_w, view_h, _ptr(views_dev),
                                  C.c_void_p(stream)), "wtk_crop_views")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the RCCL rendezvous token (128 bytes) to hand to every other rank out of band."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(load().wtk_comm_unique_id(buf, COMM_ID_BYTES), "wtk_comm_unique_id")
+    return bytes(buf)
+
+
+class WtkComm:
+    """The C ABI's own RCCL communicator (wtk_comm_*): one per rank, for callers that do not use torch.distributed."""
+
+    def __init__(self, device: int, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise WtkError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(load().wtk_comm_create(C.byref(self._h), device, rank, world, buf), "wtk_comm_create")
+        self.rank, self.world, self.device = rank, world, device
+
+    def allgather_tracks(self, local_dev, n_local: int, all_dev, stream: int = 0):
+        """all_dev[r * n_local : (r + 1) * n_local] = rank r's local_dev [n_local, 4] float32 (device tensors)."""
+        _check(load().wtk_allgather_tracks(self._h, _ptr(local_dev), n_local, _ptr(all_dev), C.c_void_p(stream)), "wtk_allgather_tracks")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().wtk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _track_is_f64(track_dev) -> int:
@@ -310,6 +356,27 @@ class HipYolo:
         """Device pointers / torch CUDA tensors; asynchronous on `stream`."""
         _check(load().wtk_yolo_predict(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh),
                                        _ptr(out_conf), _ptr(out_anchor), C.c_void_p(stream)), "wtk_yolo_predict")
+
+    def predict_nms(self, frames_dev, B: int, H: int, W: int, Cc: int, max_det: int, out_xywh, out_conf=None, out_cls=None, out_anchor=None,
+                    out_count=None, conf: float = 0.1, iou: float = 0.7, stream: int = 0):
+        """General greedy NMS, up to `max_det` boxes per frame (wtk_yolo_predict_nms); outputs [B,max_det,...] device tensors."""
+        _check(load().wtk_yolo_predict_nms(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh), _ptr(out_conf),
+                                           _ptr(out_cls), _ptr(out_anchor), _ptr(out_count), C.c_void_p(stream)), "wtk_yolo_predict_nms")
+
+    def decode_nms_host(self, box: np.ndarray, cls: np.ndarray, H: int, W: int, max_det: int, conf: float = 0.1, iou: float = 0.7):
+        """NMS on given head logits -> (xywh [B,max_det,4], conf [B,max_det], cls [B,max_det], anchor [B,max_det], count [B])."""
+        box = np.ascontiguousarray(box, dtype=np.float32)
+        cls = np.ascontiguousarray(cls, dtype=np.float32)
+        B = box.shape[0]
+        assert box.shape == (B, self.anchors, 64) and cls.shape == (B, self.anchors, self.nc)
+        xywh = np.empty((B, max_det, 4), dtype=np.float32)
+        cf = np.empty((B, max_det), dtype=np.float32)
+        kc = np.empty((B, max_det), dtype=np.int32)
+        an = np.empty((B, max_det), dtype=np.int32)
+        cnt = np.empty((B,), dtype=np.int32)
+        _check(load().wtk_yolo_decode_nms_host(self._h, _ptr(box), _ptr(cls), B, H, W, conf, iou, max_det, _ptr(xywh), _ptr(cf), _ptr(kc), _ptr(an),
+                                               _ptr(cnt)), "wtk_yolo_decode_nms_host")
+        return xywh, cf, kc, an, cnt
 
     def predict_views(self, frames_dev, n_frames: int, H: int, W: int, Cc: int, frame_index_dev, pos_xy_dev, B: int, view_w: int,
                       view_h: int, out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1, iou: float = 0.7, max_det: int = 1,

@@ -56,13 +56,16 @@ class ShardPlan:
         return int(np.searchsorted(key, f0, side="left")), int(np.searchsorted(key, f1, side="left"))
 
 
-def exchange_tracks(track: torch.Tensor, local_xywh: torch.Tensor, plan: ShardPlan, s: int, group=None):
+def exchange_tracks(track: torch.Tensor, local_xywh: torch.Tensor, plan: ShardPlan, s: int, group=None, comm=None, stream: int = 0):
     """The path's only collective: all-gather the ranks' [B,4] slices into the track rows of super-batch s
-    (rank order == frame order, so the gathered block is contiguous).  Backend-agnostic: RCCL on the GPUs,
-    gloo in the CPU tests."""
+    (rank order == frame order, so the gathered block is contiguous).  Through torch.distributed (RCCL on the GPUs, gloo in
+    the CPU tests) or, with `comm` (hip.WtkComm), through the C ABI's own RCCL communicator (wtk_allgather_tracks)."""
+    f0, f1 = plan.super_range(s)
+    if comm is not None:
+        comm.allgather_tracks(local_xywh, plan.B, track[f0:f1], stream=stream)
+        return
     import torch.distributed as dist
 
-    f0, f1 = plan.super_range(s)
     dist.all_gather_into_tensor(track[f0:f1].view(-1), local_xywh.contiguous().view(-1), group=group)
 
 
@@ -74,10 +77,10 @@ class TrackPipeline:
 
     def __init__(self, dets, mlp: hip.HipMLP, folded: FoldedResMLP, batch: int, total_frames: int,
                  imaging_frame_num: int, pred_frame_num: int, cycle_frame_num: int, conf: float = 0.1,
-                 rank: int = 0, world: int = 1, group=None, device: Optional[torch.device] = None):
+                 rank: int = 0, world: int = 1, group=None, device: Optional[torch.device] = None, comm=None):
         self.dets = list(dets) if isinstance(dets, (list, tuple)) else [dets]
         self.mlp, self.folded = mlp, folded
-        self.rank, self.world, self.group = rank, world, group
+        self.rank, self.world, self.group, self.comm = rank, world, group, comm
         self.conf = conf
         self.device = device or torch.device("cuda", self.dets[0].device)
         self.plan = ShardPlan(batch, world, total_frames, imaging_frame_num, pred_frame_num, cycle_frame_num)
@@ -112,7 +115,7 @@ class TrackPipeline:
             det.predict_views(frames_dev, frames_dev.shape[0], H, W, C, frame_index, pos_xy, self.plan.B, vw, vh, out, self.local_conf[lane],
                               self.local_anchor[lane], conf=self.conf, stream=st)
         if self.world > 1:
-            exchange_tracks(self.track, self.local_xywh[lane], self.plan, s, self.group)
+            exchange_tracks(self.track, self.local_xywh[lane], self.plan, s, self.group, self.comm, st)
         self.det_done[lane].record(torch.cuda.current_stream(self.device))
         lo, hi = self.plan.cycles(s)
         if hi > lo:
