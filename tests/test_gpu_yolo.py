@@ -658,6 +658,33 @@ def test_three_slab_counted_wait_schedule_equals_two_slab(hip_lib, monkeypatch, 
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("B,H,W", [(64, 640, 640), (24, 1280, 736), (33, 640, 512)])
+def test_weight_stationary_64ch_kernel_equals_window_kernel(hip_lib, monkeypatch, B, H, W):
+    """conv3x3_ws64_kernel (all nine 64x64 tap slabs resident in LDS, two wave groups alternating multiply / stage + epilogue, one
+    barrier per tile) against conv3x3_halo_kernel on the same layers (model.4 / model.15 bottlenecks; WTK_NO_WS64=1): same fragment
+    layouts, K order, bias-initialised accumulators and SiLU, so every head logit and result is bit-identical — on the BASELINE
+    shape, on a 3-strip geometry (160 x 92 maps), and with a batch that leaves the two groups of a block unequal tile counts;
+    two runs of the default build catch a missing wait as a run-to-run difference."""
+    w = ys.synthetic_weights("s", 1, seed=5)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(B + H).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    outs = []
+    for off in ("1", "0", "0"):
+        monkeypatch.setenv("WTK_NO_WS64", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        idx = [i for i, t in enumerate(ys.conv_table("s", 1)) if t["name"] == "model.4.m.1.cv2"][0]
+        outs.append((res, det.debug_head(min(B, 8)), det.debug_tensor(idx, min(B, 4))))
+        det.close()
+    ref_res, (ref_box, ref_cls), ref_t = outs[0]
+    for res, (box, cls), t in outs[1:]:
+        np.testing.assert_array_equal(t, ref_t)
+        np.testing.assert_array_equal(box, ref_box)
+        np.testing.assert_array_equal(cls, ref_cls)
+        for x, y in zip(res, ref_res):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3)])
 def test_fused_front_and_c2f_tail_match_oracle_layers(hip_lib, H, W, C):
     """Layer-level parity of the two fused kernels against the CPU restatement (not only through the head logits):

@@ -47,6 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB_PATH
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("WTK_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (-DWTK_*_STAMPS, -DWTK_WS64_ABLATE)
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))

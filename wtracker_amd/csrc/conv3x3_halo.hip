@@ -892,6 +892,285 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the final tile's duplicate requests must not outlive the block's LDS
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-stationary window kernel for the 64 -> 64 channel 3x3 layers (fp16: the c = 64 bottlenecks on the 80x80 maps).
+//
+// All nine tap slabs of such a layer are 9 x 64 x 64 x 2 B = 72 KiB: they fit LDS next to two window buffers, so they are
+// staged ONCE per persistent block and the main loop has no weight LDS-DMA and no per-tap barrier at all (the one change the
+// ablation of conv3x3_halo_kernel showed to shorten a tap, profiles/r01_notes.md).  The block is two GROUPS of four waves (one
+// wave of each group per SIMD).  A group owns a window buffer and walks its own tiles of 256 flat output pixels; per tile it
+//   P: multiplies — 18 (tap, k-half) steps of 16 MFMAs per wave (64 px x 64 cout wave tile, 0.5 ds_read_b128 per MFMA), fragment
+//      reads of step s+1 issued before the MFMAs of step s, no barrier, no vector-memory instruction in the stream;
+//   Q: requests the next tile's window (LDS-DMA, buffer form), runs the SiLU / residual epilogue of the tile just finished while
+//      those requests land, waits for them.
+// The groups alternate: while one multiplies the other is in Q, one s_barrier per interval (= per 288 MFMAs of a wave instead of
+// per 32).  The matrix pipe of a SIMD is fed by one wave at a time and never waits for an epilogue or a window.
+// Geometry, fragment layouts, K order (tap-major, two 32-deep halves), bias-initialised accumulators and SiLU are those of
+// conv3x3_halo_kernel<_Float16, 64, ...>: results are bit-identical (WTK_NO_WS64=1 switches back; tests compare).
+// LDS: 73 728 (weights) + 2 x 44 032 (344-row windows: strips of <= 41 columns) = 161 792 B of 163 840.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWsRows = 344;                 // window rows per group buffer (43 pieces of 8 rows)
+constexpr int kWsPiecesPerWave = 11;         // 43 pieces over the 4 waves of a group
+
+__global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
+    asm volatile("" ::"s"(a.in), "s"(a.w), "s"(a.bias), "s"(a.in_ld), "s"(a.in_coff), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Kpad), "s"(a.S), "s"(a.pitch),
+                 "s"(a.strips), "s"(a.d_strips.mul), "s"(a.d_strips.sh1), "s"(a.d_strips.sh2), "s"(a.d_pitch.mul), "s"(a.d_pitch.sh1), "s"(a.d_pitch.sh2),
+                 "s"(a.d_h1.mul), "s"(a.d_h1.sh1), "s"(a.d_h1.sh2), "s"(a.grid), "s"(a.blocks_per_strip));
+    using T = _Float16;
+    constexpr int TP = 4, TC = 4, NV = 16, WP = 64;
+    __shared__ __attribute__((aligned(16))) char wts[9 * 8192];
+    __shared__ __attribute__((aligned(16))) char win0[kWsRows * 128];
+    __shared__ __attribute__((aligned(16))) char win1[kWsRows * 128];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, gw = wave & 3; // group, wave inside the group (= pixel quarter of the group's tile)
+    const int lr = lane & 15, lg = lane >> 4;
+    const int pitch = a.pitch;
+    const int halo_rows = 256 + 2 * pitch + 2;
+    const int total = a.strips * a.blocks_per_strip; // one cout tile
+    const int NG = 2 * a.grid;                      // groups in the launch
+    const int g0 = 2 * (int)blockIdx.x;             // this block's first group id
+    // tiles of a group: v = g, g + NG, ... < total
+    const int nA = g0 < total ? (total - g0 + NG - 1) / NG : 0;
+    const int nB = g0 + 1 < total ? (total - g0 - 1 + NG - 1) / NG : 0;
+    const int n_mine = grp ? nB : nA;
+    const int intervals = 2 * nA > 2 * nB + 1 ? 2 * nA : 2 * nB + 1;
+    char *win = grp ? win1 : win0;
+
+    // ---- per-tile geometry (flat origin, strip, image base, window piece offsets)
+    struct Tile {
+        int o0, xs;
+        const char *img;
+        unsigned hoff[kWsPiecesPerWave];
+        unsigned hvalid;
+    };
+    auto setup_tile = [&](int k, Tile &tc) __attribute__((always_inline)) {
+        const int v = g0 + grp + k * NG;
+        const int xcd = v & 7, q8 = total >> 3, r8 = total & 7; // XCD-aware bijective remap (as conv3x3_halo_kernel)
+        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+        const int rb = (int)fdiv((unsigned)L, a.d_strips);
+        const int strip = L - rb * a.strips;
+        tc.o0 = rb * 256;
+        tc.xs = strip * a.S;
+        const int n_base = (int)fdiv(fdiv((unsigned)tc.o0, a.d_pitch), a.d_h1);
+        tc.img = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.in) + (long long)n_base * a.H * a.W * a.in_ld + a.in_coff);
+        // window rows of this wave's pieces gw, gw + 4, ...: lane L evaluates row L & 7 of piece slot L >> 3 in two rounds (slots 0..7, 8..10)
+        unsigned row_e[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int q = rr * 8 + (lane >> 3);
+            const int hr = (gw + 4 * q) * 8 + (lane & 7);
+            int pn, iy, ix;
+            const bool ok = q < kWsPiecesPerWave && hr < halo_rows && halo_in_coords(a, tc.o0 + hr, tc.xs, pn, iy, ix);
+            // 32-bit offsets relative to the window's first image: pixel index < 2^24, bytes per pixel < 2^24 -> full-rate 24-bit multiplies
+            const unsigned pixel = __umul24(__umul24((unsigned)(pn - n_base), (unsigned)a.H) + (unsigned)iy, (unsigned)a.W) + (unsigned)ix;
+            row_e[rr] = ok ? __umul24(pixel, (unsigned)(a.in_ld * (int)sizeof(T))) : 0xffffffffu;
+        }
+        const unsigned lc_term = (unsigned)((((lane & 7) ^ ((lane >> 3) & 7)) * 8) * (int)sizeof(T));
+        tc.hvalid = 0;
+#pragma unroll
+        for (int q = 0; q < kWsPiecesPerWave; ++q) {
+            const unsigned v2 = (unsigned)__builtin_amdgcn_ds_bpermute(((q & 7) * 8 + (lane >> 3)) * 4, (int)row_e[q >> 3]);
+            const bool ok = v2 != 0xffffffffu;
+            tc.hoff[q] = ok ? v2 + lc_term : 0u;
+            tc.hvalid |= ok ? (1u << q) : 0u;
+        }
+    };
+    auto stage_window = [&](const Tile &tc) __attribute__((always_inline)) {
+        const rsrc_t rs = make_rsrc(tc.img);
+#pragma unroll
+        for (int q = 0; q < kWsPiecesPerWave; ++q) {
+            const int piece = gw + 4 * q;
+            if (piece * 8 >= kWsRows) continue; // static after unrolling for q < 10; q == 10: waves 0..2 only (wave-uniform)
+            lds_dma16_buf(rs, ((tc.hvalid >> q) & 1u) ? tc.hoff[q] : 0xffffffffu, 0u, win + piece * 1024);
+        }
+    };
+
+    // ---- prologue: all nine weight slabs (every thread one 16-byte piece per tap) + group 0's first window
+    {
+        const int row = tid >> 3, wp = tid & 7;
+        const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+        const unsigned wvoff = (unsigned)(((long long)row * a.Kpad + (wp ^ key) * 8) * (long long)sizeof(T));
+        const rsrc_t rs = make_rsrc(a.w);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) lds_dma16_buf(rs, wvoff, (unsigned)(tap * 64 * (int)sizeof(T)), wts + tap * 8192 + (8 * wave) * 128);
+    }
+    Tile cur;
+    cur.o0 = cur.xs = 0, cur.img = nullptr, cur.hvalid = 0;
+    if (grp == 0 && n_mine > 0) {
+        setup_tile(0, cur);
+        stage_window(cur);
+    }
+    // accumulators start at the bias
+    floatx4 acc[TC][TP];
+    float biasv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) biasv[i] = a.bias[lg * NV + i];
+    auto arm_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){biasv[i * 4 + 0], biasv[i * 4 + 1], biasv[i * 4 + 2], biasv[i * 4 + 3]};
+    };
+    arm_acc();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // fragment addressing (conv3x3_halo_kernel, BN = 64)
+    const int wrow_l = (lr >> 2) * NV + (lr & 3);
+    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
+    const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
+    const int prow0 = gw * WP + lr;
+    T *out = reinterpret_cast<T *>(a.out);
+    const T *res = reinterpret_cast<const T *>(a.res);
+    const int cb = lg * NV;
+
+    auto load_frags = [&](int step, uint4 (&pf)[TP], uint4 (&wf)[TC]) __attribute__((always_inline)) { // step static after unrolling
+        const int tap = step >> 1, kh = step & 1;
+        const int base = prow0 + (tap / 3) * pitch + (tap % 3);
+        unsigned pa = base * 128 + ((lg ^ (base & 7)) << 4);
+        unsigned wa = tap * 8192 + wfrag0;
+        if (kh) pa ^= 64u, wa ^= 64u;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(win + pa + j * 2048);
+#pragma unroll
+        for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wts + wa + i * 512);
+    };
+    auto compute_tile = [&]() __attribute__((always_inline)) {
+        // Two fragment register sets: the eight ds_read_b128 of step s+1 are issued BETWEEN the MFMAs of step s (one read per two
+        // MFMAs), so a wave that has the SIMD's matrix pipe to itself never waits for LDS.  hipcc's scheduler otherwise sinks every
+        // read to just before its first use (one register set, the LDS latency exposed 18 times per tile): the sched_barrier /
+        // sched_group_barrier calls pin the order.
+        uint4 pf[2][TP], wf[2][TC];
+        if (a.slabs & 8) __builtin_amdgcn_s_setprio(3); // the multiplying wave wins the SIMD's issue arbitration; its partner (stage + epilogue) takes the gaps
+        load_frags(0, pf[0], wf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            if (s + 1 < 18) load_frags(s + 1, pf[(s + 1) & 1], wf[(s + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(wf[s & 1][i], pf[s & 1][j], acc[i][j], (T *)nullptr);
+            if (s + 1 < 18) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); // 2 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (a.slabs & 8) __builtin_amdgcn_s_setprio(0);
+    };
+    auto epilogue = [&](const Tile &tc) __attribute__((always_inline)) {
+        int pix_e, col_e;
+        halo_out_pixel(a, tc.o0 + gw * WP, tc.xs, lane, pix_e, col_e);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const long long pix = lane_fetch(j * 16 + lr, pix_e);
+            float v[NV];
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            if (pix < 0) continue;
+            if (a.act) {
+                wtk_silu_scaled_run<NV>(v);
+            }
+            if (res) {
+                float rv[NV];
+                load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] += rv[i];
+            }
+            store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
+        }
+    };
+
+    // ---- interval schedule: group g multiplies in intervals i with (i & 1) == g, the other group is in Q; one barrier per interval
+    Tile done; // tile whose accumulators are waiting for their epilogue
+    done = cur;
+#ifdef WTK_WS64_ABLATE
+    const bool stamp_on = a.dbg_stamps != nullptr && blockIdx.x < 2 && lane == 0;
+    unsigned long long *stamp = a.dbg_stamps + ((long long)blockIdx.x * 8 + wave) * 16 * 4;
+    if (stamp_on) stamp[16 * 4 - 1] = __builtin_amdgcn_s_memtime(); // slot 15.3: loop entry
+#endif
+    for (int i = 0; i < intervals; ++i) {
+#ifdef WTK_WS64_ABLATE
+        if (stamp_on && i < 15) stamp[i * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
+        if ((i & 1) == grp) {
+            const int k = (i - grp) >> 1;
+            if (k < n_mine) {
+#ifdef WTK_WS64_ABLATE
+                if (!(a.bm & 1))
+#endif
+                    compute_tile();
+                done = cur;
+            }
+        } else {
+            const int kprev = (i - 1 - grp) >> 1, knext = (i + 1 - grp) >> 1;
+            const bool has_prev = i - 1 - grp >= 0 && kprev < n_mine, has_next = knext < n_mine;
+            if (has_prev && (a.slabs & 16)) {
+#ifdef WTK_WS64_ABLATE
+                if (!(a.bm & 4))
+#endif
+                    epilogue(done);
+                arm_acc();
+            }
+            if (has_next) {
+                setup_tile(knext, cur);
+#ifdef WTK_WS64_ABLATE
+                if (!(a.bm & 2))
+#endif
+                    stage_window(cur); // the group finished reading its window before the last barrier
+            }
+            if (has_prev && !(a.slabs & 16)) {
+#ifdef WTK_WS64_ABLATE
+                if (!(a.bm & 4))
+#endif
+                    epilogue(done);
+                arm_acc();
+            }
+#ifdef WTK_WS64_ABLATE
+            if (stamp_on && i < 15) stamp[i * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef WTK_WS64_ABLATE
+        if (stamp_on && i < 15) stamp[i * 4 + 2] = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef WTK_WS64_ABLATE
+        if (stamp_on && i < 15) stamp[i * 4 + 3] = __builtin_amdgcn_s_memtime();
+#endif
+    }
+}
+
+hipError_t launch_ws64(HaloArgs a, int num_cus, hipStream_t stream) {
+    const long long tiles = (long long)a.strips * a.blocks_per_strip;
+    if (tiles <= 0 || tiles > 0x3fffffffLL || num_cus < 8) return hipErrorInvalidValue;
+    if (256 + 2 * a.pitch + 2 > kWsRows) return hipErrorInvalidValue;
+    a.d_nct = make_fastdiv(1u);
+    a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
+    a.d_strips = make_fastdiv((unsigned)a.strips);
+    a.d_pitch = make_fastdiv((unsigned)a.pitch);
+    a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
+    const long long cap = num_cus / 8 * 8; // one block per CU (158 KiB of LDS)
+    const long long want = (tiles + 1) / 2;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    a.grid = (int)grid;
+    hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(grid), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int num_cus, hipStream_t stream) {
     const long long tiles = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (tiles <= 0 || tiles > 0x3fffffffLL || num_cus < 8) return hipErrorInvalidValue;
@@ -945,6 +1224,21 @@ void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch
     *S = (W + *strips - 1) / *strips;
     *pitch = *strips == 1 ? *S + 1 : *S + 2; // one strip: the zero column right of a row is the one left of the next row
     *blocks_per_strip = (int)(((long long)N * (H + 1) * *pitch + bm - 1) / bm);
+}
+
+int ws64_rows_max() { return kWsRows; }
+
+bool ws64_eligible(int k, int stride, int cin, int cout, int cout_pad, int is_f16, bool has_out2, bool has_tail) {
+    return is_f16 && k == 3 && stride == 1 && cin == 64 && cout == 64 && cout_pad == 64 && !has_out2 && !has_tail;
+}
+
+hipError_t launch_conv3x3_ws64(const HaloArgs &a, int num_cus, hipStream_t stream) {
+    if (a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64 || a.out2 || a.tail_w || a.Kpad < 576 || a.Kpad % 64) return hipErrorInvalidValue;
+    if (a.in_ld % 8 || a.in_coff % 8 || a.out_ld % 8 || a.out_coff % 8) return hipErrorInvalidValue;
+    if (a.res && (a.res_ld % 8 || a.res_coff % 8)) return hipErrorInvalidValue;
+    if (a.pitch != (a.strips == 1 ? a.S + 1 : a.S + 2) || a.strips * a.S < a.W || (a.strips == 1 && a.S != a.W)) return hipErrorInvalidValue;
+    if ((long long)a.blocks_per_strip * 256 < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
+    return launch_ws64(a, num_cus, stream);
 }
 
 int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : (cout_stored % 192 == 0 ? 192 : 64); }

@@ -43,6 +43,16 @@ extern "C" int wtk_device_count(void) {
     return n;
 }
 
+#ifdef WTK_WS64_ABLATE // diagnostic builds: per-wave interval stamps of the kernel under study (tools/gpu_sessions/ws64_stamps.py)
+static unsigned long long *g_dbg_stamps = nullptr;
+constexpr size_t kDbgStampBytes = 1 << 20;
+extern "C" int wtk_debug_stamps(unsigned long long *host, size_t n_words) {
+    if (!g_dbg_stamps || n_words * 8 > kDbgStampBytes) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpy(host, g_dbg_stamps, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+
 // Kernel attributes (dynamic LDS above 64 KiB) are per device: initialise them once for every device a handle is created on.
 static unsigned long long g_attr_done = 0; // bit d = device d initialised
 static int ensure_attributes(int device) {
@@ -449,6 +459,7 @@ struct wtk_yolo {
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
+    int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
     int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
     int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
@@ -715,6 +726,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
+    if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -1247,7 +1259,25 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
                 const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
-                if (op.halo == 2) {
+                bool ws64 = false;
+                if (op.halo == 1 && h->use_ws64 && h->halo_slabs == 3 &&
+                    ws64_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, h->is_f16, op.out2_buf >= 0, op.tail_op >= 0)) {
+                    halo_geometry_stacked(B, ib.h, ib.w, ws64_rows_max(), &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
+                    // worth it when every group of a persistent block gets at least two tiles (weights are staged once per block)
+                    ws64 = (long long)g.strips * g.blocks_per_strip >= 4LL * h->num_cus;
+                }
+                if (ws64) {
+                    g.zeros = h->zero_page;
+                    if (const char *e = std::getenv("WTK_WS64_ABLATE")) g.bm = std::atoi(e); // timing-only switches of -DWTK_WS64_ABLATE builds
+                    if (const char *e = std::getenv("WTK_WS64_FLAGS")) g.slabs = std::atoi(e);  // 8: s_setprio around the multiply phase
+#ifdef WTK_WS64_ABLATE
+                    if (std::getenv("WTK_WS64_STAMPS")) {
+                        if (!g_dbg_stamps) HIP_TRY(hipMalloc(&g_dbg_stamps, kDbgStampBytes));
+                        g.dbg_stamps = g_dbg_stamps;
+                    }
+#endif
+                    HIP_TRY(launch_conv3x3_ws64(g, h->num_cus, st));
+                } else if (op.halo == 2) {
                     halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
                 } else {
                     halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
@@ -1261,7 +1291,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     }
                 }
                 g.zeros = h->zero_page;
-                if (op.halo == 2)
+                if (ws64) {
+                } else if (op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32(g, st));
                 else
                     HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));

@@ -179,6 +179,10 @@ void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, 
 void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256);
 int halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
+// weight-stationary form for 64 -> 64 channel layers (fp16): all nine slabs resident in LDS, two wave groups alternating multiply / stage+epilogue
+int ws64_rows_max();
+bool ws64_eligible(int k, int stride, int cin, int cout, int cout_pad, int is_f16, bool has_out2, bool has_tail);
+hipError_t launch_conv3x3_ws64(const HaloArgs &a, int num_cus, hipStream_t stream);
 // thin fp16 layers (Cin = 32, Cout <= 96): conv3x3_c32.hip
 bool c32_eligible(int k, int stride, int cin, int cout_stored, int is_f16, bool has_out2);
 hipError_t launch_conv3x3_c32(HaloArgs a, hipStream_t stream);
