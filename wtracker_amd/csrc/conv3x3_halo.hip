@@ -608,6 +608,21 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     T *out = reinterpret_cast<T *>(a.out);
     T *out2 = reinterpret_cast<T *>(a.out2);
     const T *res = reinterpret_cast<const T *>(a.res);
+    // the residual of all pixel tiles is requested before any arithmetic (junk pixels read pixel 0): one exposed memory latency
+    // per block instead of TP (variants with a 256-register budget only)
+    constexpr bool kHoistRes = MINW <= 2 && sizeof(T) == 2 && BN != 192 && !TAIL; // raw fp16 values: 8 VGPRs per pixel tile
+    half8 rres[kHoistRes ? TP : 1][kHoistRes ? NV / 8 : 1];
+    if constexpr (kHoistRes) {
+        if (res) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const long long pr = pixj[j];
+                const T *rp = res + (pr < 0 ? 0 : pr) * a.res_ld + a.res_coff + cb;
+#pragma unroll
+                for (int q = 0; q < NV / 8; ++q) rres[j][q] = *reinterpret_cast<const half8 *>(rp + 8 * q);
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const long long pix = pixj[TAIL ? 0 : j];
@@ -622,10 +637,15 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             wtk_silu_scaled_run<NV>(v);
         }
         if (res) {
-            float rv[NV];
-            load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+            if constexpr (kHoistRes) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] += rv[i];
+                for (int i = 0; i < NV; ++i) v[i] += (float)rres[j][i >> 3][i & 7];
+            } else {
+                float rv[NV];
+                load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] += rv[i];
+            }
         }
         store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
         if (out2) { // 2x nearest upsample: pixel (n, 2y+dy, 2X+dx) of the [2H][2W] map = 4*pix - 2X + 2W*dy + dx
@@ -853,6 +873,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 #pragma unroll
         for (int j = 0; j < TP; ++j) pixj[j] = lane_fetch(j * 16 + lr, pix_e), colj[j] = lane_fetch(j * 16 + lr, col_e);
         if (cb + NV <= a.Cout) {
+            // residual of all four pixel tiles, requested before any arithmetic (see conv3x3_halo_kernel); raw fp16: 8 VGPRs per tile
+            constexpr bool kHoistRes = sizeof(T) == 2 && BN == 128;
+            half8 rres[kHoistRes ? TP : 1][kHoistRes ? NV / 8 : 1];
+            if constexpr (kHoistRes) {
+                if (res) {
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        const T *rp = res + (pixj[j] < 0 ? 0 : (long long)pixj[j]) * a.res_ld + a.res_coff + cb;
+#pragma unroll
+                        for (int q = 0; q < NV / 8; ++q) rres[j][q] = *reinterpret_cast<const half8 *>(rp + 8 * q);
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const long long pix = pixj[j];
@@ -866,10 +899,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
                     wtk_silu_scaled_run<NV>(vv);
                 }
                 if (res) {
-                    float rv[NV];
-                    load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+                    if constexpr (kHoistRes) {
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) vv[i] += rv[i];
+                        for (int i = 0; i < NV; ++i) vv[i] += (float)rres[j][i >> 3][i & 7];
+                    } else {
+                        float rv[NV];
+                        load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) vv[i] += rv[i];
+                    }
                 }
                 store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, vv);
                 if (out2) {
@@ -1070,25 +1108,35 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
     auto epilogue = [&](const Tile &tc) __attribute__((always_inline)) {
         int pix_e, col_e;
         halo_out_pixel(a, tc.o0 + gw * WP, tc.xs, lane, pix_e, col_e);
+        long long pixj[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) pixj[j] = lane_fetch(j * 16 + lr, pix_e);
+        // the residual of ALL four pixel tiles is requested before any arithmetic (junk pixels read pixel 0): one exposed memory
+        // latency per tile instead of four — this phase is the long pole of an interval (stamped), every cycle it waits counts
+        half8 rraw[TP][2];
+        if (res) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const T *rp = res + (pixj[j] < 0 ? 0 : pixj[j]) * a.res_ld + a.res_coff + cb;
+                rraw[j][0] = *reinterpret_cast<const half8 *>(rp);
+                rraw[j][1] = *reinterpret_cast<const half8 *>(rp + 8);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            const long long pix = lane_fetch(j * 16 + lr, pix_e);
             float v[NV];
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
-            if (pix < 0) continue;
             if (a.act) {
                 wtk_silu_scaled_run<NV>(v);
             }
             if (res) {
-                float rv[NV];
-                load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
 #pragma unroll
-                for (int i = 0; i < NV; ++i) v[i] += rv[i];
+                for (int i = 0; i < NV; ++i) v[i] += (float)rraw[j][i >> 3][i & 7];
             }
-            store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
+            if (pixj[j] >= 0) store_run_h<NV>(out + pixj[j] * a.out_ld + a.out_coff + cb, v);
         }
     };
 
