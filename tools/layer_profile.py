@@ -155,6 +155,8 @@ def main():
             short = "c32"
         elif "conv1x1_wide" in kname:
             short = "wide256"
+        elif "ws64" in kname:
+            short = "ws64"
         elif "halo" in kname:
             m = re.search(r"Li(\d+)ELi(\d)ELi(\d)E", kname)
             short = f"halo{m.group(1)}/{m.group(2)}" if m else "halo"

@@ -21,6 +21,7 @@ SIMDS = 256 * 4
 
 
 def kernel_of(name: str) -> str:
+    name = name.replace("conv3x3_ws64", "conv3x3_halo")  # the weight-stationary 64-channel form counts with the window kernel
     for k in ("conv3x3_halo", "conv_igemm", "conv1x1_wide", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma"):
         if k in name:
             return k
@@ -67,7 +68,9 @@ def main():
             m = merged.setdefault(names.get(k, k), {"dur": 0})
             for kk, v in a.items():
                 m[kk] = m.get(kk, 0) + v
-        json.dump({"definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch duration x 2.4 GHz), rocprofv3 --pmc, single stream, one 64-frame forward",
+        from wtracker_amd import _build
+
+        json.dump({"src_sha": _build.source_sha(), "collected": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ..., one pass, single stream", "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch duration x 2.4 GHz), rocprofv3 --pmc, single stream, one 64-frame forward",
                    "per_kernel": {k: {"mfma_util": util(a), "mfma_instructions": a.get("SQ_INSTS_MFMA", 0.0), "wait_any_share": a.get("SQ_WAIT_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 1.0), 1.0)}
                                   for k, a in merged.items()}, "whole_forward": util(tot)}, open(sys.argv[2], "w"), indent=1)
     print("\n# per op")

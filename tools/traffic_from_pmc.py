@@ -43,7 +43,7 @@ def main():
         if kind in ("conv", "fused"):
             total += b
             n += 1
-        kn = rf["Kernel_Name"]
+        kn = rf["Kernel_Name"].replace("conv3x3_ws64", "conv3x3_halo")  # the weight-stationary 64-channel form counts with the window kernel
         key = next((k for k in ("conv3x3_halo", "conv_igemm", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma") if k in kn), "head")
         if "conv1x1_wide" in kn:
             key = "conv_igemm"
@@ -54,7 +54,9 @@ def main():
         e["hbm_bytes_per_forward"] += b
     for e in per_kernel.values():
         e["hbm_bytes_per_launch_avg"] = e["hbm_bytes_per_forward"] / e["launches"]
-    print(json.dumps({"conv_launches": n, "hbm_bytes_per_forward": total, "hbm_bytes_per_launch_avg": total / n,
+    from wtracker_amd import _build
+
+    print(json.dumps({"src_sha": _build.source_sha(), "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes, single stream", "conv_launches": n, "hbm_bytes_per_forward": total, "hbm_bytes_per_launch_avg": total / n,
                       "batch": a.batch, "correction": "FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE exact, KiB units",
                       "per_kernel": per_kernel, "per_op_bytes": per_op}, indent=1))
 
