@@ -135,13 +135,11 @@ def main():
     from wtracker_amd import frames as fr
     from wtracker_amd import yolo_spec as ys
 
-    # The library is built BEFORE any rendezvous: at N = 1 a stale library is rebuilt here; at N > 1 every rank
-    # refuses to run on a stale one (a half-written .so must never be loaded by a sibling rank) — __graft_entry__.build() first.
-    if not os.environ.get("WTK_HIP_LIB") and _build.needs_build():
-        if world == 1:
-            _build.build(verbose=False)
-        else:
-            raise SystemExit("libwtk_hip.so is missing or older than its sources: run `python __graft_entry__.py` before a multi-rank bench")
+    # The library is (re)built BEFORE any rendezvous, serialised over the ranks of the node by a file lock (_build.ensure_built): a
+    # stale or missing .so is compiled by the first rank through the lock, a compiler error makes every rank exit non-zero, and
+    # no rank can sit in a barrier waiting for a build that failed.  WTK_HIP_LIB (another build on purpose) skips the check.
+    if not os.environ.get("WTK_HIP_LIB"):
+        _build.ensure_built(verbose=False)
     if args.backend != "nccl" and torch.cuda.device_count() <= local_rank:
         local_rank = 0  # rehearsal: ranks share the one visible GPU
     torch.cuda.set_device(local_rank)

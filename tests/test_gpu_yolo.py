@@ -685,6 +685,41 @@ def test_weight_stationary_64ch_kernel_equals_window_kernel(hip_lib, monkeypatch
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("B,H,W", [(64, 640, 640), (3, 352, 224), (9, 1280, 736)])
+def test_stride2_window_kernel_matches_implicit_gemm(hip_lib, monkeypatch, B, H, W):
+    """conv3x3_s2_kernel (strided 3x3 convs through an LDS-resident window of the four input parity planes) against the implicit-GEMM
+    path (WTK_NO_S2WIN=1).  The window kernel walks K chunk-major / plane-major, the implicit GEMM tap-major: the same products in
+    another fp32 summation order, so outputs agree to rounding, not bit for bit — model.5 / 7 / 16 / 19 outputs within two fp16 ulps of
+    their scale, head logits within 1 % of the logit scale, survivors equal except on near-ties; two default runs must be bit-identical (a missing
+    wait shows as a run-to-run difference).  Shapes: BASELINE (256- and 128-pixel blocks), ragged small maps, non-square 1280."""
+    w = ys.synthetic_weights("s", 1, seed=0)  # the calibrated seed: activations and logits stay O(1 .. 10)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(B * H + W).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    table = ys.conv_table("s", 1)
+    idx = {nm: [i for i, t in enumerate(table) if t["name"] == nm][0] for nm in ("model.5", "model.7", "model.16", "model.19")}
+    outs = []
+    for off in ("1", "0", "0"):
+        monkeypatch.setenv("WTK_NO_S2WIN", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        nb = min(B, 4)
+        outs.append((res, det.debug_head(nb), {nm: det.debug_tensor(i, nb) for nm, i in idx.items()}))
+        det.close()
+    (res_r, (box_r, cls_r), t_r), (res_a, (box_a, cls_a), t_a), (res_b, (box_b, cls_b), t_b) = outs
+    for x, y in zip(res_a, res_b):  # determinism of the window kernel
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(cls_a, cls_b)
+    for nm in idx:
+        scale = max(1.0, float(np.abs(t_r[nm]).max()))
+        err = float(np.abs(t_a[nm] - t_r[nm]).max())
+        assert err <= 2.0 * scale * 2.0 ** -10, (nm, err, scale)  # two fp16 ulps at the tensor's scale (inputs of later layers differ by an ulp already)
+    lscale = max(1.0, float(np.abs(cls_r).max()), float(np.abs(box_r).max()))
+    assert np.abs(cls_a - cls_r).max() < 0.01 * lscale and np.abs(box_a - box_r).max() < 0.01 * lscale
+    same = res_a[2] == res_r[2]
+    assert same.mean() >= 0.9
+    np.testing.assert_allclose(res_a[0][same & (res_r[2] >= 0)], res_r[0][same & (res_r[2] >= 0)], rtol=0, atol=0.05)
+
+
 @pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3)])
 def test_fused_front_and_c2f_tail_match_oracle_layers(hip_lib, H, W, C):
     """Layer-level parity of the two fused kernels against the CPU restatement (not only through the head logits):

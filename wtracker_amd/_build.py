@@ -71,5 +71,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+def ensure_built(verbose: bool = False) -> str:
+    """Build if stale, serialised over the processes of a node by an exclusive file lock: with N ranks starting together the
+    first one through the lock compiles, the others find a fresh library (or hit the same compiler error and exit non-zero too).
+    No rendezvous is involved, so a failed build can never leave ranks waiting in a barrier."""
+    import fcntl
+
+    if not needs_build():
+        return LIB_PATH
+    lock = os.path.join(PKG_DIR, ".build.lock")
+    with open(lock, "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            if needs_build():
+                build(force=False, verbose=verbose)
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+    return LIB_PATH
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

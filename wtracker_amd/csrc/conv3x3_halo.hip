@@ -136,6 +136,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -1219,6 +1223,236 @@ hipError_t launch_ws64(HaloArgs a, int num_cus, hipStream_t stream) {
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / STRIDE-2 convolution with an LDS-resident window (fp16, 128-cout tile): model.5 / 7 / 16 / 19 of YOLOv8s.
+//
+// The implicit-GEMM kernel re-stages the pixel operand for each of the nine taps (one LDS-DMA request per 4 MFMAs and wave).
+// Here the input is read as its four PARITY PLANES: plane (py, px) holds input pixels (2Y + py, 2X + px), i.e. one pixel per
+// output pixel, and in plane coordinates the stride-2 conv is a stride-1 conv whose taps are 1-D shifts of the flat window —
+// exactly the geometry of conv3x3_halo_kernel on the OUTPUT map (stacked images, one shared zero row, pitch = Wo + 1).
+// Output (y, x) needs input rows 2y-1, 2y, 2y+1 = plane rows (y-1, py=1), (y, py=0), (y, py=1), columns alike, so
+//   plane (1,1) serves 4 taps (kh, kw in {0, 2}), planes (0,1) and (1,0) two each, plane (0,0) one (kh = kw = 1): 9 in all.
+// A 64-channel chunk of one plane is staged ONCE (its per-lane request addresses gather the plane out of the NHWC tensor:
+// the plane's offset is a wave-uniform constant on top of plane (0,0)'s per-row offsets) and multiplied by 1 / 2 / 2 / 4 taps:
+// 2.25 taps per staged window instead of 1.  Weight slabs: the three-slab ring of conv3x3_halo_kernel (slab of step g+2
+// requested in step g, counted vmcnt).  Window pieces are requested ahead of the slab pieces of a step, so "all but the slab
+// requests of this step" (vmcnt(WR)) at the last tap of a plane means the next plane's window has landed.
+// K is walked chunk-major / plane-major (the implicit-GEMM kernel: tap-major), so results equal that kernel's up to fp32
+// summation order, not bit for bit (WTK_NO_S2WIN=1 switches back; tests compare within one fp16 ulp of the activations' scale).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kS2Rows = 344; // window rows per buffer (43 pieces): BMT + (Wo + 1) + 2 <= 344  ->  Wo <= 85 at BMT = 256
+
+template <int BMT>
+__global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
+    asm volatile("" ::"s"(a.in), "s"(a.w), "s"(a.bias), "s"(a.in_ld), "s"(a.in_coff), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Cin), "s"(a.CoutPad), "s"(a.Kpad),
+                 "s"(a.S), "s"(a.pitch), "s"(a.d_pitch.mul), "s"(a.d_pitch.sh1), "s"(a.d_pitch.sh2), "s"(a.d_nct.mul), "s"(a.d_nct.sh1), "s"(a.d_nct.sh2),
+                 "s"(a.d_h1.mul), "s"(a.d_h1.sh1), "s"(a.d_h1.sh2), "s"(a.grid));
+    using T = _Float16;
+    constexpr int BN = 128, WAVES_C = 2, WAVES_P = 4, WC = 64, WP = BMT / WAVES_P, TP = WP / 16, TC = 4, NV = 16, WR = 2;
+    constexpr int kPieces = kS2Rows / 8;              // 43
+    constexpr int KW = (kPieces + 7) / 8;             // window pieces per wave (6)
+    __shared__ __attribute__((aligned(16))) char win0[kS2Rows * 128];
+    __shared__ __attribute__((aligned(16))) char win1[kS2Rows * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf0[BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf1[BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf2[BN * 128];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_p = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nwg = a.grid;
+    int L;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int nct = a.CoutPad / BN;
+    const unsigned t = fdiv((unsigned)L, a.d_nct);
+    const int n0 = (L - (int)t * nct) * BN;
+    const int o0 = (int)t * BMT; // one strip: row blocks only
+    const int pitch = a.pitch;   // Wo + 1
+    const int halo_rows = BMT + pitch + 2;
+    const int Hin = 2 * a.H, Win = 2 * a.W; // a.H, a.W: OUTPUT map (the geometry lives there)
+    const int n_base = (int)fdiv(fdiv((unsigned)o0, a.d_pitch), a.d_h1);
+    const char *img = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.in) + (long long)n_base * Hin * Win * a.in_ld + a.in_coff);
+    const T *wgt = reinterpret_cast<const T *>(a.w);
+
+    // ---- window rows of this wave's pieces (wave, wave + 8, ...): byte offset of plane (0,0)'s pixel (2Y, 2X), evaluated once
+    unsigned hoff[KW];
+    unsigned hvalid = 0;
+    {
+        const int hr_e = (wave + 8 * (lane >> 3)) * 8 + (lane & 7);
+        int pn, Y, X;
+        const bool ok_e = (lane >> 3) < KW && hr_e < halo_rows && halo_in_coords(a, o0 + hr_e, 0, pn, Y, X);
+        const unsigned pixel = __umul24(__umul24((unsigned)(pn - n_base), (unsigned)Hin) + (unsigned)(2 * Y), (unsigned)Win) + (unsigned)(2 * X);
+        const unsigned row_e = ok_e ? __umul24(pixel, (unsigned)(a.in_ld * (int)sizeof(T))) : 0xffffffffu;
+        const unsigned lc_term = (unsigned)((((lane & 7) ^ ((lane >> 3) & 7)) * 8) * (int)sizeof(T));
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            const unsigned v = (unsigned)__builtin_amdgcn_ds_bpermute((q * 8 + (lane >> 3)) * 4, (int)row_e);
+            const bool ok = v != 0xffffffffu;
+            hoff[q] = ok ? v + lc_term : 0u;
+            hvalid |= ok ? (1u << q) : 0u;
+        }
+    }
+    const rsrc_t irs = make_rsrc(img);
+    // window piece q of this wave for plane (py, px), channel chunk c (never skipped: constant request count per step)
+    auto issue_piece = [&](char *buf, int q, int py, int px, int c) __attribute__((always_inline)) { // q static after unrolling
+        const bool back = q > 0 && wave + 8 * q >= kPieces; // wave-uniform: the last slot of the highest waves re-requests their previous piece
+        const int piece = __builtin_amdgcn_readfirstlane(back ? wave + 8 * (q - 1) : wave + 8 * q);
+        const unsigned off = back ? hoff[q > 0 ? q - 1 : 0] : hoff[q];
+        const bool ok = back ? ((hvalid >> (q > 0 ? q - 1 : 0)) & 1u) : ((hvalid >> q) & 1u);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((((py * Win + px) * a.in_ld) + c * 64) * (int)sizeof(T)); // wave-uniform
+        lds_dma16_buf(irs, ok ? off : 0xffffffffu, so, buf + piece * 1024);
+    };
+    const int wrow0 = tid >> 3, wp = tid & 7;
+    unsigned wvoff[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int row = wrow0 + 64 * i;
+        const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+        wvoff[i] = (unsigned)(((long long)row * a.Kpad + (wp ^ key) * 8) * (long long)sizeof(T));
+    }
+    const rsrc_t wrs = make_rsrc(wgt + (long long)n0 * a.Kpad);
+    auto issue_weights = [&](char *buf, int tap, int c) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)((tap * a.Cin + c * 64) * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < WR; ++i) lds_dma16_buf(wrs, wvoff[i], so, buf + (64 * i + 8 * wave) * 128);
+    };
+
+    const int cb = n0 + wave_c * WC + lg * NV;
+    floatx4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const floatx4 b4 = (floatx4){a.bias[cb + i * 4 + 0], a.bias[cb + i * 4 + 1], a.bias[cb + i * 4 + 2], a.bias[cb + i * 4 + 3]};
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = b4;
+    }
+    const int wrow_l = wave_c * WC + (lr >> 2) * NV + (lr & 3);
+    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
+    const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
+    const int prow0 = wave_p * WP + lr;
+    auto compute_tap = [&](const char *win, const char *wb, int tapoff) __attribute__((always_inline)) {
+        const int base = prow0 + tapoff;
+        const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4);
+#pragma unroll
+        for (int kh2 = 0; kh2 < 2; ++kh2) {
+            const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
+            const unsigned wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
+            uint4 pf[TP], wf[TC];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(win + pa + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(wf[i], pf[j], acc[i][j], (T *)nullptr);
+        }
+    };
+
+    // ---- the nine steps of a channel chunk.  Plane order (1,1) [4 taps], (0,1) [2], (1,0) [2], (0,0) [1]; window buffers alternate per
+    // plane (even number of planes per chunk: the parity is static).  kStep*: static tables, indexed by the unrolled step.
+    //                         step:   0  1  2  3   4  5   6  7   8
+    constexpr int kStepTap[9] =      { 0, 2, 6, 8,  3, 5,  1, 7,  4};              // kh * 3 + kw of the packed weights
+    constexpr int kStepDY[9] =       {-1,-1, 0, 0,  0, 0, -1, 0,  0};
+    constexpr int kStepDX[9] =       {-1, 0,-1, 0, -1, 0,  0, 0,  0};
+    constexpr int kStepBuf[9] =      { 0, 0, 0, 0,  1, 1,  0, 0,  1};              // window buffer of the step's plane
+    constexpr int kStepReq[9] =      { 2, 2, 2, 0,  KW,0,  KW,0,  KW};             // next plane's window pieces requested in this step
+    constexpr int kStepReqFrom[9] =  { 0, 2, 4, 0,  0, 0,  0, 0,  0};              // first piece slot of that request
+    constexpr int kNextPy[9] =       { 0, 0, 0, 0,  1, 1,  0, 0,  1};              // plane whose window the step requests:
+    constexpr int kNextPx[9] =       { 1, 1, 1, 1,  0, 0,  0, 0,  1};              //   (0,1) (0,1) (0,1) - (1,0) - (0,0) - next chunk's (1,1)
+    static_assert(KW == 6, "request schedule written for six window pieces per wave");
+    const int nchunks = a.Cin / 64;
+
+    // ---- prologue: window of chunk 0 / plane (1,1) + slabs of steps 0 and 1
+#pragma unroll
+    for (int q = 0; q < KW; ++q) issue_piece(win0, q, 1, 1, 0);
+    issue_weights(wbuf0, kStepTap[0], 0);
+    issue_weights(wbuf1, kStepTap[1], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // one step; S is a compile-time constant so that every table entry, buffer choice and request count folds
+    auto step = [&](auto s_tag, int c, bool more) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_tag)::value;
+        const char *wcur = S % 3 == 0 ? wbuf0 : (S % 3 == 1 ? wbuf1 : wbuf2);
+        char *wnext2 = (S + 2) % 3 == 0 ? wbuf0 : ((S + 2) % 3 == 1 ? wbuf1 : wbuf2);
+        const char *wcur_win = kStepBuf[S] ? win1 : win0;
+        char *wnext_win = kStepBuf[S] ? win0 : win1;
+        compute_tap(wcur_win, wcur, (kStepDY[S] + 1) * pitch + (kStepDX[S] + 1));
+        // requests after the step's reads and MFMAs; window pieces BEFORE slab pieces (they are the older ones for the counted wait)
+        const int cn = S == 8 ? (more ? c + 1 : c) : c;
+        if constexpr (kStepReq[S] > 0) {
+#pragma unroll
+            for (int q = 0; q < kStepReq[S]; ++q) issue_piece(wnext_win, kStepReqFrom[S] + q, kNextPy[S], kNextPx[S], cn);
+        }
+        if constexpr (S < 7)
+            issue_weights(wnext2, kStepTap[S + 2], c);
+        else
+            issue_weights(wnext2, kStepTap[S - 7], more ? c + 1 : c);
+        // last step of a plane (3, 5, 7, 8): everything but this step's slab requests has landed -> the next plane's window is complete
+        constexpr bool plane_end = S == 3 || S == 5 || S == 7 || S == 8;
+        wait_vmcnt(plane_end ? WR : WR + kStepReq[S]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        step(std::integral_constant<int, 0>{}, c, more);
+        step(std::integral_constant<int, 1>{}, c, more);
+        step(std::integral_constant<int, 2>{}, c, more);
+        step(std::integral_constant<int, 3>{}, c, more);
+        step(std::integral_constant<int, 4>{}, c, more);
+        step(std::integral_constant<int, 5>{}, c, more);
+        step(std::integral_constant<int, 6>{}, c, more);
+        step(std::integral_constant<int, 7>{}, c, more);
+        step(std::integral_constant<int, 8>{}, c, more);
+    }
+
+    // ---- epilogue (bias already in the accumulators)
+    int pix_e, col_e;
+    halo_out_pixel(a, o0 + wave_p * WP, 0, lane, pix_e, col_e);
+    long long pixj[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) pixj[j] = lane_fetch(j * 16 + lr, pix_e);
+    T *out = reinterpret_cast<T *>(a.out);
+    if (cb + NV <= a.Cout) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            if (pixj[j] < 0) continue;
+            float v[NV];
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            if (a.act) {
+                wtk_silu_scaled_run<NV>(v);
+            }
+            store_run_h<NV>(out + pixj[j] * a.out_ld + a.out_coff + cb, v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last chunk's duplicate requests must not outlive the block's LDS
+}
+
+template <int BMT> hipError_t launch_s2(HaloArgs a, hipStream_t stream) {
+    const long long blocks = (long long)a.blocks_per_strip * (a.CoutPad / 128);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.d_nct = make_fastdiv((unsigned)(a.CoutPad / 128));
+    a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
+    a.d_strips = make_fastdiv(1u);
+    a.d_pitch = make_fastdiv((unsigned)a.pitch);
+    a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
+    a.grid = (int)blocks;
+    hipLaunchKernelGGL((conv3x3_s2_kernel<BMT>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int num_cus, hipStream_t stream) {
     const long long tiles = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (tiles <= 0 || tiles > 0x3fffffffLL || num_cus < 8) return hipErrorInvalidValue;
@@ -1272,6 +1506,20 @@ void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch
     *S = (W + *strips - 1) / *strips;
     *pitch = *strips == 1 ? *S + 1 : *S + 2; // one strip: the zero column right of a row is the one left of the next row
     *blocks_per_strip = (int)(((long long)N * (H + 1) * *pitch + bm - 1) / bm);
+}
+
+// stride-2 window kernel: a.H / a.W are the OUTPUT map; one strip (pitch = W + 1); a.bm = 128 selects the half-size block
+bool s2win_eligible(int k, int stride, int cin, int cout, int cout_pad, int is_f16, int wo, bool plain) {
+    return is_f16 && k == 3 && stride == 2 && cin % 64 == 0 && cout_pad % 128 == 0 && cout % 16 == 0 && plain && 256 + (wo + 1) + 2 <= kS2Rows;
+}
+
+hipError_t launch_conv3x3_s2(const HaloArgs &a, hipStream_t stream) {
+    if (a.Cin % 64 || a.CoutPad % 128 || a.Cout > a.CoutPad || a.Cout % 16 || a.out2 || a.tail_w || a.res || a.Kpad < 9 * a.Cin || a.Kpad % 64) return hipErrorInvalidValue;
+    if (a.in_ld % 8 || a.in_coff % 8 || a.out_ld % 8 || a.out_coff % 8) return hipErrorInvalidValue;
+    const int bm = a.bm == 128 ? 128 : 256;
+    if (a.strips != 1 || a.S != a.W || a.pitch != a.W + 1 || bm + a.pitch + 2 > kS2Rows) return hipErrorInvalidValue;
+    if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
+    return bm == 128 ? launch_s2<128>(a, stream) : launch_s2<256>(a, stream);
 }
 
 int ws64_rows_max() { return kWsRows; }

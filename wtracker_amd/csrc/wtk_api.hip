@@ -459,6 +459,7 @@ struct wtk_yolo {
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
+    int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
     int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
     int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
@@ -727,6 +728,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
+    if (const char *e = std::getenv("WTK_NO_S2WIN")) h->use_s2win = e[0] != '1';
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -1296,6 +1298,27 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     HIP_TRY(launch_conv3x3_c32(g, st));
                 else
                     HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
+            } else if (h->use_s2win && op.tail_op < 0 &&
+                       s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, h->is_f16, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0) &&
+                       ib.h == 2 * ob.h && ib.w == 2 * ob.w) {
+                // strided 3x3: parity-plane window kernel; the geometry lives on the OUTPUT map (stacked images, one strip)
+                HaloArgs g;
+                std::memset(&g, 0, sizeof(g));
+                g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
+                g.N = B, g.H = ob.h, g.W = ob.w, g.Cin = op.cin;
+                g.Cout = op.cout, g.CoutPad = op.cout_pad;
+                g.w = op.w, g.bias = op.bias;
+                g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
+                g.act = op.act, g.Kpad = op.Kpad;
+                g.S = ob.w, g.pitch = ob.w + 1, g.strips = 1;
+                g.bm = 256;
+                g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 255) / 256);
+                if (2LL * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus) { // small maps: half-size blocks fill the chip
+                    g.bm = 128;
+                    g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 127) / 128);
+                }
+                g.zeros = h->zero_page;
+                HIP_TRY(launch_conv3x3_s2(g, st));
             } else if (op.tail_op >= 0) { // implicit GEMM with the 1x1 behind it fused into its epilogue
                 const Op &t = h->ops[op.tail_op];
                 a.tail_w = t.w, a.tail_bias = t.bias, a.tail_kpad = t.Kpad, a.tail_act = t.act;

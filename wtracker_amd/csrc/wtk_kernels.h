@@ -179,6 +179,10 @@ void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, 
 void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256);
 int halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream);
+// 3x3 / stride-2 convs (fp16, 128-cout tiles) through an LDS-resident window of the four input parity planes; H / W of the args
+// are the OUTPUT map, `plain` = no residual / second output / fused tail / second source
+bool s2win_eligible(int k, int stride, int cin, int cout, int cout_pad, int is_f16, int wo, bool plain);
+hipError_t launch_conv3x3_s2(const HaloArgs &a, hipStream_t stream);
 // weight-stationary form for 64 -> 64 channel layers (fp16): all nine slabs resident in LDS, two wave groups alternating multiply / stage+epilogue
 int ws64_rows_max();
 bool ws64_eligible(int k, int stride, int cin, int cout, int cout_pad, int is_f16, bool has_out2, bool has_tail);
