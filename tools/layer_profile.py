@@ -157,6 +157,8 @@ def main():
             short = "wide256"
         elif "ws64" in kname:
             short = "ws64"
+        elif "conv3x3_s2" in kname:
+            short = "s2win"
         elif "halo" in kname:
             m = re.search(r"Li(\d+)ELi(\d)ELi(\d)E", kname)
             short = f"halo{m.group(1)}/{m.group(2)}" if m else "halo"

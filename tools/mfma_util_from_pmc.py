@@ -21,6 +21,8 @@ SIMDS = 256 * 4
 
 
 def kernel_of(name: str) -> str:
+    if "conv3x3_s2" in name:
+        return "conv3x3_s2"  # strided window kernel: its own row in the table, merged into the implicit-GEMM family in the JSON
     name = name.replace("conv3x3_ws64", "conv3x3_halo")  # the weight-stationary 64-channel form counts with the window kernel
     for k in ("conv3x3_halo", "conv_igemm", "conv1x1_wide", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma"):
         if k in name:
@@ -62,7 +64,8 @@ def main():
             return e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * e["dur"] * 1e-9 * 2.4e9)
 
         names = {"conv3x3_halo": "conv3x3_halo_kernel", "front_fused": "front_fused_kernel+c2f32_fused_kernel", "c2f32_fused": "front_fused_kernel+c2f32_fused_kernel",
-                 "conv_igemm": "conv_igemm_kernel+conv1x1_wide_kernel", "conv1x1_wide": "conv_igemm_kernel+conv1x1_wide_kernel"}
+                 "conv_igemm": "conv_igemm_kernel+conv1x1_wide_kernel", "conv1x1_wide": "conv_igemm_kernel+conv1x1_wide_kernel",
+                 "conv3x3_s2": "conv_igemm_kernel+conv1x1_wide_kernel"}
         merged = {}
         for k, a in agg.items():
             m = merged.setdefault(names.get(k, k), {"dur": 0})

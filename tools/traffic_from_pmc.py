@@ -43,7 +43,7 @@ def main():
         if kind in ("conv", "fused"):
             total += b
             n += 1
-        kn = rf["Kernel_Name"].replace("conv3x3_ws64", "conv3x3_halo")  # the weight-stationary 64-channel form counts with the window kernel
+        kn = rf["Kernel_Name"].replace("conv3x3_ws64", "conv3x3_halo").replace("conv3x3_s2", "conv_igemm")  # as wtk_yolo_get_kernel_profile counts them: the weight-stationary 64-channel form with the window kernel, the strided window kernel with the family of the implicit GEMM it replaces
         key = next((k for k in ("conv3x3_halo", "conv_igemm", "front_fused", "c2f32_fused", "conv3x3_c32", "sppf_pool", "stem_mfma") if k in kn), "head")
         if "conv1x1_wide" in kn:
             key = "conv_igemm"

@@ -1510,7 +1510,9 @@ void halo_geometry_stacked(int N, int H, int W, int rows_max, int *S, int *pitch
 
 // stride-2 window kernel: a.H / a.W are the OUTPUT map; one strip (pitch = W + 1); a.bm = 128 selects the half-size block
 bool s2win_eligible(int k, int stride, int cin, int cout, int cout_pad, int is_f16, int wo, bool plain) {
-    return is_f16 && k == 3 && stride == 2 && cin % 64 == 0 && cout_pad % 128 == 0 && cout % 16 == 0 && plain && 256 + (wo + 1) + 2 <= kS2Rows;
+    // cin >= 128: the 64-channel strided conv (model.3) keeps the implicit-GEMM kernel, whose fused-tail form (model.3 + model.4.cv1) must stay
+    // bit-identical to its stand-alone form (test_fused_kernels_equal_layer_by_layer switches the fusion off and on)
+    return is_f16 && k == 3 && stride == 2 && cin % 64 == 0 && cin >= 128 && cout_pad % 128 == 0 && cout % 16 == 0 && plain && 256 + (wo + 1) + 2 <= kS2Rows;
 }
 
 hipError_t launch_conv3x3_s2(const HaloArgs &a, hipStream_t stream) {
