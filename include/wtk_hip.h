@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WTK_ABI_VERSION 1
+#define WTK_ABI_VERSION 2 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_* (additive: every v1 entry point is unchanged) */
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */

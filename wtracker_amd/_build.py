@@ -30,12 +30,13 @@ def needs_build() -> bool:
 
 
 def source_sha() -> str:
-    """sha256[:16] over the kernel sources of libwtk_hip.so: the key that ties a committed rocprofv3 artefact under profiles/
-    to the build it was collected on (bench.py only quotes such a file when the key matches)."""
+    """sha256[:16] over the kernel sources of libwtk_hip.so (csrc/*.hip + csrc/wtk_kernels.h; the public C header only declares
+    entry points and is left out): the key that ties a committed rocprofv3 artefact under profiles/ to the build it was
+    collected on (bench.py only quotes such a file when the key matches)."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(SOURCES + ["wtk_kernels.h"]):
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
