@@ -91,7 +91,6 @@ template <int NV> __device__ __forceinline__ void store_run_h(float *p, const fl
 }
 
 constexpr int kBM = 256;
-constexpr int kHaloBytes = kHaloRowsMax * 128;
 
 // One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address).  RAW = true issues it from inline asm:
 // hipcc then does not know an LDS write is pending and inserts no vmcnt wait of its own in front of later ds_reads —
@@ -544,7 +543,12 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r];
-            if (lg * 8 < a.tail_cout) store_run_h<8>(tout + pix * a.tail_ld + a.tail_coff + lg * 8, v2); // padded couts are never stored
+            if (lg * 8 < a.tail_cout) { // padded couts are never stored
+                if (a.tail_f32)
+                    store_run_h<8>(reinterpret_cast<float *>(a.tail_out) + pix * a.tail_ld + a.tail_coff + lg * 8, v2); // head logits stay fp32
+                else
+                    store_run_h<8>(tout + pix * a.tail_ld + a.tail_coff + lg * 8, v2);
+            }
         }
         return;
     } else if constexpr (TAIL) {
@@ -604,7 +608,10 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r];
-                store_run_h<16>(tout + pix * a.tail_ld + a.tail_coff + lg * 16, v2);
+                if (a.tail_f32)
+                    store_run_h<16>(reinterpret_cast<float *>(a.tail_out) + pix * a.tail_ld + a.tail_coff + lg * 16, v2); // head logits stay fp32
+                else
+                    store_run_h<16>(tout + pix * a.tail_ld + a.tail_coff + lg * 16, v2);
             }
             return;
         }
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
         for (int rr = 0; rr < 2; ++rr) {
             const int q = rr * 8 + (lane >> 3);
             const int hr = (gw + 4 * q) * 8 + (lane & 7);
-            int pn, iy, ix;
+            int pn = 0, iy = 0, ix = 0;
             const bool ok = q < kWsPiecesPerWave && hr < halo_rows && halo_in_coords(a, tc.o0 + hr, tc.xs, pn, iy, ix);
             // 32-bit offsets relative to the window's first image: pixel index < 2^24, bytes per pixel < 2^24 -> full-rate 24-bit multiplies
             const unsigned pixel = __umul24(__umul24((unsigned)(pn - n_base), (unsigned)a.H) + (unsigned)iy, (unsigned)a.W) + (unsigned)ix;
@@ -1286,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
     unsigned hvalid = 0;
     {
         const int hr_e = (wave + 8 * (lane >> 3)) * 8 + (lane & 7);
-        int pn, Y, X;
+        int pn = 0, Y = 0, X = 0;
         const bool ok_e = (lane >> 3) < KW && hr_e < halo_rows && halo_in_coords(a, o0 + hr_e, 0, pn, Y, X);
         const unsigned pixel = __umul24(__umul24((unsigned)(pn - n_base), (unsigned)Hin) + (unsigned)(2 * Y), (unsigned)Win) + (unsigned)(2 * X);
         const unsigned row_e = ok_e ? __umul24(pixel, (unsigned)(a.in_ld * (int)sizeof(T))) : 0xffffffffu;

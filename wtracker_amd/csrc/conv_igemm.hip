@@ -535,7 +535,10 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
                     for (int e = 0; e < NV; ++e) v[e] += rv[e];
                 }
-                store_run<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
+                if (sizeof(T) == 2 && a.out_f32)
+                    store_run<NV>(reinterpret_cast<float *>(a.out) + pix * a.out_ld + a.out_coff + cb, v); // head logits stay fp32
+                else
+                    store_run<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
                 if (out2) {
                     const int Ho2 = a.Ho * 2, Wo2 = a.Wo * 2;
 #pragma unroll

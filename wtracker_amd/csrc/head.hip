@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void head_nms_kernel(const NmsArgs q) {
     __shared__ float ws[16];
     __shared__ int wi[16];
     __shared__ float kept[4];
-    __shared__ int kept_i, kept_c;
+    __shared__ int kept_i;
     int count = 0;
     for (int det = 0; det < q.max_det; ++det) {
         // ---- next survivor: highest live score, lowest index on ties
@@ -245,7 +245,6 @@ __global__ __launch_bounds__(1024) void head_nms_kernel(const NmsArgs q) {
             kept_i = bi;
             if (bi != 0x7fffffff) {
                 const int kc = cl[bi];
-                kept_c = kc;
                 const float x1 = bx[4 * bi], y1 = bx[4 * bi + 1], x2 = bx[4 * bi + 2], y2 = bx[4 * bi + 3];
                 const float offc = (float)kc * kNmsMaxWh;
                 kept[0] = x1 + offc, kept[1] = y1 + offc, kept[2] = x2 + offc, kept[3] = y2 + offc;

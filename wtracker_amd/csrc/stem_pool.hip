@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void view_letterbox_kernel(const ViewLetterbox
         for (int c = 0; c < a.C; ++c) d[c] = 114;
         return;
     }
-    const int f = a.frame_index ? a.frame_index[n] : n;
+    const int f = min(max(a.frame_index ? a.frame_index[n] : n, 0), a.F - 1); // a bad index must not become a bad address
     const uint8_t *s = a.frames + (long long)f * a.H * a.W * a.C;
     const int oy = a.pos_xy[2 * n + 1] - a.view_h / 2, ox = a.pos_xy[2 * n] - a.view_w / 2; // view origin in frame coordinates
     auto px = [&](int vr, int vc, int c) -> int { // view pixel through the replicate border

@@ -396,6 +396,7 @@ static int find_spec(const std::vector<ConvSpec> &v, const std::string &name) {
 struct Buf {
     size_t elems_per_image = 0; // h*w*C
     int h = 0, w = 0, C = 0;
+    int f32 = 0; // 1: stored as fp32 whatever the handle's dtype (the Detect outputs: head logits are never rounded to fp16)
     void *ptr = nullptr;
 };
 
@@ -851,6 +852,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         const int d2c = P.new_buf(fh[i], fw[i], dims.hc);
         h->box_buf[i] = P.new_buf(fh[i], fw[i], 64);
         h->cls_buf[i] = P.new_buf(fh[i], fw[i], h->cls_ld);
+        h->bufs[h->box_buf[i]].f32 = h->bufs[h->cls_buf[i]].f32 = 1;
         h->lh[i] = fh[i];
         h->lw[i] = fw[i];
         const size_t first_op = h->ops.size();
@@ -932,7 +934,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
 
     // ---- activation workspace: every tensor gets its own allocation (288 GB HBM: no liveness reuse needed)
     for (Buf &b : h->bufs) {
-        if (dev_alloc(h, &b.ptr, b.elems_per_image * (size_t)h->max_batch * h->esize)) {
+        if (dev_alloc(h, &b.ptr, b.elems_per_image * (size_t)h->max_batch * (b.f32 ? 4 : h->esize))) {
             wtk_yolo_destroy(h);
             return 1;
         }
@@ -1053,10 +1055,10 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
         q.iou = nms->iou, q.max_det = nms->max_det;
         q.scratch_score = h->nms_score, q.scratch_cls = h->nms_cls, q.scratch_box = h->nms_box;
         q.out_xywh = out_xywh, q.out_conf = out_conf, q.out_anchor = out_anchor, q.out_cls = nms->out_cls, q.out_count = nms->out_count;
-        HIP_TRY(launch_head_nms(q, h->is_f16, st));
+        HIP_TRY(launch_head_nms(q, 0, st)); // the Detect outputs are fp32 tensors in both modes
         return 0;
     }
-    HIP_TRY(launch_head(a, h->is_f16, st));
+    HIP_TRY(launch_head(a, 0, st)); // the Detect outputs are fp32 tensors in both modes
     return 0;
 }
 
@@ -1075,7 +1077,7 @@ static int ensure_nms_scratch(wtk_yolo *h, hipStream_t st) {
 // `vs` != nullptr: the batch rows are camera views of full frames (wtk_yolo_predict_views) — crop + letterbox in one kernel.
 struct ViewSrc {
     const int32_t *pos_xy, *frame_index;
-    int view_w, view_h;
+    int view_w, view_h, n_frames;
 };
 static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
                         float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr, const NmsOut *nms = nullptr) {
@@ -1084,6 +1086,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         ViewLetterboxArgs va;
         va.frames = frames_dev, va.frame_index = vs->frame_index, va.pos_xy = vs->pos_xy, va.dst = h->lb_dev;
         va.N = B, va.H = H, va.W = W, va.C = C;
+        va.F = vs->n_frames;
         va.view_w = vs->view_w, va.view_h = vs->view_h;
         va.rows = vs->view_w, va.cols = vs->view_h; // frame[y : y + w, x : x + h], view_controller.py:171
         va.Sh = h->S_h, va.Sw = h->S_w;
@@ -1214,6 +1217,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.out = ob.ptr;
             a.out_ld = ob.C;
             a.out_coff = op.out_coff;
+            a.out_f32 = ob.f32;
             if (op.out2_buf >= 0) {
                 a.out2 = h->bufs[op.out2_buf].ptr;
                 a.out2_ld = h->bufs[op.out2_buf].C;
@@ -1258,6 +1262,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     g.tail_w = t.w, g.tail_bias = t.bias, g.tail_kpad = t.Kpad;
                     g.tail_out = h->bufs[t.out_buf].ptr, g.tail_ld = h->bufs[t.out_buf].C, g.tail_coff = t.out_coff;
                     g.tail_cout = t.cout;
+                    g.tail_f32 = h->bufs[t.out_buf].f32;
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
                 const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
@@ -1449,7 +1454,7 @@ extern "C" int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, in
         HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
         h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
     }
-    const ViewSrc vs{pos_xy_dev, frame_index_dev, view_w, view_h};
+    const ViewSrc vs{pos_xy_dev, frame_index_dev, view_w, view_h, n_frames};
     return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, &vs);
 }
 
@@ -1493,19 +1498,14 @@ extern "C" int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float 
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t A = (size_t)h->lh[level] * h->lw[level];
-    std::vector<char> tmp;
     if (box_host) {
         const size_t n = (size_t)B * A * 64;
-        tmp.resize(n * h->esize);
-        HIP_TRY(hipMemcpy(tmp.data(), h->bufs[h->box_buf[level]].ptr, tmp.size(), hipMemcpyDeviceToHost));
-        to_f32(tmp.data(), box_host, n, h->is_f16);
+        HIP_TRY(hipMemcpy(box_host, h->bufs[h->box_buf[level]].ptr, n * 4, hipMemcpyDeviceToHost)); // fp32 in both modes
     }
     if (cls_host) {
         const size_t n = (size_t)B * A * h->cls_ld;
-        tmp.resize(n * h->esize);
-        HIP_TRY(hipMemcpy(tmp.data(), h->bufs[h->cls_buf[level]].ptr, tmp.size(), hipMemcpyDeviceToHost));
         std::vector<float> full(n);
-        to_f32(tmp.data(), full.data(), n, h->is_f16);
+        HIP_TRY(hipMemcpy(full.data(), h->bufs[h->cls_buf[level]].ptr, n * 4, hipMemcpyDeviceToHost)); // fp32 in both modes
         for (size_t i = 0; i < (size_t)B * A; ++i)
             for (int k = 0; k < h->dims.nc; ++k) cls_host[i * h->dims.nc + k] = full[i * h->cls_ld + k];
     }
@@ -1525,10 +1525,10 @@ extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B,
     if (out_cap < px * op->cout) return fail("wtk_yolo_debug_tensor: output buffer too small");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<char> tmp(px * b.C * h->esize);
+    std::vector<char> tmp(px * b.C * (b.f32 ? 4 : h->esize));
     HIP_TRY(hipMemcpy(tmp.data(), b.ptr, tmp.size(), hipMemcpyDeviceToHost));
     std::vector<float> full(px * b.C);
-    to_f32(tmp.data(), full.data(), full.size(), h->is_f16);
+    to_f32(tmp.data(), full.data(), full.size(), b.f32 ? 0 : h->is_f16);
     const float unscale = op->act ? 1.0f / kActScale : 1.0f; // SiLU outputs are stored log2(e)-scaled
     for (size_t i = 0; i < px; ++i)
         for (int k = 0; k < op->cout; ++k) out_host[i * op->cout + k] = full[i * b.C + op->out_coff + k] * unscale;
@@ -1593,16 +1593,8 @@ static int upload_head_logits(wtk_yolo *h, const float *box_host, const float *c
                 std::memcpy(&bx[((size_t)n * Al + j) * 64], &box_host[((size_t)n * A + a0 + j) * 64], 64 * sizeof(float));
                 for (int k = 0; k < h->dims.nc; ++k) cl[((size_t)n * Al + j) * h->cls_ld + k] = cls_host[((size_t)n * A + a0 + j) * h->dims.nc + k];
             }
-        if (h->is_f16) {
-            std::vector<uint16_t> hb(bx.size()), hc(cl.size());
-            for (size_t i = 0; i < bx.size(); ++i) hb[i] = f32_to_f16_bits(bx[i]);
-            for (size_t i = 0; i < cl.size(); ++i) hc[i] = f32_to_f16_bits(cl[i]);
-            HIP_TRY(hipMemcpy(h->bufs[h->box_buf[l]].ptr, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(h->bufs[h->cls_buf[l]].ptr, hc.data(), hc.size() * 2, hipMemcpyHostToDevice));
-        } else {
-            HIP_TRY(hipMemcpy(h->bufs[h->box_buf[l]].ptr, bx.data(), bx.size() * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(h->bufs[h->cls_buf[l]].ptr, cl.data(), cl.size() * 4, hipMemcpyHostToDevice));
-        }
+        HIP_TRY(hipMemcpy(h->bufs[h->box_buf[l]].ptr, bx.data(), bx.size() * 4, hipMemcpyHostToDevice)); // fp32 in both modes
+        HIP_TRY(hipMemcpy(h->bufs[h->cls_buf[l]].ptr, cl.data(), cl.size() * 4, hipMemcpyHostToDevice));
         a0 += Al;
     }
     return 0;

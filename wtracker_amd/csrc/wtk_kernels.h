@@ -122,6 +122,7 @@ struct ConvArgs {
     const float *tail_bias; // [128]
     void *tail_out;
     int tail_kpad, tail_ld, tail_coff, tail_act;
+    int out_f32; // fp16 kernels only: `out` is an fp32 tensor (the six Detect output convs: head logits are never rounded to fp16)
 };
 
 // Tile configurations (pixels x couts), all 4 waves / 256 threads
@@ -165,6 +166,7 @@ struct HaloArgs {
     void *tail_out;
     int tail_kpad, tail_ld, tail_coff;
     int tail_cout; // channels actually stored by the tail (multiple of 8; 64 for the box tower, cls_ld for the class tower)
+    int tail_f32;  // 1: tail_out is an fp32 tensor (head logits are kept in fp32 in both precision modes)
     int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
@@ -281,6 +283,7 @@ struct ViewLetterboxArgs {
     const int *pos_xy;      // [N][2] platform position (x, y)
     uint8_t *dst;           // [N][Sh][Sw][C] network input
     int N, H, W, C;
+    int F;                  // frames in the stack (frame indices are clamped to [0, F))
     int view_w, view_h;     // the (w, h) the reference passes to _custom_view
     int rows, cols;         // view shape: rows = w, cols = h (view_controller.py:171)
     int Sh, Sw;
