@@ -184,6 +184,19 @@ int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, int32_t W, i
                    void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Decision margin of every frame of the handle's last max_det = 1 call, in class-logit units:
+ *   min( best anchor's logit - best logit among all other anchors ,  | best logit - logit(conf) | )
+ * i.e. how far the result is from selecting another survivor or from flipping between a detection and a NaN row.  The fp16
+ * mode's head logits differ from the fp32 reference's by ~0.01: a frame whose margin is well above that has the fp32
+ * survivor; a caller that needs the reference's survivor on EVERY frame re-runs the few frames below its threshold on an fp32
+ * handle (wtracker_amd.controllers.YoloConfig.recheck_margin does).  No counterpart in the reference.
+ * wtk_yolo_margin_buffer: device pointer of the handle's [max_batch] float buffer (valid once the call's stream work is done);
+ * wtk_yolo_last_margins_host: synchronises the device and copies B values.
+ * ------------------------------------------------------------------------------------------ */
+int wtk_yolo_margin_buffer(wtk_yolo *h, const float **margins_dev);
+int wtk_yolo_last_margins_host(wtk_yolo *h, int32_t B, float *margins_host);
+
+/* ------------------------------------------------------------------------------------------
  * Detector with the GENERAL greedy NMS (max_det >= 1 boxes per frame): the part of ultralytics'
  * non_max_suppression(conf, iou, agnostic=False, max_det) that the reference's call site never reaches because it
  * hard-wires max_det = 1 (yolo_controller.py:76; yolo/yolo_train_config.yaml:49-50,61 give iou 0.7, max_det 300, class-aware).

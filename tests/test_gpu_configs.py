@@ -89,6 +89,47 @@ def test_fp16_accuracy_vs_fp32_oracle_at_640_b64(hip_lib, capsys):
     np.testing.assert_allclose(c32, co, rtol=0, atol=1e-4)
 
 
+def test_fp16_with_margin_recheck_restores_fp32_survivors(hip_lib, tmp_path):
+    """YoloConfig(dtype="fp16", recheck_margin=0.08): the detector reports every frame's decision margin (best vs second-best anchor
+    logit / distance to the conf threshold); frames below the margin are re-run by an fp32 handle.  On the 256-frame accuracy set the
+    fp32 restatement's survivor must come back on EVERY frame, with a minority of the frames re-run; the margins themselves are
+    checked against the oracle's top-2 logit gaps."""
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    size, N, B = 640, 256, 64
+    w = ys.synthetic_weights("s", 1, seed=0)
+    path = str(tmp_path / "s.wtk")
+    ys.save_weights(path, w, "s", 1)
+    depth, width, maxch = ys.SCALES["s"]
+    oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
+    frames = fr.diverse_frames(N, size, seed=1000)
+    xo, co, ao, gap = _oracle_run(oracle, frames, size, 0.1)
+    ec = ExperimentConfig("synthetic", N, 60, (size, size), 32, (size // 2, size // 2))
+    tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.5, 0.5))
+    plain = HipYoloController(tc, YoloConfig(model_path=path, pred_kwargs={"imgsz": size, "conf": 0.1}, dtype="fp16", max_batch=B))
+    guarded = HipYoloController(tc, YoloConfig(model_path=path, pred_kwargs={"imgsz": size, "conf": 0.1}, dtype="fp16", max_batch=B, recheck_margin=0.08))
+    rows_p, rows_g, rechecked, margins = [], [], 0, []
+    for i in range(0, N, B):
+        rows_p.append(np.asarray(plain.predict(list(frames[i : i + B])), dtype=np.float64))
+        margins.append(plain._model.detector((size, size), B).last_margins(B))
+        rows_g.append(np.asarray(guarded.predict(list(frames[i : i + B])), dtype=np.float64))
+        rechecked += guarded.last_rechecked
+    rows_p, rows_g, margins = np.concatenate(rows_p), np.concatenate(rows_g), np.concatenate(margins)
+    # margins track the oracle's own: min(top-1 / top-2 logit gap, distance of the best logit from logit(conf)), within the fp16 logit noise
+    best_logit = np.log(co.astype(np.float64) / (1.0 - co.astype(np.float64)))
+    want = np.minimum(gap, np.abs(best_logit - np.log(0.1 / 0.9)))
+    assert np.abs(margins - want).max() < 0.05 and (margins >= 0).all()
+    ok = ao >= 0
+    np.testing.assert_allclose(rows_g[ok], xo[ok], rtol=0, atol=1.0)  # the fp32 survivor's box (fp16 rows: IoU >= 0.997 -> well inside 1 px)
+    close = np.abs(rows_g[ok] - xo[ok]).max(axis=1) < 1.0
+    assert close.all()
+    n_plain_off = int((np.abs(rows_p[ok] - xo[ok]).max(axis=1) >= 1.0).sum())
+    assert 0 < rechecked < 0.4 * N, rechecked
+    print(f"\nrecheck: {rechecked} of {N} frames re-run in fp32; plain fp16 rows off by >= 1 px: {n_plain_off}, guarded: 0")
+
+
 @pytest.mark.parametrize("dtype,B", [("fp16", 2), ("fp32", 1)])
 def test_c5_full_size_1280_matches_oracle(hip_lib, dtype, B):
     """BASELINE config 5 frame shape (1280x1280, A = 33 600 anchors) against the restatement: head logits within the

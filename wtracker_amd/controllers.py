@@ -270,6 +270,11 @@ class YoloConfig:
     # 'fp16' is the opt-in throughput mode: 6.5x faster, ~97 % survivor-index match, IoU >= 0.997 on matched frames
     # (tests/test_gpu_configs.py::test_fp16_accuracy_vs_fp32_oracle_at_640_b64).
     dtype: str = "fp32"
+    # fp16 mode only: frames whose decision margin (best vs second-best anchor logit, or best logit vs the conf threshold; class-logit
+    # units, wtk_yolo_last_margins_host) is below this value are detected AGAIN by an fp32 handle, whose result replaces the row.
+    # The fp16 head logits are within ~0.01-0.02 of the fp32 ones, so a margin of 0.08 restores the fp32 restatement's survivor
+    # on every frame of the 256-frame accuracy set (tests/test_gpu_configs.py) while ~20 % of the frames are re-run.  0 = off.
+    recheck_margin: float = 0.0
     scale: str = "s"
     max_batch: int = 64
     model: Any = field(default=None, init=False, repr=False)
@@ -298,15 +303,17 @@ class _YoloModel:
         self.weights, self.nc = yolo_spec.load_weights(cfg.model_path)
         self._dets: dict = {}
 
-    def detector(self, net_hw: tuple, batch: int) -> hip.HipYolo:
-        det = self._dets.get(net_hw)
+    def detector(self, net_hw: tuple, batch: int, dtype: Optional[str] = None) -> hip.HipYolo:
+        dtype = dtype or self.cfg.dtype
+        key = (net_hw, dtype)
+        det = self._dets.get(key)
         if det is None or det.max_batch < batch:
             if det is not None:
                 det.close()
             width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
-            det = hip.HipYolo(self.weights, net_hw, max(batch, self.cfg.max_batch), dtype=self.cfg.dtype, nc=self.nc,
+            det = hip.HipYolo(self.weights, net_hw, max(batch, self.cfg.max_batch), dtype=dtype, nc=self.nc,
                               width=width, depth=depth, max_channels=maxch, device=self.cfg.device_index())
-            self._dets[net_hw] = det
+            self._dets[key] = det
         return det
 
 
@@ -325,6 +332,7 @@ class HipYoloController(SimController):
         self._camera_frames = deque(maxlen=timing_config.cycle_frame_num)
         self._model = yolo_config.load_model()
         self._device_frames = device_frames
+        self.last_rechecked = 0  # frames of the last predict call that were re-run in fp32 (YoloConfig.recheck_margin)
         if device_frames is not None:
             if not getattr(device_frames, "is_cuda", False) or str(device_frames.dtype) != "torch.uint8" or device_frames.dim() not in (3, 4):
                 raise hip.WtkError("device_frames must be a CUDA uint8 tensor [F,H,W] or [F,H,W,3]")
@@ -361,6 +369,13 @@ class HipYoloController(SimController):
         net_hw = yolo_spec.letterbox_shape(H, W, imgsz)
         det = self._model.detector(net_hw, batch.shape[0])
         xywh, _, anchor = det.predict_host(batch, conf=conf, iou=iou, max_det=1)
+        self.last_rechecked = 0
+        if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
+            weak = np.nonzero(det.last_margins(batch.shape[0]) < self.yolo_config.recheck_margin)[0]
+            if len(weak):  # ambiguous frames: the reference's precision decides
+                x32, _, a32 = self._model.detector(net_hw, len(weak), dtype="fp32").predict_host(batch[weak], conf=conf, iou=iou, max_det=1)
+                xywh[weak], anchor[weak] = x32, a32
+                self.last_rechecked = len(weak)
         if (anchor < 0).any():
             out = xywh.astype(np.float64)
             out[anchor < 0] = np.nan
@@ -388,10 +403,23 @@ class HipYoloController(SimController):
         cf = torch.empty((n,), dtype=torch.float32, device=dev)
         an = torch.empty((n,), dtype=torch.int32, device=dev)
         C = fr.shape[3] if fr.dim() == 4 else 1
+        net_hw = yolo_spec.letterbox_shape(vw, vh, imgsz)
         with torch.cuda.device(dev):
             det.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx, pos, n, vw, vh, out, cf, an, conf=conf, iou=iou, max_det=1,
                               stream=torch.cuda.current_stream(dev).cuda_stream)
         xywh, anchor = out.cpu().numpy(), an.cpu().numpy()
+        self.last_rechecked = 0
+        if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
+            weak = np.nonzero(det.last_margins(n) < self.yolo_config.recheck_margin)[0]
+            if len(weak):
+                wsel = torch.from_numpy(weak).to(dev)
+                det32 = self._model.detector(net_hw, len(weak), dtype="fp32")
+                k = len(weak)
+                with torch.cuda.device(dev):
+                    det32.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx[wsel].contiguous(), pos[wsel].contiguous(), k, vw, vh,
+                                        out[:k], cf[:k], an[:k], conf=conf, iou=iou, max_det=1, stream=torch.cuda.current_stream(dev).cuda_stream)
+                xywh[weak], anchor[weak] = out[:k].cpu().numpy(), an[:k].cpu().numpy()
+                self.last_rechecked = k
         if (anchor < 0).any():
             res = xywh.astype(np.float64)
             res[anchor < 0] = np.nan

@@ -26,8 +26,17 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
     const int A0 = a.lh[0] * a.lw[0], A1 = a.lh[1] * a.lw[1], A2 = a.lh[2] * a.lw[2];
     const int A = A0 + A1 + A2;
 
-    float best = -INFINITY;
+    float best = -INFINITY, second = -INFINITY; // second: best logit among all OTHER anchors (ties with the winner count: margin 0)
     int best_i = 0x7fffffff;
+    auto merge = [](float &b, int &bi, float &s2nd, float b2, int bi2, float s2) __attribute__((always_inline)) {
+        if (b2 > b || (b2 == b && bi2 < bi)) {
+            s2nd = fmaxf(fmaxf(b, s2nd), s2);
+            b = b2;
+            bi = bi2;
+        } else {
+            s2nd = fmaxf(fmaxf(b2, s2nd), s2);
+        }
+    };
     for (int i = threadIdx.x; i < A; i += 1024) {
         int lvl, j;
         if (i < A0) {
@@ -41,27 +50,31 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
         const T *c = reinterpret_cast<const T *>(a.cls[lvl]) + ((long long)n * Al + j) * a.cls_ld;
         float m = ldf(c);
         for (int k = 1; k < a.nc; ++k) m = fmaxf(m, ldf(c + k)); // conf = max over classes
-        better(best, best_i, m, i);
+        merge(best, best_i, second, m, i, -INFINITY);
     }
     // wavefront butterfly (64 lanes)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        const float s2 = __shfl_xor(best, off, 64);
+        const float b2 = __shfl_xor(best, off, 64);
         const int i2 = __shfl_xor(best_i, off, 64);
-        better(best, best_i, s2, i2);
+        const float s2 = __shfl_xor(second, off, 64);
+        merge(best, best_i, second, b2, i2, s2);
     }
-    __shared__ float ws[16];
+    __shared__ float ws[16], wsec[16];
     __shared__ int wi[16];
     if ((threadIdx.x & 63) == 0) {
         ws[threadIdx.x >> 6] = best;
         wi[threadIdx.x >> 6] = best_i;
+        wsec[threadIdx.x >> 6] = second;
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
     best = ws[0];
     best_i = wi[0];
+    second = wsec[0];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) better(best, best_i, ws[w], wi[w]);
+    for (int w = 1; w < 16; ++w) merge(best, best_i, second, ws[w], wi[w], wsec[w]);
+    if (a.out_margin && threadIdx.x == 0) a.out_margin[n] = fminf(best - second, fabsf(best - a.conf_logit));
 
     // score = sigmoid(logit) in fp32, candidate iff score > conf (non_max_suppression `xc`)
     const float score = 1.0f / (1.0f + expf(-best));

@@ -449,6 +449,7 @@ struct wtk_yolo {
     size_t lb_cap = 0;
     void *zero_page = nullptr;
     float *o_xywh = nullptr, *o_conf = nullptr;
+    float *o_margin = nullptr; // decision margin of every frame of the last max_det = 1 call (wtk_yolo_last_margins_host / wtk_yolo_margin_buffer)
     int *o_anchor = nullptr;
     // scratch of the general NMS (max_det > 1), allocated at its first use
     float *nms_score = nullptr, *nms_box = nullptr;
@@ -940,7 +941,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         }
     }
     if (dev_alloc(h, (void **)&h->o_xywh, sizeof(float) * 4 * h->max_batch) || dev_alloc(h, (void **)&h->o_conf, sizeof(float) * h->max_batch) ||
-        dev_alloc(h, (void **)&h->o_anchor, sizeof(int) * h->max_batch)) {
+        dev_alloc(h, (void **)&h->o_anchor, sizeof(int) * h->max_batch) || dev_alloc(h, (void **)&h->o_margin, sizeof(float) * h->max_batch)) {
         wtk_yolo_destroy(h);
         return 1;
     }
@@ -1049,6 +1050,8 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
     a.out_xywh = out_xywh;
     a.out_conf = out_conf;
     a.out_anchor = out_anchor;
+    a.out_margin = h->o_margin;
+    a.conf_logit = conf > 0.f && conf < 1.f ? std::log(conf / (1.f - conf)) : (conf <= 0.f ? -INFINITY : INFINITY);
     if (nms) {
         NmsArgs q;
         q.h = a;
@@ -1481,6 +1484,20 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
     if (out_conf) HIP_TRY(hipMemcpyAsync(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost, st));
     if (out_anchor) HIP_TRY(hipMemcpyAsync(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int wtk_yolo_margin_buffer(wtk_yolo *h, const float **margins_dev) {
+    if (!h || !margins_dev) return fail("wtk_yolo_margin_buffer: null argument");
+    *margins_dev = h->o_margin;
+    return 0;
+}
+
+extern "C" int wtk_yolo_last_margins_host(wtk_yolo *h, int32_t B, float *margins_host) {
+    if (!h || !margins_host || B <= 0 || B > h->max_batch) return fail("wtk_yolo_last_margins_host: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(margins_host, h->o_margin, sizeof(float) * B, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -320,6 +320,10 @@ struct HeadArgs {
     float *out_xywh; // [N][4]
     float *out_conf; // [N] or null
     int *out_anchor; // [N] or null
+    // decision margin of the frame in logit units, or null: min(best - second-best class logit over the anchors,
+    // |best - logit(conf)|) — how far the fp32 result is from choosing another anchor or from flipping detection / NaN row
+    float *out_margin;
+    float conf_logit; // log(conf / (1 - conf))
 };
 hipError_t launch_head(const HeadArgs &a, int is_f16, hipStream_t stream);
 

@@ -55,6 +55,7 @@ SYMBOLS = [
     "wtk_yolo_predict_views", "wtk_track_median_centers", "wtk_track_polyfit", "wtk_track_training_pairs",
     "wtk_yolo_predict_nms", "wtk_yolo_decode_nms_host",
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
+    "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
 ]
 
 
@@ -102,6 +103,8 @@ def load() -> C.CDLL:
     lib.wtk_track_training_pairs.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.wtk_yolo_predict_nms.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
     lib.wtk_yolo_decode_nms_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp]
+    lib.wtk_yolo_margin_buffer.argtypes = [vp, C.POINTER(vp)]
+    lib.wtk_yolo_last_margins_host.argtypes = [vp, i32, vp]
     lib.wtk_comm_unique_id.argtypes = [vp, C.c_size_t]
     lib.wtk_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
     lib.wtk_comm_destroy.argtypes = [vp]
@@ -356,6 +359,19 @@ class HipYolo:
         """Device pointers / torch CUDA tensors; asynchronous on `stream`."""
         _check(load().wtk_yolo_predict(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh),
                                        _ptr(out_conf), _ptr(out_anchor), C.c_void_p(stream)), "wtk_yolo_predict")
+
+    def last_margins(self, B: int) -> np.ndarray:
+        """Decision margins (class-logit units) of the B frames of the last max_det = 1 call: min(best - second-best anchor logit,
+        |best - logit(conf)|) — small values mark frames on which a perturbation of the logits could change the result."""
+        out = np.empty((B,), dtype=np.float32)
+        _check(load().wtk_yolo_last_margins_host(self._h, B, _ptr(out)), "wtk_yolo_last_margins_host")
+        return out
+
+    def margin_buffer(self) -> int:
+        """Device address of the handle's [max_batch] float margin buffer (for device-resident pipelines)."""
+        p = C.c_void_p()
+        _check(load().wtk_yolo_margin_buffer(self._h, C.byref(p)), "wtk_yolo_margin_buffer")
+        return int(p.value)
 
     def predict_nms(self, frames_dev, B: int, H: int, W: int, Cc: int, max_det: int, out_xywh, out_conf=None, out_cls=None, out_anchor=None,
                     out_count=None, conf: float = 0.1, iou: float = 0.7, stream: int = 0):
