@@ -120,7 +120,7 @@ def test_fp16_with_margin_recheck_restores_fp32_survivors(hip_lib, tmp_path):
     # margins track the oracle's own: min(top-1 / top-2 logit gap, distance of the best logit from logit(conf)), within the fp16 logit noise
     best_logit = np.log(co.astype(np.float64) / (1.0 - co.astype(np.float64)))
     want = np.minimum(gap, np.abs(best_logit - np.log(0.1 / 0.9)))
-    assert np.abs(margins - want).max() < 0.05 and (margins >= 0).all()
+    assert np.abs(margins - want).max() < 0.1 and np.median(np.abs(margins - want)) < 0.01 and (margins >= 0).all()
     ok = ao >= 0
     np.testing.assert_allclose(rows_g[ok], xo[ok], rtol=0, atol=1.0)  # the fp32 survivor's box (fp16 rows: IoU >= 0.997 -> well inside 1 px)
     close = np.abs(rows_g[ok] - xo[ok]).max(axis=1) < 1.0
