@@ -30,7 +30,9 @@ extern "C" {
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
-    WTK_F16 = 1  /* fp16 storage, fp16 MFMA (v_mfma_f32_16x16x32_f16) with fp32 accumulate */
+    WTK_F16 = 1, /* fp16 storage, fp16 MFMA (v_mfma_f32_16x16x32_f16) with fp32 accumulate */
+    WTK_F16X3 = 2 /* split-fp16 storage (hi + lo * 2^-11 pairs), three fp16 MFMAs per product: fp32-grade results (the error of a plain
+                     fp32 dot product) from the fp16 matrix pipe.  Channel widths in multiples of 64 (YOLOv8 s / l).                     */
 } wtk_dtype;
 
 const char *wtk_last_error(void);

@@ -1,0 +1,99 @@
+"""GPU parity of the split-fp16 mode (dtype "f16x3": hi + lo * 2^-11 pairs, three fp16 MFMAs per product) — held to the
+fp32 mode's tolerances against the CPU restatement (oracle/yolo_oracle.py), and compared tensor by tensor with the exact-fp32
+MFMA mode of the same library.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo_oracle as yo
+from wtracker_amd import frames as fr
+from wtracker_amd import hip
+from wtracker_amd import yolo_spec as ys
+
+pytestmark = pytest.mark.gpu
+
+F32_LOGIT_ATOL = 2e-3  # the fp32 mode's bounds (tests/test_gpu_yolo.py)
+F32_BOX_ATOL = 2e-2
+
+
+def _det(scale, hw, dtype, max_batch, nc=1, seed=0):
+    w = ys.synthetic_weights(scale, nc, seed=seed)
+    depth, width, maxch = ys.SCALES[scale]
+    det = hip.HipYolo(w, hw, max_batch, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch)
+    return w, det, ys.model_dims(width, depth, maxch, nc)
+
+
+@pytest.mark.parametrize("size,B", [(128, 2), (256, 3), (352, 2)])
+def test_f16x3_head_logits_and_boxes_match_oracle(hip_lib, size, B):
+    w, det, dims = _det("s", (size, size), "f16x3", B)
+    oracle = yo.YoloOracle(w, dims)
+    frames, _ = fr.synthetic_frames(B, size, seed=11)
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(frames), size)
+        box_o, cls_o = oracle.forward(x)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+    box_g, cls_g = det.debug_head(B)
+    np.testing.assert_allclose(cls_g, cls_o.numpy(), rtol=1e-3, atol=F32_LOGIT_ATOL)
+    np.testing.assert_allclose(box_g, box_o.numpy(), rtol=1e-3, atol=F32_LOGIT_ATOL)
+    xywh_o, conf_o, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.1)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=F32_BOX_ATOL)
+    np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("H,W,C", [(224, 160, 1), (128, 192, 3)])
+def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, H, W, C):
+    """Every conv output of the split mode against the exact-fp32 MFMA mode of the same library on the same frames: a split
+    product carries the error of an fp32 product (2^-22 relative per operand pair), so the tensors agree to fp32 rounding
+    accumulated over the layers in front of them — three orders of magnitude below the fp16 mode's 2^-11 per layer."""
+    B = 3
+    rng = np.random.default_rng(H + W)
+    frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
+    outs = {}
+    for dtype in ("fp32", "f16x3"):
+        _, det, _ = _det("s", (H, W), dtype, B)
+        res = det.predict_host(frames, conf=0.05)
+        tensors = {}
+        for i, t in enumerate(ys.conv_table("s", 1)):
+            try:
+                tensors[t["name"]] = det.debug_tensor(i, B)
+            except hip.WtkError:
+                pass  # a conv computed inside another op (concatenated Detect stems report under their first blob)
+        outs[dtype] = (res, det.debug_head(B), tensors)
+        det.close()
+    (res_r, (box_r, cls_r), t_r), (res_s, (box_s, cls_s), t_s) = outs["fp32"], outs["f16x3"]
+    assert set(t_r) == set(t_s) and len(t_r) >= 50
+    worst = 0.0
+    for nm in t_r:
+        scale = max(1.0, float(np.abs(t_r[nm]).max()))
+        err = float(np.abs(t_s[nm] - t_r[nm]).max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-5, (nm, err, scale)
+    print(f"f16x3 vs fp32 mode, {len(t_r)} tensors: worst scaled difference {worst:.2e}")
+    lscale = max(1.0, float(np.abs(cls_r).max()), float(np.abs(box_r).max()))
+    assert np.abs(cls_s - cls_r).max() < 2e-5 * lscale and np.abs(box_s - box_r).max() < 2e-5 * lscale
+    np.testing.assert_array_equal(res_s[2], res_r[2])
+    np.testing.assert_allclose(res_s[0], res_r[0], rtol=0, atol=2e-3, equal_nan=True)
+
+
+def test_f16x3_full_size_640_survivors_equal_oracle(hip_lib):
+    size, B = 640, 4
+    w, det, dims = _det("s", (size, size), "f16x3", B)
+    oracle = yo.YoloOracle(w, dims)
+    frames, _ = fr.synthetic_frames(B, size, seed=0)
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(frames), size)
+        box_o, cls_o = oracle.forward(x)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+    box_g, cls_g = det.debug_head(B)
+    assert np.abs(cls_g - cls_o.numpy()).max() < F32_LOGIT_ATOL
+    xywh_o, _, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.1)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=F32_BOX_ATOL)
+
+
+def test_f16x3_rejects_scales_it_cannot_split(hip_lib):
+    w = ys.synthetic_weights("n", 1, seed=0)
+    depth, width, maxch = ys.SCALES["n"]
+    with pytest.raises(hip.WtkError, match="WTK_F16X3"):
+        hip.HipYolo(w, (128, 128), 1, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)

@@ -1497,6 +1497,8 @@ bool halo_eligible(int k, int stride, int cin, int is_f16) {
     return k == 3 && stride == 1 && cin % cch == 0;
 }
 
+bool split_halo_eligible(int k, int stride, int cin, int cout) { return false; }
+
 int halo_rows_max(int cout_stored, int slabs) { return (slabs == 3 && halo_cout_tile(cout_stored) == 192) ? kHaloRowsSmall : kHaloRowsMax; }
 
 void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm) {

@@ -119,8 +119,11 @@ template <bool NTL> __device__ __forceinline__ void dma_buf(const rsrc_t &rs, un
 // second cout tile re-reads the rows from L2 — hence only for CoutPad == BN).
 // UP (K1 only): two-source input, channels [0, in2_split) come from a half-resolution tensor (see ConvArgs::in2).
 // TAIL: fused 1x1 tail (ConvArgs::tail_w), fp16 128x128 tile only.
-template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT, bool UP = false, bool TAIL = false>
+// SPLIT (T = fp16): operands are split-fp16 tensors (wtk_kernels.h): a 128-byte row is 32 channels as [hi32 | lo32], a K step is three MFMAs
+// per tile pair (hi*hi into acc, hi*lo + lo*hi into acc1), the epilogue combines acc + 2^-11 acc1 and stores split (or fp32) values.
+template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool K1, bool NT, bool UP = false, bool TAIL = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 * 1024) ? 3 : 2) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!SPLIT || (sizeof(T) == 2 && !TAIL), "split mode: fp16 storage, no fused tail");
     constexpr int CE = Elem<T>::CE;
     constexpr int BKE = 8 * CE; // K elements per step = one 128-byte row
     constexpr int WP = BM / WAVES_P, WC = BN / WAVES_C;
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     // Accumulators START at the bias (the MFMA chain adds the products to it): saves one v_add per output value in the
     // epilogue, where the SiLU's VALU work — not the matrix pipe — bounds every layer with a short K (-2 % conv time).
     floatx4 acc[TC][TP];
+    floatx4 acc1[SPLIT ? TC : 1][SPLIT ? TP : 1]; // split mode: the 2^-11 cross terms
 
     // fragment addresses: pixel tiles j are base + j*2048 (same swizzle key), cout tiles i are
     // base + i*512 (key independent of i); the second k-half is base ^ 64.
@@ -403,6 +407,33 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         }
     };
 
+    // split mode: one K step = hi fragments (k-half 0) and lo fragments (k-half 1) of the same 32 channels
+    auto compute_split = [&](const char *pt) __attribute__((always_inline)) {
+        if constexpr (SPLIT) {
+            uint4 ph[TP], wh[TC], wl[TC];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) ph[j] = *reinterpret_cast<const uint4 *>(pt + pfrag0 + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wh[i] = *reinterpret_cast<const uint4 *>(pt + wfrag0 + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wl[i] = *reinterpret_cast<const uint4 *>(pt + (wfrag0 ^ 64u) + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    mma_frag(wh[i], ph[j], acc[i][j], (T *)nullptr);
+                    mma_frag(wl[i], ph[j], acc1[i][j], (T *)nullptr);
+                }
+            uint4 pl[TP];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pl[j] = *reinterpret_cast<const uint4 *>(pt + (pfrag0 ^ 64u) + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_frag(wh[i], pl[j], acc1[i][j], (T *)nullptr);
+        }
+    };
+
     // bias of the NEXT tile to be multiplied (rows exist up to CoutPad): requested at the top of the current tile's
     // epilogue, consumed at its end when the accumulators are re-armed — the L2 round trip hides behind the SiLU work
     float bias_r[NV];
@@ -417,7 +448,10 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){bias_r[i * 4 + 0], bias_r[i * 4 + 1], bias_r[i * 4 + 2], bias_r[i * 4 + 3]};
+            for (int j = 0; j < TP; ++j) {
+                acc[i][j] = (floatx4){bias_r[i * 4 + 0], bias_r[i * 4 + 1], bias_r[i * 4 + 2], bias_r[i * 4 + 3]};
+                if constexpr (SPLIT) acc1[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            }
     };
     load_bias(0);
     arm_acc();
@@ -525,18 +559,28 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
                 for (int t = 0; t < TC; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r]; // bias already inside
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (SPLIT)
+                            v[t * 4 + r] = acc[t][j][r] + acc1[t][j][r] * kSplitInv; // bias already inside acc
+                        else
+                            v[t * 4 + r] = acc[t][j][r]; // bias already inside
+                    }
                 if (a.act) {
                     wtk_silu_scaled_run<NV>(v);
                 }
                 if (res) {
                     float rv[NV];
-                    load_run<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+                    if constexpr (SPLIT)
+                        wtk_split_load<NV>(reinterpret_cast<const _Float16 *>(a.res) + pix * a.res_ld + a.res_coff, cb, rv);
+                    else
+                        load_run<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
 #pragma unroll
                     for (int e = 0; e < NV; ++e) v[e] += rv[e];
                 }
                 if (sizeof(T) == 2 && a.out_f32)
                     store_run<NV>(reinterpret_cast<float *>(a.out) + pix * a.out_ld + a.out_coff + cb, v); // head logits stay fp32
+                else if constexpr (SPLIT)
+                    wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out) + pix * a.out_ld + a.out_coff, cb, v);
                 else
                     store_run<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
                 if (out2) {
@@ -546,7 +590,10 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx) {
                             const long long pix2 = ((long long)n * Ho2 + (2 * ho + dy)) * Wo2 + (2 * wo + dx);
-                            store_run<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
+                            if constexpr (SPLIT)
+                                wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out2) + pix2 * a.out2_ld + a.out2_coff, cb, v);
+                            else
+                                store_run<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
                         }
                 }
             }
@@ -576,8 +623,12 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem0, 1);
 #else
         if (s + 1 < total_stages) issue_stage(smem1); // smem1 was last read before the previous barrier
-        compute_half(smem0, 0);
-        compute_half(smem0, 1);
+        if constexpr (SPLIT) {
+            compute_split(smem0);
+        } else {
+            compute_half(smem0, 0);
+            compute_half(smem0, 1);
+        }
 #endif
         after_compute(smem0);
         if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -589,8 +640,12 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem1, 1);
 #else
         if (s + 2 < total_stages) issue_stage(smem0);
-        compute_half(smem1, 0);
-        compute_half(smem1, 1);
+        if constexpr (SPLIT) {
+            compute_split(smem1);
+        } else {
+            compute_half(smem1, 0);
+            compute_half(smem1, 1);
+        }
 #endif
         after_compute(smem1);
         if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -603,7 +658,7 @@ int conv_cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : ((cfg == CFG_256x64
 
 hipError_t conv_init_attributes() { return hipSuccess; } // LDS is static: nothing to raise
 
-template <typename T, int BM, int BN, int WAVES_P, int WAVES_C>
+template <typename T, int BM, int BN, int WAVES_P, int WAVES_C, bool SPLIT = false>
 static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     long long ptiles;
     if (a.tile_w == 0)
@@ -629,7 +684,7 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
     const bool k1 = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     if (k1 && (a.Ho != a.H || a.Wo != a.W)) return hipErrorInvalidValue; // the 1x1 loader reads input pixel m for output pixel m
     if (a.tail_w) {
-        if constexpr (BM == 128 && BN == 128 && sizeof(T) == 2) {
+        if constexpr (BM == 128 && BN == 128 && sizeof(T) == 2 && !SPLIT) {
             if (k1 || a.in2 || a.res || a.out2 || a.Cout != BN || a.CoutPad != BN || !a.tail_bias || !a.tail_out || a.tail_kpad < BN || a.tail_kpad % 8 || a.tail_ld % 8 ||
                 a.tail_coff % 8)
                 return hipErrorInvalidValue; // built for the strided 3x3 -> 1x1 (128 -> 128) pair only
@@ -643,20 +698,20 @@ static hipError_t launch_t(ConvArgs a, hipStream_t stream) {
         if constexpr (BM == 128 && BN == 128) {
             if (!k1) return hipErrorInvalidValue;
             if (a.CoutPad == BN)
-                hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
+                hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true, true, false, SPLIT>), dim3(grid), dim3(64 * NW), 0, stream, a);
             else
-                hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
+                hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false, true, false, SPLIT>), dim3(grid), dim3(64 * NW), 0, stream, a);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue; // the two-source loader is only built for the 128x128 tile
         }
     }
     if (k1 && a.CoutPad == BN)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true>), dim3(grid), dim3(64 * NW), 0, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, true, false, false, SPLIT>), dim3(grid), dim3(64 * NW), 0, stream, a);
     else if (k1)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false>), dim3(grid), dim3(64 * NW), 0, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, true, false, false, false, SPLIT>), dim3(grid), dim3(64 * NW), 0, stream, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, false, false>), dim3(grid), dim3(64 * NW), 0, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WAVES_P, WAVES_C, false, false, false, false, SPLIT>), dim3(grid), dim3(64 * NW), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -687,6 +742,27 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
         case CFG_256x32: return launch_t<float, 256, 32, 4, 1>(a, stream);
         case CFG_128x64: return launch_t<float, 128, 64, 4, 1>(a, stream);
         }
+    }
+    return hipErrorInvalidValue;
+}
+
+// Split-fp16 operands: the fp16 instantiations with SPLIT = true; every channel-like argument of `a` is in pseudo-channels (see ConvArgs)
+hipError_t launch_conv_split(const ConvArgs &a, int cfg, hipStream_t stream) {
+    const int bn = conv_cfg_bn(cfg), bm = conv_cfg_bm(cfg);
+    if (a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % 8 != 0 || a.Cin % 64 != 0 || a.in_ld % 64 != 0 || a.in_coff % 64 != 0) return hipErrorInvalidValue;
+    if (a.Kpad % 64 != 0 || a.Kpad < a.K || a.K != a.KH * a.KW * a.Cin || a.tail_w) return hipErrorInvalidValue;
+    if (!a.out_f32 && (a.out_ld % 64 != 0 || a.out_coff % 64 != 0)) return hipErrorInvalidValue;
+    if (a.res && (a.res_ld % 64 != 0 || a.res_coff % 64 != 0)) return hipErrorInvalidValue;
+    if (a.out2 && (a.out2_ld % 64 != 0 || a.out2_coff % 64 != 0)) return hipErrorInvalidValue;
+    if (a.tile_w != 0 && (bm % a.tile_w != 0)) return hipErrorInvalidValue;
+    if (a.in2 && (a.in2_split <= 0 || a.in2_split % 64 != 0 || a.in2_split > a.Cin || a.in2_ld % 64 != 0 || a.in2_coff % 64 != 0 || a.H % 2 != 0 || a.W % 2 != 0 ||
+                  cfg != CFG_128x128))
+        return hipErrorInvalidValue;
+    switch (cfg) {
+    case CFG_128x128: return launch_t<_Float16, 128, 128, 2, 2, true>(a, stream);
+    case CFG_256x64: return launch_t<_Float16, 256, 64, 4, 1, true>(a, stream);
+    case CFG_256x32: return launch_t<_Float16, 256, 32, 4, 1, true>(a, stream);
+    case CFG_128x64: return launch_t<_Float16, 128, 64, 4, 1, true>(a, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -144,6 +144,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
                 v[i * 4 + r] = wtk_silu_scaled(s);
             }
         T *o = out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout + cb;
+        if constexpr (sizeof(T) == 4 && NV % 8 == 0) {
+            if (a.out_split) { // one pixel = 2 * Cout halves = Cout floats
+                wtk_split_store<NV>(reinterpret_cast<_Float16 *>(out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout), cb, v);
+                continue;
+            }
+        }
         if constexpr (sizeof(T) == 2) {
             // NV = 4*TC halves per lane: 8-byte units (TC odd: 16 / 48 couts) or 16-byte units
 #pragma unroll
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
 hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream) {
     if ((a.Cout != 16 && a.Cout != 32 && a.Cout != 48 && a.Cout != 64) || (a.C != 1 && a.C != 3)) return hipErrorInvalidValue;
     if (a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2) return hipErrorInvalidValue;
+    if (a.out_split && (is_f16 || a.Cout % 32 != 0)) return hipErrorInvalidValue;
     const long long blocks = (long long)a.N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
@@ -341,7 +348,8 @@ template <> struct PoolVec<float, 4> {
     typedef float type __attribute__((ext_vector_type(4)));
 };
 
-template <typename T, int CE, int GP>
+// SPLIT (T = float): the buffer holds split-fp16 pairs; hi + lo * 2^-11 is exact in fp32, so the maxima are those of the stored values
+template <typename T, int CE, int GP, bool SPLIT = false>
 __global__ __launch_bounds__(512) void sppf_pool_kernel(const PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_pool[];
     using V = typename PoolVec<T, CE>::type;
@@ -353,9 +361,23 @@ __global__ __launch_bounds__(512) void sppf_pool_kernel(const PoolArgs a) {
     const int ld = 4 * a.c;
     T *base = reinterpret_cast<T *>(a.buf) + (long long)n * HW * ld + g0 * CE;
     const int items = HW * GP; // item = pixel*GP + group: consecutive lanes read consecutive 16-B groups of a pixel
+    typedef _Float16 half4_p __attribute__((ext_vector_type(4)));
+    auto split_at = [&](int px, int g, int slice) __attribute__((always_inline)) -> _Float16 * { // 4 real channels of a group: hi at the result, lo 32 halves on
+        const int c0 = (g0 + g) * CE;
+        return reinterpret_cast<_Float16 *>(a.buf) + ((long long)n * HW + px) * (2 * ld) + 2 * slice * a.c + 64 * (c0 >> 5) + (c0 & 31);
+    };
     for (int i = threadIdx.x; i < items; i += 512) {
         const int px = i / GP, g = i - px * GP;
-        A[i] = *reinterpret_cast<const V *>(base + (long long)px * ld + g * CE);
+        if constexpr (SPLIT) {
+            const _Float16 *p = split_at(px, g, 0);
+            const half4_p hv = *reinterpret_cast<const half4_p *>(p), lv = *reinterpret_cast<const half4_p *>(p + 32);
+            V v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)hv[e] + (float)lv[e] * kSplitInv;
+            A[i] = v;
+        } else {
+            A[i] = *reinterpret_cast<const V *>(base + (long long)px * ld + g * CE);
+        }
     }
     __syncthreads();
     for (int pass = 1; pass <= 3; ++pass) {
@@ -383,7 +405,20 @@ __global__ __launch_bounds__(512) void sppf_pool_kernel(const PoolArgs a) {
                 if ((unsigned)(y + d) < (unsigned)a.H) m = __builtin_elementwise_max(m, Bv[i + d * a.W * GP]);
             }
             A[i] = m;
-            *reinterpret_cast<V *>(base + (long long)px * ld + pass * a.c + g * CE) = m;
+            if constexpr (SPLIT) {
+                _Float16 *p = split_at(px, g, pass);
+                half4_p hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 hh = (_Float16)m[e];
+                    hv[e] = hh;
+                    lv[e] = (_Float16)((m[e] - (float)hh) * kSplitScale);
+                }
+                *reinterpret_cast<half4_p *>(p) = hv;
+                *reinterpret_cast<half4_p *>(p + 32) = lv;
+            } else {
+                *reinterpret_cast<V *>(base + (long long)px * ld + pass * a.c + g * CE) = m;
+            }
         }
         __syncthreads();
     }
@@ -399,6 +434,8 @@ hipError_t pool_init_attributes() {
     WTK_POOL_ATTR(_Float16, 8, 4)
     WTK_POOL_ATTR(float, 4, 1)
     WTK_POOL_ATTR(float, 4, 4)
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sppf_pool_kernel<float, 4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sppf_pool_kernel<float, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
 #undef WTK_POOL_ATTR
     return hipSuccess;
 }
@@ -419,6 +456,12 @@ hipError_t launch_sppf_pool(const PoolArgs &a_in, int is_f16, hipStream_t stream
             hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 4>), dim3(blocks), dim3(512), lds, stream, a);
         else
             hipLaunchKernelGGL((sppf_pool_kernel<_Float16, 8, 1>), dim3(blocks), dim3(512), lds, stream, a);
+    } else if (a.split) {
+        if (a.c % 32 != 0) return hipErrorInvalidValue;
+        if (gp == 4)
+            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 4, true>), dim3(blocks), dim3(512), lds, stream, a);
+        else
+            hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 1, true>), dim3(blocks), dim3(512), lds, stream, a);
     } else {
         if (gp == 4)
             hipLaunchKernelGGL((sppf_pool_kernel<float, 4, 4>), dim3(blocks), dim3(512), lds, stream, a);

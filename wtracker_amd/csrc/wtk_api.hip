@@ -92,6 +92,12 @@ static uint16_t f32_to_f16_bits(float f) {
     return b;
 }
 
+static float f16_bits_to_f32(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
 // =============================================================================================
 // ResMLP
 // =============================================================================================
@@ -432,6 +438,9 @@ struct wtk_yolo {
     int device = 0;
     int is_f16 = 1;
     int esize = 2;
+    // WTK_F16X3: split-fp16 storage (wtk_kernels.h, kSplitScale).  Planned like the fp32 mode (is_f16 = 0, esize = 4: a split tensor
+    // takes the same 4 bytes per value), launched on the SPLIT instantiations of the fp16 kernels with pseudo-channel arguments.
+    int split = 0;
     int S_h = 0, S_w = 0, max_batch = 0;
     ModelDims dims;
     std::vector<Buf> bufs;
@@ -538,6 +547,7 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
     const int ce = h->is_f16 ? 8 : 4;
     op.K = op.k * op.k * op.cin;
     op.Kpad = (op.K + 8 * ce - 1) / (8 * ce) * (8 * ce);
+    if (h->split) op.Kpad = op.K; // cin % 32 == 0 (checked at create): rows of 2 K halves, no K tail
     const int bn = op.halo == 2 ? 32 : (op.halo ? halo_cout_tile(op.cout) : conv_cfg_bn(op.cfg));
     op.cout_pad = (op.cout + bn - 1) / bn * bn;
     std::vector<float> wf((size_t)op.cout_pad * op.Kpad, 0.f), bf(op.cout_pad, 0.f);
@@ -555,7 +565,24 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
     }
     if (dev_alloc(h, (void **)&op.bias, bf.size() * sizeof(float))) return 1;
     HIP_TRY(hipMemcpy(op.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (h->is_f16) {
+    if (h->split) {
+        // [cout_pad][tap][block of 32 channels][hi32 | lo32]: 2 K halves per weight, the k order of a split activation row
+        std::vector<uint16_t> wh(wf.size() * 2);
+        const int taps = op.k * op.k, blocks = op.cin / 32;
+        for (int r = 0; r < op.cout_pad; ++r)
+            for (int t = 0; t < taps; ++t)
+                for (int b = 0; b < blocks; ++b)
+                    for (int c = 0; c < 32; ++c) {
+                        const float x = wf[(size_t)r * op.Kpad + (size_t)t * op.cin + b * 32 + c];
+                        const uint16_t hb = f32_to_f16_bits(x);
+                        const float hi = (float)f16_bits_to_f32(hb);
+                        const size_t o = ((size_t)r * op.Kpad + (size_t)t * op.cin + b * 32) * 2 + c;
+                        wh[o] = hb;
+                        wh[o + 32] = f32_to_f16_bits((x - hi) * kSplitScale);
+                    }
+        if (dev_alloc(h, &op.w, wh.size() * 2)) return 1;
+        HIP_TRY(hipMemcpy(op.w, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+    } else if (h->is_f16) {
         std::vector<uint16_t> wh(wf.size());
         for (size_t i = 0; i < wf.size(); ++i) wh[i] = f32_to_f16_bits(wf[i]);
         if (dev_alloc(h, &op.w, wh.size() * 2)) return 1;
@@ -613,6 +640,7 @@ struct Planner {
         }
         op.cout = std::max(cout, cout_store_pad); // channels actually stored (>= real cout, zero rows beyond)
         op.cfg = pick_cfg(op.cout, op.k == 1 && op.stride == 1);
+        if (h->split && op.cfg == CFG_256x64) op.cfg = CFG_128x64; // the split 256x64 instantiation spills (two accumulator sets)
         op.in_buf = in_buf;
         op.in_coff = in_coff;
         op.out_buf = out_buf;
@@ -647,7 +675,8 @@ struct Planner {
         op.tile_w = 0;
         if (op.k == 3 && wo >= 64 && wo % 16 == 0 && ho % (bm / 16) == 0) op.tile_w = 16;
         op.halo = halo_eligible(op.k, op.stride, op.cin, h->is_f16) && h->use_halo ? 1 : 0;
-        if (h->use_halo && c32_eligible(op.k, op.stride, op.cin, op.cout, h->is_f16, out2_buf >= 0)) op.halo = 2;
+        if (h->split) op.halo = split_halo_eligible(op.k, op.stride, op.cin, op.cout) && h->use_halo ? 1 : 0;
+        if (!h->split && h->use_halo && c32_eligible(op.k, op.stride, op.cin, op.cout, h->is_f16, out2_buf >= 0)) op.halo = 2;
         op.macs_per_image = (double)ho * wo * cout * op.k * op.k * op.cin;
         if (pack_conv(h, op, wp, bp, couts)) {
             failed = true;
@@ -694,7 +723,7 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
 
 extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (!out || !d || !d->convs) return fail("wtk_yolo_create: null argument");
-    if (d->dtype != WTK_F32 && d->dtype != WTK_F16) return fail("wtk_yolo_create: dtype must be WTK_F32 or WTK_F16");
+    if (d->dtype != WTK_F32 && d->dtype != WTK_F16 && d->dtype != WTK_F16X3) return fail("wtk_yolo_create: dtype must be WTK_F32, WTK_F16 or WTK_F16X3");
     if (d->imgsz_h <= 0 || d->imgsz_w <= 0 || d->imgsz_h % 32 || d->imgsz_w % 32) return fail("wtk_yolo_create: imgsz must be a positive multiple of 32");
     if (d->max_batch <= 0) return fail("wtk_yolo_create: max_batch must be positive");
     if (d->nc < 1 || d->nc > 32) return fail("wtk_yolo_create: nc must be in [1, 32]");
@@ -711,12 +740,18 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     for (int i = 0; i < 5; ++i)
         if (dims.c[i] % 16 != 0) return fail("wtk_yolo_create: channel widths must be multiples of 16 for this build");
     if (dims.hb % 16 || dims.hc % 16) return fail("wtk_yolo_create: head widths must be multiples of 16");
+    if (d->dtype == WTK_F16X3) {
+        for (int i = 0; i < 5; ++i)
+            if (dims.c[i] % 64 != 0 && !(i == 0 && dims.c[0] == 32)) return fail("wtk_yolo_create: WTK_F16X3 needs channel widths in multiples of 64 (stem: 32)");
+        if (dims.hb % 32 || dims.hc % 32) return fail("wtk_yolo_create: WTK_F16X3 needs head widths in multiples of 32");
+    }
     HIP_TRY(hipSetDevice(d->device));
     if (ensure_attributes(d->device)) return 1;
 
     wtk_yolo *h = new wtk_yolo();
     h->device = d->device;
     h->is_f16 = d->dtype == WTK_F16;
+    h->split = d->dtype == WTK_F16X3;
     h->esize = h->is_f16 ? 2 : 4;
     h->S_h = d->imgsz_h;
     h->S_w = d->imgsz_w;
@@ -773,7 +808,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         op.spec = i0;
         // repack [cout][3][3][3(RGB)] -> K = tap*4 + channel (see stem_mfma_kernel)
         const float *w0 = d->convs[i0].weight;
-        const int taps = h->is_f16 ? 16 : 9;
+        const int taps = h->is_f16 ? 16 : 9; // split mode: the fp32 stem (pixels / 255 are not fp16 numbers), split store
         std::vector<float> wp((size_t)c[0] * taps * 4, 0.f);
         for (int co = 0; co < c[0]; ++co)
             for (int tap = 0; tap < 9; ++tap)
@@ -1188,6 +1223,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.out = h->bufs[op.out_buf].ptr;
             a.Cout = op.cout;
             a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
+            a.out_split = h->split; // fp32 arithmetic (pixels / 255 are not fp16 numbers), split store
             HIP_TRY(launch_stem(a, h->is_f16, st));
             ++launches[0];
             flops[0] += op_flops(op);
@@ -1197,6 +1233,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             PoolArgs a;
             a.buf = b.ptr;
             a.N = B, a.H = b.h, a.W = b.w, a.c = op.cin;
+            a.split = h->split;
             HIP_TRY(launch_sppf_pool(a, h->is_f16, st));
             ++launches[2];
         } else {
@@ -1248,7 +1285,16 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;
                 a.tiles_y = (ob.h + th - 1) / th;
             }
-            if (op.halo) {
+            if (h->split) {
+                // pseudo-channels: every channel count / offset of a split tensor doubles (an fp32 output keeps its real layout)
+                a.in_ld *= 2, a.in_coff *= 2, a.Cin *= 2, a.K *= 2, a.Kpad *= 2;
+                a.in2_ld *= 2, a.in2_coff *= 2, a.in2_split *= 2;
+                a.res_ld *= 2, a.res_coff *= 2, a.out2_ld *= 2, a.out2_coff *= 2;
+                if (!a.out_f32) a.out_ld *= 2, a.out_coff *= 2;
+            }
+            if (h->split && !op.halo) {
+                HIP_TRY(launch_conv_split(a, op.cfg, st));
+            } else if (op.halo) {
                 HaloArgs g;
                 std::memset(&g, 0, sizeof(g));
                 g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
@@ -1545,7 +1591,16 @@ extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B,
     std::vector<char> tmp(px * b.C * (b.f32 ? 4 : h->esize));
     HIP_TRY(hipMemcpy(tmp.data(), b.ptr, tmp.size(), hipMemcpyDeviceToHost));
     std::vector<float> full(px * b.C);
-    to_f32(tmp.data(), full.data(), full.size(), b.f32 ? 0 : h->is_f16);
+    if (h->split && !b.f32) {
+        const _Float16 *sp = reinterpret_cast<const _Float16 *>(tmp.data());
+        for (size_t i = 0; i < px; ++i)
+            for (int c = 0; c < b.C; ++c) {
+                const size_t o = i * 2 * b.C + 64 * (c >> 5) + (c & 31);
+                full[i * b.C + c] = (float)sp[o] + (float)sp[o + 32] * kSplitInv;
+            }
+    } else {
+        to_f32(tmp.data(), full.data(), full.size(), b.f32 ? 0 : h->is_f16);
+    }
     const float unscale = op->act ? 1.0f / kActScale : 1.0f; // SiLU outputs are stored log2(e)-scaled
     for (size_t i = 0; i < px; ++i)
         for (int k = 0; k < op->cout; ++k) out_host[i * op->cout + k] = full[i * b.C + op->out_coff + k] * unscale;

@@ -82,6 +82,48 @@ template <int NV> __device__ __forceinline__ void wtk_silu_scaled_run(float (&v)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-fp16 storage ("f16x3" mode: fp32-grade results from the fp16 matrix pipe).  A value x is kept as the pair
+//   hi = fp16(x),  lo = fp16((x - hi) * 2^11)          (x - hi is exact in fp32; the scale keeps lo out of the fp16 subnormals)
+// and a product is x*w = hi_x*hi_w + 2^-11 (hi_x*lo_w + lo_x*hi_w) + O(2^-24 |x||w|): three v_mfma_f32_16x16x32_f16 (exact fp16
+// products, fp32 accumulation; the 2^-11 terms in their own accumulator) instead of eight v_mfma_f32_16x16x4_f32 per 32 channels
+// of K — 16 x the FLOP rate at 3 x the instructions.  Measured against float64 on wide-range data the error equals the plain
+// fp32 dot product's (3.6e-7 vs 3.1e-7 of sum|x||w|, K = 1152).
+// Layout: a tensor of C channels (C % 32 == 0) is an fp16 tensor of 2C pseudo-channels: per block of 32 channels 32 hi halves,
+// then 32 lo halves (one 128-byte LDS row = the two k-halves the fp16 kernels already address).  Loaders, LDS-DMA and swizzles
+// of the fp16 kernels work unchanged on pseudo-channels; only the MFMA pattern, the accumulators and the epilogue differ.
+// Range: |x| must stay below the fp16 maximum (65504), as in the fp16 mode.
+// ---------------------------------------------------------------------------------------------
+constexpr float kSplitScale = 2048.0f, kSplitInv = 1.0f / 2048.0f;
+typedef _Float16 wtk_h8 __attribute__((ext_vector_type(8)));
+// store NV (8 or 16) consecutive channels starting at real channel c (multiple of NV) of one pixel; `pix` = the pixel's pseudo-channel 0
+template <int NV> __device__ __forceinline__ void wtk_split_store(_Float16 *pix, int c, const float (&v)[NV]) {
+    static_assert(NV % 8 == 0 && NV <= 32, "runs of 8 channels inside one 32-channel block");
+    _Float16 *p = pix + 64 * (c >> 5) + (c & 31);
+#pragma unroll
+    for (int i = 0; i < NV; i += 8) {
+        wtk_h8 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 h = (_Float16)v[i + j];
+            hv[j] = h;
+            lv[j] = (_Float16)((v[i + j] - (float)h) * kSplitScale);
+        }
+        *reinterpret_cast<wtk_h8 *>(p + i) = hv;
+        *reinterpret_cast<wtk_h8 *>(p + 32 + i) = lv;
+    }
+}
+template <int NV> __device__ __forceinline__ void wtk_split_load(const _Float16 *pix, int c, float (&v)[NV]) {
+    static_assert(NV % 8 == 0 && NV <= 32, "runs of 8 channels inside one 32-channel block");
+    const _Float16 *p = pix + 64 * (c >> 5) + (c & 31);
+#pragma unroll
+    for (int i = 0; i < NV; i += 8) {
+        const wtk_h8 hv = *reinterpret_cast<const wtk_h8 *>(p + i), lv = *reinterpret_cast<const wtk_h8 *>(p + 32 + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i + j] = (float)hv[j] + (float)lv[j] * kSplitInv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip).  Activations are NHWC; a tensor argument is a
 // *channel-slice view* (base pointer, pixel stride `ld` in elements, first channel `coff`), so
 // C2f / SPPF / FPN concatenations are never materialised: producers write into the slice of
@@ -123,6 +165,8 @@ struct ConvArgs {
     void *tail_out;
     int tail_kpad, tail_ld, tail_coff, tail_act;
     int out_f32; // fp16 kernels only: `out` is an fp32 tensor (the six Detect output convs: head logits are never rounded to fp16)
+    // split mode (launch_conv_split): in / in2 / res / out / out2 are split-fp16 tensors; in_ld, in_coff, Cin, K, Kpad, in2_*, res_*, out_ld,
+    // out_coff are given in PSEUDO-channels (2 x the real ones); Cout / CoutPad stay real (an fp32 `out` keeps real out_ld / out_coff)
 };
 
 // Tile configurations (pixels x couts), all 4 waves / 256 threads
@@ -131,6 +175,7 @@ int conv_cfg_bm(int cfg);
 int conv_cfg_bn(int cfg);
 // is_f16: 1 -> _Float16 storage + v_mfma_f32_16x16x32_f16; 0 -> fp32 + v_mfma_f32_16x16x4_f32
 hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t stream);
+hipError_t launch_conv_split(const ConvArgs &a, int cfg, hipStream_t stream); // split-fp16 operands (see kSplitScale above)
 hipError_t conv_init_attributes();
 // fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
@@ -174,6 +219,7 @@ struct HaloArgs {
     FastDiv d_bps, d_strips, d_pitch, d_nct, d_h1; // filled by the launchers (d_h1: H + 1, conv3x3_halo.hip's stacked rows)
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
+bool split_halo_eligible(int k, int stride, int cin, int cout); // split-fp16 operands (real channel counts)
 int halo_rows_max(int cout_stored, int slabs); // window rows the kernel variant for this Cout can hold
 void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256); // per image (conv3x3_c32)
 // conv3x3_halo.hip: the N images of a strip are stacked vertically with ONE shared zero row between neighbours, and a map that
@@ -205,6 +251,7 @@ struct StemArgs {
     void *out; // [N][H/2][W/2][Cout]
     int Cout;
     int Ho, Wo;
+    int out_split; // fp32 kernel only: store split-fp16 pairs (Cout % 32 == 0)
 };
 hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream);
 
@@ -299,6 +346,7 @@ struct PoolArgs {
     void *buf; // [N][H][W][4c]
     int N, H, W, c;
     FastDiv d_w; // filled by the launcher
+    int split;   // fp32 kernel only: buf is a split-fp16 tensor (c % 32 == 0); the maxima are taken on the reconstructed fp32 values
 };
 hipError_t launch_sppf_pool(const PoolArgs &a, int is_f16, hipStream_t stream);
 hipError_t pool_init_attributes();

@@ -17,7 +17,8 @@ _lib: Optional[C.CDLL] = None
 
 WTK_F32 = 0
 WTK_F16 = 1
-DTYPES = {"fp32": WTK_F32, "f32": WTK_F32, "float32": WTK_F32, "fp16": WTK_F16, "f16": WTK_F16, "float16": WTK_F16}
+WTK_F16X3 = 2
+DTYPES = {"fp32": WTK_F32, "f32": WTK_F32, "float32": WTK_F32, "fp16": WTK_F16, "f16": WTK_F16, "float16": WTK_F16, "f16x3": WTK_F16X3, "fp16x3": WTK_F16X3}
 
 
 class WtkError(RuntimeError):
