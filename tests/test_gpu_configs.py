@@ -78,20 +78,21 @@ def test_fp16_accuracy_vs_fp32_oracle_at_640_b64(hip_lib, capsys):
     assert rep["nan_row_agreement"] >= 0.98 and rep["nan_row_agreement_at_median_conf"] >= 0.95
     # a differing survivor only ever happens where the oracle itself is nearly tied
     assert rep["mismatch_oracle_logit_gap_max"] < 0.1
-    # reference precision: fp32 mode is index-exact on all 256 frames
-    _, _, det32 = _s_models(size, "fp32", B)
-    res = [det32.predict_host(frames[i : i + B], conf=0.1) for i in range(0, N, B)]
-    det32.close()
-    x32, c32, a32 = (np.concatenate([r[k] for r in res]) for k in range(3))
-    np.testing.assert_array_equal(a32, ao)
-    ok = ao >= 0
-    np.testing.assert_allclose(x32[ok], xo[ok], rtol=0, atol=2e-2)
-    np.testing.assert_allclose(c32, co, rtol=0, atol=1e-4)
+    # reference precision: the fp32 mode and the split-fp16 mode ("f16x3") are index-exact on all 256 frames
+    for exact in ("fp32", "f16x3"):
+        _, _, det32 = _s_models(size, exact, B)
+        res = [det32.predict_host(frames[i : i + B], conf=0.1) for i in range(0, N, B)]
+        det32.close()
+        x32, c32, a32 = (np.concatenate([r[k] for r in res]) for k in range(3))
+        np.testing.assert_array_equal(a32, ao)
+        ok = ao >= 0
+        np.testing.assert_allclose(x32[ok], xo[ok], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(c32, co, rtol=0, atol=1e-4)
 
 
 def test_fp16_with_margin_recheck_restores_fp32_survivors(hip_lib, tmp_path):
     """YoloConfig(dtype="fp16", recheck_margin=0.08): the detector reports every frame's decision margin (best vs second-best anchor
-    logit / distance to the conf threshold); frames below the margin are re-run by an fp32 handle.  On the 256-frame accuracy set the
+    logit / distance to the conf threshold); frames below the margin are re-run by a full-precision handle (f16x3 at scale s).  On the 256-frame accuracy set the
     fp32 restatement's survivor must come back on EVERY frame, with a minority of the frames re-run; the margins themselves are
     checked against the oracle's top-2 logit gaps."""
     from wtracker_amd.controllers import HipYoloController, YoloConfig
@@ -127,7 +128,8 @@ def test_fp16_with_margin_recheck_restores_fp32_survivors(hip_lib, tmp_path):
     assert close.all()
     n_plain_off = int((np.abs(rows_p[ok] - xo[ok]).max(axis=1) >= 1.0).sum())
     assert 0 < rechecked < 0.4 * N, rechecked
-    print(f"\nrecheck: {rechecked} of {N} frames re-run in fp32; plain fp16 rows off by >= 1 px: {n_plain_off}, guarded: 0")
+    assert guarded.yolo_config.recheck_mode() == "f16x3"  # scale s: the second look runs on the fp16 matrix pipe with split operands
+    print(f"\nrecheck: {rechecked} of {N} frames re-run in f16x3; plain fp16 rows off by >= 1 px: {n_plain_off}, guarded: 0")
 
 
 @pytest.mark.parametrize("dtype,B", [("fp16", 2), ("fp32", 1)])

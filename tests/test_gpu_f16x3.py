@@ -41,12 +41,13 @@ def test_f16x3_head_logits_and_boxes_match_oracle(hip_lib, size, B):
     np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("H,W,C", [(224, 160, 1), (128, 192, 3)])
-def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, H, W, C):
+@pytest.mark.parametrize("H,W,C,no_halo", [(224, 160, 1, "0"), (128, 192, 3, "0"), (224, 160, 1, "1")])
+def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, monkeypatch, H, W, C, no_halo):
     """Every conv output of the split mode against the exact-fp32 MFMA mode of the same library on the same frames: a split
     product carries the error of an fp32 product (2^-22 relative per operand pair), so the tensors agree to fp32 rounding
     accumulated over the layers in front of them — three orders of magnitude below the fp16 mode's 2^-11 per layer."""
     B = 3
+    monkeypatch.setenv("WTK_NO_HALO", no_halo)  # "1": the 3x3 stride-1 convs through the split implicit GEMM instead of the split window kernel
     rng = np.random.default_rng(H + W)
     frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
     outs = {}

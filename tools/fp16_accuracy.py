@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--wseed", type=int, default=0)
     ap.add_argument("--conf", type=float, default=0.1)
     ap.add_argument("--out", default="")
-    ap.add_argument("--dtypes", default="fp16,fp32")
+    ap.add_argument("--dtypes", default="fp16,fp32,f16x3")
     args = ap.parse_args()
 
     from oracle import yolo_oracle as yo

@@ -76,8 +76,8 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
         fl = sum(2.0 * px4 * co * ci * k * k for (nm, kd, st, co, ci, k, ex) in ops[i0 : i0 + 3])
         by = px4 * 64 * es + px4 * 64 * es
         ops = ops[:i0] + [("model.2 tail(m.0+cv2)", "fused", 4, 0, 0, 0, (fl, by))] + ops[i0 + 3 :]
-    # model.4.cv1 in the epilogue of model.3 (TAIL instantiation of the implicit-GEMM kernel: fourth bool of its template list)
-    if any("conv_igemm_kernel" in k and "Lb0ELb0ELb0ELb1EEEvNS_8ConvArgsE" in k for k in kernel_names):
+    # model.4.cv1 in the epilogue of model.3 (TAIL instantiation of the implicit-GEMM kernel: fourth of the five bools of its template list)
+    if any("conv_igemm_kernel" in k and "Lb0ELb0ELb0ELb1ELb0EEEvNS_8ConvArgsE" in k for k in kernel_names):
         i0 = next(i for i, o in enumerate(ops) if o[0] == "model.3")
         (n3, k3, st3, co3, ci3, kk3, ex3), (n4, k4, st4, co4, ci4, kk4, ex4) = ops[i0], ops[i0 + 1]
         px = (size // st3) ** 2 * batch
@@ -86,8 +86,8 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
         ops = ops[:i0] + [("model.3+4.cv1", "fused", st3, 0, 0, 0, (fl, by))] + ops[i0 + 2 :]
     # Detect towers: the last 1x1 runs in the epilogue of the 3x3 before it (TAIL instantiations of the window kernel:
     # 64-cout tile = box tower, 128-cout tile = class tower)
-    tails = {"box": any("conv3x3_halo_kernel" in k and "Li64E" in k and "Lb1EEEvNS_8HaloArgsE" in k for k in kernel_names),
-             "cls": any("conv3x3_halo_kernel" in k and "Li128E" in k and "Lb1EEEvNS_8HaloArgsE" in k for k in kernel_names)}
+    tails = {"box": any("conv3x3_halo_kernel" in k and "Li64E" in k and "Lb1ELb0EEEvNS_8HaloArgsE" in k for k in kernel_names),
+             "cls": any("conv3x3_halo_kernel" in k and "Li128E" in k and "Lb1ELb0EEEvNS_8HaloArgsE" in k for k in kernel_names)}
     for tower, on in tails.items():
         if not on:
             continue

@@ -271,10 +271,13 @@ class YoloConfig:
     # (tests/test_gpu_configs.py::test_fp16_accuracy_vs_fp32_oracle_at_640_b64).
     dtype: str = "fp32"
     # fp16 mode only: frames whose decision margin (best vs second-best anchor logit, or best logit vs the conf threshold; class-logit
-    # units, wtk_yolo_last_margins_host) is below this value are detected AGAIN by an fp32 handle, whose result replaces the row.
+    # units, wtk_yolo_last_margins_host) is below this value are detected AGAIN by a full-precision handle, whose result replaces the row.
     # The fp16 head logits are within ~0.01-0.02 of the fp32 ones, so a margin of 0.08 restores the fp32 restatement's survivor
     # on every frame of the 256-frame accuracy set (tests/test_gpu_configs.py) while ~20 % of the frames are re-run.  0 = off.
     recheck_margin: float = 0.0
+    # precision of that second look: "auto" = "f16x3" where the scale has it (s, l: fp32-grade results at 2.4x the fp32 mode's rate,
+    # tests/test_gpu_f16x3.py), else "fp32"
+    recheck_dtype: str = "auto"
     scale: str = "s"
     max_batch: int = 64
     model: Any = field(default=None, init=False, repr=False)
@@ -288,6 +291,11 @@ class YoloConfig:
         if self.device == "cpu":
             raise hip.WtkError("HipYoloController has no CPU path: use device='cuda' (the MI355X)")
         return int(self.device.split(":")[1]) if ":" in self.device else 0
+
+    def recheck_mode(self, nc: int = 1) -> str:
+        if self.recheck_dtype != "auto":
+            return self.recheck_dtype
+        return "f16x3" if yolo_spec.split_capable(self.scale, nc) else "fp32"
 
     def load_model(self) -> "_YoloModel":
         if self.model is None:
@@ -332,7 +340,7 @@ class HipYoloController(SimController):
         self._camera_frames = deque(maxlen=timing_config.cycle_frame_num)
         self._model = yolo_config.load_model()
         self._device_frames = device_frames
-        self.last_rechecked = 0  # frames of the last predict call that were re-run in fp32 (YoloConfig.recheck_margin)
+        self.last_rechecked = 0  # frames of the last predict call that were detected again at full precision (YoloConfig.recheck_margin)
         if device_frames is not None:
             if not getattr(device_frames, "is_cuda", False) or str(device_frames.dtype) != "torch.uint8" or device_frames.dim() not in (3, 4):
                 raise hip.WtkError("device_frames must be a CUDA uint8 tensor [F,H,W] or [F,H,W,3]")
@@ -373,7 +381,8 @@ class HipYoloController(SimController):
         if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
             weak = np.nonzero(det.last_margins(batch.shape[0]) < self.yolo_config.recheck_margin)[0]
             if len(weak):  # ambiguous frames: the reference's precision decides
-                x32, _, a32 = self._model.detector(net_hw, len(weak), dtype="fp32").predict_host(batch[weak], conf=conf, iou=iou, max_det=1)
+                x32, _, a32 = self._model.detector(net_hw, len(weak), dtype=self.yolo_config.recheck_mode(self._model.nc)).predict_host(
+                    batch[weak], conf=conf, iou=iou, max_det=1)
                 xywh[weak], anchor[weak] = x32, a32
                 self.last_rechecked = len(weak)
         if (anchor < 0).any():
@@ -413,7 +422,7 @@ class HipYoloController(SimController):
             weak = np.nonzero(det.last_margins(n) < self.yolo_config.recheck_margin)[0]
             if len(weak):
                 wsel = torch.from_numpy(weak).to(dev)
-                det32 = self._model.detector(net_hw, len(weak), dtype="fp32")
+                det32 = self._model.detector(net_hw, len(weak), dtype=self.yolo_config.recheck_mode(self._model.nc))
                 k = len(weak)
                 with torch.cuda.device(dev):
                     det32.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx[wsel].contiguous(), pos[wsel].contiguous(), k, vw, vh,

@@ -203,8 +203,11 @@ __device__ __forceinline__ int lane_fetch(int src_lane, int v) { return __builti
 // BMT: flat output pixels per block, 256 or 128 (small maps: twice the blocks, so a 20x20 map still fills the chip).
 // TAIL: instantiation with the fused 1x1 tail (see the epilogue); a separate instantiation so that its extra registers do
 // not touch the plain variant's allocation (the 64-cout variant lives at 2 blocks per CU = 128 VGPRs).
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false>
+// SPLIT (T = fp16): split-fp16 operands (wtk_kernels.h, kSplitScale): a 128-byte row is 32 channels as [hi32 | lo32]; per tap and tile pair
+// three MFMAs (hi*hi into acc, hi*lo + lo*hi into acc1); a.Cin / in_ld / out_ld / ... are pseudo-channel counts (2 x real), a.Cout is real.
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
+    static_assert(!SPLIT || (sizeof(T) == 2 && !TAIL && BN != 192 && MINW <= 2), "split mode: fp16 storage, 64 / 128 couts, 256-register budget");
 #ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -322,10 +325,14 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     };
 
     floatx4 acc[TC][TP];
+    floatx4 acc1[SPLIT ? TC : 1][SPLIT ? TP : 1]; // split mode: the 2^-11 cross terms
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TP; ++j) {
+            acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) acc1[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        }
 
     // weight fragments: row(i) = wave_c*64 + (lr>>2)*16 + 4*i + (lr&3); the swizzle key does not depend on
     // i, so the four tiles are one base + immediates (i*512), and the second k-half is base ^ 64.
@@ -337,6 +344,29 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     auto compute_tap = [&](const char *halo, const char *wb, int tapoff) {
         const int base = prow0 + tapoff;
         const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4); // tiles j: + j*2048 (key unchanged)
+        if constexpr (SPLIT) { // k-half 0 = the hi halves of the row's 32 channels, k-half 1 = their lo halves
+            uint4 ph[TP], wh[TC], wl[TC], pl[TP];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) ph[j] = *reinterpret_cast<const uint4 *>(halo + pfrag0 + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wh[i] = *reinterpret_cast<const uint4 *>(wb + wfrag0 + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wl[i] = *reinterpret_cast<const uint4 *>(wb + (wfrag0 ^ 64u) + i * 512);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pl[j] = *reinterpret_cast<const uint4 *>(halo + (pfrag0 ^ 64u) + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    mma_h(wh[i], ph[j], acc[i][j], (T *)nullptr);
+                    mma_h(wl[i], ph[j], acc1[i][j], (T *)nullptr);
+                }
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(wh[i], pl[j], acc1[i][j], (T *)nullptr);
+            return;
+        }
 #pragma unroll
         for (int kh2 = 0; kh2 < 2; ++kh2) {
             const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     const T *res = reinterpret_cast<const T *>(a.res);
     // the residual of all pixel tiles is requested before any arithmetic (junk pixels read pixel 0): one exposed memory latency
     // per block instead of TP (variants with a 256-register budget only)
-    constexpr bool kHoistRes = MINW <= 2 && sizeof(T) == 2 && BN != 192 && !TAIL; // raw fp16 values: 8 VGPRs per pixel tile
+    constexpr bool kHoistRes = MINW <= 2 && sizeof(T) == 2 && BN != 192 && !TAIL && !SPLIT; // raw fp16 values: 8 VGPRs per pixel tile
     half8 rres[kHoistRes ? TP : 1][kHoistRes ? NV / 8 : 1];
     if constexpr (kHoistRes) {
         if (res) {
@@ -643,7 +673,12 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (SPLIT)
+                    v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                else
+                    v[i * 4 + r] = acc[i][j][r];
+            }
         if (a.act) {
             wtk_silu_scaled_run<NV>(v);
         }
@@ -653,12 +688,18 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
                 for (int i = 0; i < NV; ++i) v[i] += (float)rres[j][i >> 3][i & 7];
             } else {
                 float rv[NV];
-                load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
+                if constexpr (SPLIT)
+                    wtk_split_load<NV>(reinterpret_cast<const _Float16 *>(a.res) + pix * a.res_ld + a.res_coff, cb, rv);
+                else
+                    load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v[i] += rv[i];
             }
         }
-        store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
+        if constexpr (SPLIT)
+            wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out) + pix * a.out_ld + a.out_coff, cb, v);
+        else
+            store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, v);
         if (out2) { // 2x nearest upsample: pixel (n, 2y+dy, 2X+dx) of the [2H][2W] map = 4*pix - 2X + 2W*dy + dx
             const int W2 = a.W * 2;
 #pragma unroll
@@ -666,7 +707,10 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const long long pix2 = 4 * pix - 2 * col + W2 * dy + dx;
-                    store_run_h<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
+                    if constexpr (SPLIT)
+                        wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out2) + pix2 * a.out2_ld + a.out2_coff, cb, v);
+                    else
+                        store_run_h<NV>(out2 + pix2 * a.out2_ld + a.out2_coff + cb, v);
                 }
         }
     }
@@ -1476,7 +1520,7 @@ template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int nu
     return hipGetLastError();
 }
 
-template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
+template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false, bool SPLIT = false> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (BMT + 2 * a.pitch + 2 > HROWS || (long long)a.blocks_per_strip * BMT < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
@@ -1486,7 +1530,7 @@ template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT =
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
     a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
     a.grid = (int)blocks;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT, TAIL>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NHALO, MINW, NWB, HROWS, BMT, TAIL, SPLIT>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1497,7 +1541,24 @@ bool halo_eligible(int k, int stride, int cin, int is_f16) {
     return k == 3 && stride == 1 && cin % cch == 0;
 }
 
-bool split_halo_eligible(int k, int stride, int cin, int cout) { return false; }
+// split-fp16 operands: real channel counts here; 64- or 128-cout tiles only (two accumulator sets)
+bool split_halo_eligible(int k, int stride, int cin, int cout) { return k == 3 && stride == 1 && cin % 32 == 0 && cout % 64 == 0; }
+int split_halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : 64; }
+
+// Every channel count / offset of `a` but Cout / CoutPad in pseudo-channels (2 x real); three weight slabs, one tile per block
+hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
+    const int bn = split_halo_cout_tile(a.Cout);
+    if (a.Cin % 64 != 0 || a.CoutPad % bn != 0 || a.Cout != a.CoutPad || a.tail_w || a.slabs == 2) return hipErrorInvalidValue;
+    if (a.in_ld % 64 || a.in_coff % 64 || a.out_ld % 64 || a.out_coff % 64 || a.Kpad != 9 * a.Cin) return hipErrorInvalidValue;
+    if (a.pitch != (a.strips == 1 ? a.S + 1 : a.S + 2) || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W || (a.strips == 1 && a.S != a.W))
+        return hipErrorInvalidValue;
+    const int bm = a.bm == 128 ? 128 : kBM;
+    if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
+    if (a.res && (a.res_ld % 64 || a.res_coff % 64)) return hipErrorInvalidValue;
+    if (a.out2 && (a.out2_ld % 64 || a.out2_coff % 64)) return hipErrorInvalidValue;
+    if (bn == 128) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
+    return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
+}
 
 int halo_rows_max(int cout_stored, int slabs) { return (slabs == 3 && halo_cout_tile(cout_stored) == 192) ? kHaloRowsSmall : kHaloRowsMax; }
 

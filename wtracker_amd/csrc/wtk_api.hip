@@ -548,7 +548,7 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
     op.K = op.k * op.k * op.cin;
     op.Kpad = (op.K + 8 * ce - 1) / (8 * ce) * (8 * ce);
     if (h->split) op.Kpad = op.K; // cin % 32 == 0 (checked at create): rows of 2 K halves, no K tail
-    const int bn = op.halo == 2 ? 32 : (op.halo ? halo_cout_tile(op.cout) : conv_cfg_bn(op.cfg));
+    const int bn = op.halo == 2 ? 32 : (op.halo ? (h->split ? split_halo_cout_tile(op.cout) : halo_cout_tile(op.cout)) : conv_cfg_bn(op.cfg));
     op.cout_pad = (op.cout + bn - 1) / bn * bn;
     std::vector<float> wf((size_t)op.cout_pad * op.Kpad, 0.f), bf(op.cout_pad, 0.f);
     int row = 0;
@@ -1306,6 +1306,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.res = a.res, g.res_ld = a.res_ld, g.res_coff = a.res_coff;
                 g.act = op.act, g.Kpad = op.Kpad;
                 g.slabs = h->halo_slabs;
+                if (h->split) g.Cin = a.Cin, g.Kpad = a.Kpad, g.slabs = 3; // pseudo-channels
                 if (op.tail_op >= 0) {
                     const Op &t = h->ops[op.tail_op];
                     g.tail_w = t.w, g.tail_bias = t.bias, g.tail_kpad = t.Kpad;
@@ -1314,7 +1315,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     g.tail_f32 = h->bufs[t.out_buf].f32;
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
-                const int rows_max = op.halo == 2 ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
+                const int rows_max = (op.halo == 2 || h->split) ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
                 bool ws64 = false;
                 if (op.halo == 1 && h->use_ws64 && h->halo_slabs == 3 &&
                     ws64_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, h->is_f16, op.out2_buf >= 0, op.tail_op >= 0)) {
@@ -1337,9 +1338,9 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
                 } else {
                     halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
-                    if (h->halo_slabs == 3) {
+                    if (h->halo_slabs == 3 || h->split) {
                         // small maps: halve the blocks when 256-pixel blocks leave at least half of the CUs without work
-                        const long long tiles = (long long)g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout));
+                        const long long tiles = (long long)g.strips * g.blocks_per_strip * (op.cout_pad / (h->split ? split_halo_cout_tile(op.cout) : halo_cout_tile(op.cout)));
                         if (h->halo_small_blocks && 2 * tiles <= h->num_cus) {
                             g.bm = 128;
                             halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
@@ -1348,7 +1349,9 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 }
                 g.zeros = h->zero_page;
                 if (ws64) {
-                } else if (op.halo == 2)
+                } else if (h->split)
+                    HIP_TRY(launch_conv3x3_halo_split(g, st));
+                else if (op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32(g, st));
                 else
                     HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));

@@ -91,6 +91,15 @@ def scale_params(scale: str | tuple) -> tuple[float, float, int]:
     return width, depth, maxch
 
 
+def split_capable(scale: str | tuple, nc: int = 1) -> bool:
+    """True when the detector's "f16x3" mode (split-fp16 operands) exists for this scale: every channel width a multiple of 64
+    (stem 32), head widths multiples of 32 — YOLOv8 s and l (wtk_yolo_create checks the same)."""
+    depth, width, maxch = SCALES[scale] if isinstance(scale, str) else scale
+    d = model_dims(width, depth, maxch, nc)
+    c = d["c"]
+    return all(v % 64 == 0 or (i == 0 and v == 32) for i, v in enumerate(c)) and d["hb"] % 32 == 0 and d["hc"] % 32 == 0
+
+
 def macs_per_frame(scale: str | tuple, nc: int, H: int, W: int) -> float:
     """Conv multiply-accumulates of one forward pass (2 FLOP each); SURVEY.md §8d: 14.216 G at s/nc=1/640^2."""
     total = 0.0
