@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WTK_ABI_VERSION 2 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_* (additive: every v1 entry point is unchanged) */
+#define WTK_ABI_VERSION 3 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_* (additive: every earlier entry point is unchanged) */
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
@@ -244,6 +244,20 @@ int wtk_track_polyfit(const void *track_dev, int32_t track_is_f64, int32_t n_fra
 int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_t n_frames, int32_t row0, int32_t n_rows,
                              const int32_t *input_frames_host, int32_t n_in, const int32_t *pred_frames_host,
                              int32_t n_out, float *x_dev, float *y_dev, int32_t *keep_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Second look at weak decisions, on the device (extension; host-side form: YoloConfig.recheck_margin).  The fp16 detector
+ * reports a decision margin per frame (wtk_yolo_margin_buffer); the K frames of a batch with the smallest margins are
+ * detected again by a full-precision handle (WTK_F16X3 / WTK_F32, e.g. through wtk_yolo_predict_views with
+ * frame_index = slots) and replace the fast rows where margin < `margin`.  No host synchronisation: K is fixed.
+ *   wtk_recheck_select  slots[k] = batch row of the k-th smallest margin (ties: lower row first; NaN = +inf), k < K
+ *   wtk_recheck_merge   row slots[k] of dst_* = row k of src_* where margins[slots[k]] < margin; *n_replaced += count
+ * Replaces nothing in the reference (yolo_controller.py:62-90 computes every frame in fp32).
+ * ------------------------------------------------------------------------------------------ */
+int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, int32_t *slots_dev, void *stream);
+int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin,
+                      const float *src_xywh, const float *src_conf, const int32_t *src_anchor, float *dst_xywh,
+                      float *dst_conf, int32_t *dst_anchor, int32_t *n_replaced_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Detector on camera views of device-resident full frames: view cropping fused with the letterbox in front of

@@ -29,6 +29,9 @@ F16_IOU_MATCHED_P01 = 0.995
 F16_CONF_ATOL = 0.02
 
 
+_ORACLE_CACHE: dict = {}
+
+
 def _s_models(size, dtype, max_batch, seed=0):
     w = ys.synthetic_weights("s", 1, seed=seed)
     depth, width, maxch = ys.SCALES["s"]
@@ -249,3 +252,57 @@ def test_c4_one_rank_share_two_lanes_equal_one_lane_and_oracle_moves(hip_lib, go
     expect = resmlp_oracle.forward(st, x.reshape(len(x), -1).astype(np.float32))
     assert ok.sum() > 600
     np.testing.assert_allclose(m1[ok], expect, rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("margin,K", [(0.08, 24), (0.04, 16)])
+def test_hybrid_detector_fp16_speed_with_full_precision_decisions(hip_lib, margin, K):
+    """wtracker_amd.hybrid.HybridDetector on the 256-frame accuracy set: fp16 on every frame, the K weakest decisions of each 64-frame
+    batch again through the split-fp16 ("f16x3") handle, all on the device (wtk_recheck_select / wtk_recheck_merge, no host round
+    trip).  Every survivor index must equal the fp32 restatement's; rows the second look did not replace are the fp16 rows bit for
+    bit; the views entry point gives the same rows as the frames entry point."""
+    from wtracker_amd.hybrid import HybridDetector
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    size, N, B = 640, 256, 64
+    w, oracle, fast = _s_models(size, "fp16", B)
+    _, _, exact = _s_models(size, "f16x3", K)
+    _, _, plain = _s_models(size, "fp16", B)
+    frames = fr.diverse_frames(N, size, seed=1000)
+    if "hybrid" not in _ORACLE_CACHE:
+        _ORACLE_CACHE["hybrid"] = _oracle_run(oracle, frames, size, 0.1)
+    xo, co, ao, gap = _ORACLE_CACHE["hybrid"]
+    hyb = HybridDetector(fast, exact, margin=margin, k=K)
+    dev = torch.from_numpy(frames).cuda()
+    out = torch.empty((N, 4), dtype=torch.float32, device="cuda")
+    cf = torch.empty((N,), dtype=torch.float32, device="cuda")
+    an = torch.empty((N,), dtype=torch.int32, device="cuda")
+    out_p, an_p = torch.empty_like(out), torch.empty_like(an)
+    margins = []
+    for i in range(0, N, B):
+        hyb.predict(dev[i : i + B], B, size, size, 1, out[i : i + B], cf[i : i + B], an[i : i + B], conf=0.1)
+        plain.predict(dev[i : i + B], B, size, size, 1, out_p[i : i + B], None, an_p[i : i + B], conf=0.1)
+        torch.cuda.synchronize()
+        margins.append(plain.last_margins(B))
+    margins = np.concatenate(margins)
+    xg, ag, xp, ap = out.cpu().numpy(), an.cpu().numpy(), out_p.cpu().numpy(), an_p.cpu().numpy()
+    replaced = int(hyb.replaced.item())
+    np.testing.assert_array_equal(ag, ao)  # the reference precision's survivor on every frame
+    ok = ao >= 0
+    assert np.abs(xg[ok] - xo[ok]).max() < 1.0
+    strong = margins >= margin
+    np.testing.assert_array_equal(xg[strong], xp[strong])  # untouched rows are the fp16 rows
+    expected = sum(min(K, int((margins[i : i + B] < margin).sum())) for i in range(0, N, B))
+    assert replaced == expected and 0 < replaced < 0.4 * N, (replaced, expected)
+    n_plain_bad = int((ap != ao).sum())
+    print(f"\nhybrid (margin {margin}): {replaced} of {N} rows replaced by the f16x3 look (K = {K} per batch of {B}); plain fp16 index mismatches {n_plain_bad}, hybrid 0")
+    # views entry point: whole-frame views in shuffled order
+    perm = np.random.default_rng(0).permutation(B).astype(np.int32)
+    idx = torch.from_numpy(perm).cuda()
+    pos = torch.tensor([[size // 2, size // 2]] * B, dtype=torch.int32).cuda()
+    out_v, an_v = torch.empty((B, 4), dtype=torch.float32, device="cuda"), torch.empty((B,), dtype=torch.int32, device="cuda")
+    hyb.predict_views(dev[:B], B, size, size, 1, idx, pos, B, size, size, out_v, None, an_v, conf=0.1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(an_v.cpu().numpy(), ag[:B][perm])
+    np.testing.assert_array_equal(out_v.cpu().numpy(), xg[:B][perm])
+    hyb.close()
+    plain.close()

@@ -198,7 +198,46 @@ template <typename T> __global__ __launch_bounds__(64) void track_pairs_kernel(c
     a.keep[i] = ok ? 1 : 0;
 }
 
+// rank of every margin among the batch's (ties broken by row): the K smallest go to slots[rank]; NaN counts as +inf
+__global__ __launch_bounds__(256) void recheck_select_kernel(const RecheckArgs a) {
+    __shared__ float m[1024];
+    for (int i = threadIdx.x; i < a.B; i += 256) {
+        const float v = a.margins[i];
+        m[i] = v == v ? v : 3.4e38f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.B; i += 256) {
+        const float mi = m[i];
+        int rank = 0;
+        for (int j = 0; j < a.B; ++j) rank += (m[j] < mi || (m[j] == mi && j < i)) ? 1 : 0;
+        if (rank < a.K) a.slots[rank] = i;
+    }
+}
+
+__global__ __launch_bounds__(64) void recheck_merge_kernel(const RecheckArgs a) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= a.K) return;
+    const int row = a.slots[k];
+    if ((unsigned)row >= (unsigned)a.B || !(a.margins[row] < a.thr)) return;
+    reinterpret_cast<float4 *>(a.dst_xywh)[row] = reinterpret_cast<const float4 *>(a.src_xywh)[k];
+    if (a.dst_conf && a.src_conf) a.dst_conf[row] = a.src_conf[k];
+    if (a.dst_anchor && a.src_anchor) a.dst_anchor[row] = a.src_anchor[k];
+    if (a.n_replaced) atomicAdd(a.n_replaced, 1);
+}
+
 } // namespace
+
+hipError_t launch_recheck_select(const RecheckArgs &a, hipStream_t stream) {
+    if (a.B <= 0 || a.B > 1024 || a.K <= 0 || a.K > a.B) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recheck_select_kernel, dim3(1), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_recheck_merge(const RecheckArgs &a, hipStream_t stream) {
+    if (a.B <= 0 || a.K <= 0 || a.K > a.B) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recheck_merge_kernel, dim3((unsigned)((a.K + 63) / 64)), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_track_median(const TrackMedianArgs &a, int track_f64, hipStream_t stream) {
     if (a.n_samples <= 0 || a.imaging_frame_num <= 0 || a.imaging_frame_num > kTrackMaxWindow || a.cycle_frame_num <= 0) return hipErrorInvalidValue;

@@ -297,6 +297,31 @@ extern "C" int wtk_track_training_pairs(const void *track_dev, int32_t track_is_
     return 0;
 }
 
+extern "C" int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, int32_t *slots_dev, void *stream) {
+    if (!margins_dev || !slots_dev) return fail("wtk_recheck_select: null argument");
+    if (B <= 0 || B > 1024 || K <= 0 || K > B) return fail("wtk_recheck_select: need 1 <= K <= B <= 1024");
+    RecheckArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.margins = margins_dev, a.B = B, a.K = K, a.slots = slots_dev;
+    HIP_TRY(launch_recheck_select(a, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin, const float *src_xywh,
+                                 const float *src_conf, const int32_t *src_anchor, float *dst_xywh, float *dst_conf, int32_t *dst_anchor,
+                                 int32_t *n_replaced_dev, void *stream) {
+    if (!margins_dev || !slots_dev || !src_xywh || !dst_xywh) return fail("wtk_recheck_merge: null argument");
+    if (B <= 0 || K <= 0 || K > B) return fail("wtk_recheck_merge: need 1 <= K <= B");
+    if (reinterpret_cast<uintptr_t>(src_xywh) % 16 || reinterpret_cast<uintptr_t>(dst_xywh) % 16) return fail("wtk_recheck_merge: xywh rows must be 16-byte aligned");
+    RecheckArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.margins = margins_dev, a.B = B, a.K = K, a.slots = const_cast<int32_t *>(slots_dev), a.thr = margin;
+    a.src_xywh = src_xywh, a.src_conf = src_conf, a.src_anchor = src_anchor;
+    a.dst_xywh = dst_xywh, a.dst_conf = dst_conf, a.dst_anchor = dst_anchor, a.n_replaced = n_replaced_dev;
+    HIP_TRY(launch_recheck_merge(a, (hipStream_t)stream));
+    return 0;
+}
+
 // =============================================================================================
 // View extraction
 // =============================================================================================

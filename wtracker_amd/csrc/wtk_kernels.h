@@ -471,4 +471,20 @@ struct TrackPairsArgs {
 };
 hipError_t launch_track_pairs(const TrackPairsArgs &a, int track_f64, hipStream_t stream);
 
+// Second look at the frames with the weakest decisions (wtk_recheck_select / wtk_recheck_merge): the K smallest decision margins of a batch,
+// and the merge of the K re-detected rows into the batch's rows
+struct RecheckArgs {
+    const float *margins; // [B] decision margins of the fast pass (wtk_yolo_margin_buffer)
+    int B, K;
+    int *slots;           // [K] batch rows of the K smallest margins (ties: lower row first), ascending
+    float thr;            // merge: a re-detected row replaces the fast one where margins[row] < thr
+    const float *src_xywh, *src_conf;
+    const int *src_anchor;
+    float *dst_xywh, *dst_conf;
+    int *dst_anchor;
+    int *n_replaced;      // nullable: += number of rows replaced
+};
+hipError_t launch_recheck_select(const RecheckArgs &a, hipStream_t stream);
+hipError_t launch_recheck_merge(const RecheckArgs &a, hipStream_t stream);
+
 } // namespace wtk

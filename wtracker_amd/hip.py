@@ -57,6 +57,7 @@ SYMBOLS = [
     "wtk_yolo_predict_nms", "wtk_yolo_decode_nms_host",
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
+    "wtk_recheck_select", "wtk_recheck_merge",
 ]
 
 
@@ -106,6 +107,8 @@ def load() -> C.CDLL:
     lib.wtk_yolo_decode_nms_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp]
     lib.wtk_yolo_margin_buffer.argtypes = [vp, C.POINTER(vp)]
     lib.wtk_yolo_last_margins_host.argtypes = [vp, i32, vp]
+    lib.wtk_recheck_select.argtypes = [vp, i32, i32, vp, vp]
+    lib.wtk_recheck_merge.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.wtk_comm_unique_id.argtypes = [vp, C.c_size_t]
     lib.wtk_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
     lib.wtk_comm_destroy.argtypes = [vp]
@@ -147,6 +150,18 @@ def crop_views(frames_dev, N: int, H: int, W: int, Cc: int, pos_xy_dev, view_w: 
     with replicate borders.  All arguments are device tensors / pointers."""
     _check(load().wtk_crop_views(_ptr(frames_dev), N, H, W, Cc, _ptr(pos_xy_dev), view_w, view_h, _ptr(views_dev),
                                  C.c_void_p(stream)), "wtk_crop_views")
+
+
+def recheck_select(margins_dev, B: int, K: int, slots_dev, stream: int = 0):
+    """slots[k] = batch row of the k-th smallest decision margin (device int32 [K]); asynchronous on `stream`."""
+    _check(load().wtk_recheck_select(_ptr(margins_dev), B, K, _ptr(slots_dev), C.c_void_p(stream)), "wtk_recheck_select")
+
+
+def recheck_merge(margins_dev, slots_dev, B: int, K: int, margin: float, src_xywh, src_conf, src_anchor, dst_xywh, dst_conf=None, dst_anchor=None,
+                  n_replaced_dev=None, stream: int = 0):
+    """Rows slots[k] of dst_* take row k of src_* where the fast pass's margin is below `margin`."""
+    _check(load().wtk_recheck_merge(_ptr(margins_dev), _ptr(slots_dev), B, K, margin, _ptr(src_xywh), _ptr(src_conf), _ptr(src_anchor), _ptr(dst_xywh),
+                                    _ptr(dst_conf), _ptr(dst_anchor), _ptr(n_replaced_dev), C.c_void_p(stream)), "wtk_recheck_merge")
 
 
 COMM_ID_BYTES = 128

@@ -1,0 +1,90 @@
+"""fp16 speed with full-precision decisions: a detector pair that looks twice at the frames it is least sure about.
+
+The fp16 detector reports a decision margin per frame (distance between its best and second-best anchor logit, or between the
+best logit and the confidence threshold: wtk_yolo_margin_buffer).  Where that margin is smaller than the fp16 logit noise
+(~0.01-0.02 class-logit units through 25 layers of fp16 storage) the surviving anchor can differ from the one the reference's
+fp32 arithmetic picks (yolo/yolo_train_config.yaml:51 `half: False`).  HybridDetector runs the fp16 handle on the whole batch,
+then — without a host round trip — the K frames with the smallest margins through a full-precision handle ("f16x3": split-fp16
+operands, fp32-grade results at 2.4x the fp32 mode's rate; or "fp32"), and merges the rows whose margin is below `margin`.
+K is fixed, so the step is a constant sequence of launches on one stream.
+
+It has the detector interface TrackPipeline uses (predict / predict_views / device / max_batch), so `dets=[HybridDetector(...)]`
+turns the open-loop pipeline into the hybrid mode.  torch: device memory only.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+
+
+class HybridDetector:
+    def __init__(self, fast: hip.HipYolo, exact: hip.HipYolo, margin: float = 0.04, k: int = 16):
+        if fast.device != exact.device:
+            raise hip.WtkError("HybridDetector: both handles must live on the same device")
+        if k < 1 or k > exact.max_batch:
+            raise hip.WtkError("HybridDetector: 1 <= k <= max_batch of the full-precision handle")
+        self.fast, self.exact, self.margin, self.k = fast, exact, float(margin), int(k)
+        self.device, self.max_batch = fast.device, fast.max_batch
+        self.dtype = f"{fast.dtype}+{exact.dtype}"
+        self.macs_per_frame, self.anchors = fast.macs_per_frame, fast.anchors
+        dev = torch.device("cuda", self.device)
+        self._slots = torch.zeros((self.k,), dtype=torch.int32, device=dev)
+        self._xywh = torch.empty((self.k, 4), dtype=torch.float32, device=dev)
+        self._conf = torch.empty((self.k,), dtype=torch.float32, device=dev)
+        self._anchor = torch.empty((self.k,), dtype=torch.int32, device=dev)
+        self._pos = None  # view centre that makes a "view" the whole frame, per frame shape
+        self._idx_tmp = torch.empty((self.k,), dtype=torch.int32, device=dev)
+        self._pos_tmp = torch.empty((self.k, 2), dtype=torch.int32, device=dev)
+        self.replaced = torch.zeros((1,), dtype=torch.int32, device=dev)  # rows replaced so far (device counter)
+
+    # -- the detector interface -------------------------------------------------------------------------------------------
+    def predict(self, frames_dev, B: int, H: int, W: int, Cc: int, out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1,
+                iou: float = 0.7, max_det: int = 1, stream: int = 0):
+        if max_det != 1:
+            raise hip.WtkError("HybridDetector: max_det must be 1")
+        self.fast.predict(frames_dev, B, H, W, Cc, out_xywh, out_conf, out_anchor, conf=conf, iou=iou, max_det=1, stream=stream)
+        k = min(self.k, B)
+        m = self.fast.margin_buffer()
+        hip.recheck_select(m, B, k, self._slots, stream=stream)
+        if self._pos is None or self._pos[0] != (H, W):
+            # wtk_yolo_predict_views cuts frame[y0 : y0 + view_w, x0 : x0 + view_h] with (x0, y0) = pos - (view_w // 2, view_h // 2)
+            # (view_controller.py:158-172): view (H, W) centred there is the frame itself
+            p = torch.tensor([[H // 2, W // 2]] * self.k, dtype=torch.int32).to(self._slots.device)
+            self._pos = ((H, W), p)
+        self.exact.predict_views(frames_dev, B, H, W, Cc, self._slots, self._pos[1], k, H, W, self._xywh, self._conf, self._anchor, conf=conf, iou=iou,
+                                 max_det=1, stream=stream)
+        hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
+
+    def predict_views(self, frames_dev, n_frames: int, H: int, W: int, Cc: int, frame_index_dev, pos_xy_dev, B: int, view_w: int, view_h: int,
+                      out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1, iou: float = 0.7, max_det: int = 1, stream: int = 0):
+        if max_det != 1:
+            raise hip.WtkError("HybridDetector: max_det must be 1")
+        self.fast.predict_views(frames_dev, n_frames, H, W, Cc, frame_index_dev, pos_xy_dev, B, view_w, view_h, out_xywh, out_conf, out_anchor, conf=conf,
+                                iou=iou, max_det=1, stream=stream)
+        k = min(self.k, B)
+        m = self.fast.margin_buffer()
+        hip.recheck_select(m, B, k, self._slots, stream=stream)
+        # the weak rows' (frame, position): gathered by torch on the caller's stream (it must be torch's current stream)
+        sl = self._slots[:k].long()
+        if frame_index_dev is None:
+            self._idx_tmp[:k] = self._slots[:k]
+        else:
+            torch.index_select(frame_index_dev, 0, sl, out=self._idx_tmp[:k])
+        torch.index_select(pos_xy_dev, 0, sl, out=self._pos_tmp[:k])
+        self.exact.predict_views(frames_dev, n_frames, H, W, Cc, self._idx_tmp, self._pos_tmp, k, view_w, view_h, self._xywh, self._conf, self._anchor,
+                                 conf=conf, iou=iou, max_det=1, stream=stream)
+        hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
+
+    def set_profiling(self, enabled: bool):
+        self.fast.set_profiling(enabled)
+
+    def get_profile(self) -> dict:
+        return self.fast.get_profile()
+
+    def get_kernel_profile(self) -> dict:
+        return self.fast.get_kernel_profile()
+
+    def close(self):
+        self.fast.close()
+        self.exact.close()
