@@ -47,7 +47,8 @@ def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, monkeypatch, H, W, C,
     product carries the error of an fp32 product (2^-22 relative per operand pair), so the tensors agree to fp32 rounding
     accumulated over the layers in front of them — three orders of magnitude below the fp16 mode's 2^-11 per layer."""
     B = 3
-    monkeypatch.setenv("WTK_NO_HALO", no_halo)  # "1": the 3x3 stride-1 convs through the split implicit GEMM instead of the split window kernel
+    monkeypatch.setenv("WTK_NO_HALO", no_halo)  # "1": every 3x3 conv through the split implicit GEMM instead of the split window kernels
+    monkeypatch.setenv("WTK_NO_S2WIN", no_halo)
     rng = np.random.default_rng(H + W)
     frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
     outs = {}
@@ -77,8 +78,9 @@ def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, monkeypatch, H, W, C,
     np.testing.assert_allclose(res_s[0], res_r[0], rtol=0, atol=2e-3, equal_nan=True)
 
 
-def test_f16x3_full_size_640_survivors_equal_oracle(hip_lib):
-    size, B = 640, 4
+@pytest.mark.parametrize("size,B", [(640, 4), (1280, 2)])
+def test_f16x3_full_size_survivors_equal_oracle(hip_lib, size, B):
+    """BASELINE configs 2 and 5 frame shapes (1280x1280: the window kernels cut the 160-column maps into two strips)."""
     w, det, dims = _det("s", (size, size), "f16x3", B)
     oracle = yo.YoloOracle(w, dims)
     frames, _ = fr.synthetic_frames(B, size, seed=0)

@@ -1294,7 +1294,8 @@ hipError_t launch_ws64(HaloArgs a, int num_cus, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kS2Rows = 344; // window rows per buffer (43 pieces): BMT + (Wo + 1) + 2 <= 344  ->  Wo <= 85 at BMT = 256
 
-template <int BMT>
+// SPLIT: split-fp16 operands (see conv3x3_halo_kernel): pseudo-channel a.Cin / in_ld / out_ld, three MFMAs per tile pair and K step.
+template <int BMT, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
     asm volatile("" ::"s"(a.in), "s"(a.w), "s"(a.bias), "s"(a.in_ld), "s"(a.in_coff), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Cin), "s"(a.CoutPad), "s"(a.Kpad),
                  "s"(a.S), "s"(a.pitch), "s"(a.d_pitch.mul), "s"(a.d_pitch.sh1), "s"(a.d_pitch.sh2), "s"(a.d_nct.mul), "s"(a.d_nct.sh1), "s"(a.d_nct.sh2),
@@ -1377,11 +1378,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
 
     const int cb = n0 + wave_c * WC + lg * NV;
     floatx4 acc[TC][TP];
+    floatx4 acc1[SPLIT ? TC : 1][SPLIT ? TP : 1];
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const floatx4 b4 = (floatx4){a.bias[cb + i * 4 + 0], a.bias[cb + i * 4 + 1], a.bias[cb + i * 4 + 2], a.bias[cb + i * 4 + 3]};
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = b4;
+        for (int j = 0; j < TP; ++j) {
+            acc[i][j] = b4;
+            if constexpr (SPLIT) acc1[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     const int wrow_l = wave_c * WC + (lr >> 2) * NV + (lr & 3);
     const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
@@ -1390,6 +1395,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
     auto compute_tap = [&](const char *win, const char *wb, int tapoff) __attribute__((always_inline)) {
         const int base = prow0 + tapoff;
         const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4);
+        if constexpr (SPLIT) {
+            uint4 ph[TP], wh[TC], wl[TC], pl[TP];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) ph[j] = *reinterpret_cast<const uint4 *>(win + pfrag0 + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wh[i] = *reinterpret_cast<const uint4 *>(wb + wfrag0 + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wl[i] = *reinterpret_cast<const uint4 *>(wb + (wfrag0 ^ 64u) + i * 512);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pl[j] = *reinterpret_cast<const uint4 *>(win + (pfrag0 ^ 64u) + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    mma_h(wh[i], ph[j], acc[i][j], (T *)nullptr);
+                    mma_h(wl[i], ph[j], acc1[i][j], (T *)nullptr);
+                }
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(wh[i], pl[j], acc1[i][j], (T *)nullptr);
+            return;
+        }
 #pragma unroll
         for (int kh2 = 0; kh2 < 2; ++kh2) {
             const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
@@ -1481,17 +1509,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (SPLIT)
+                        v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                    else
+                        v[i * 4 + r] = acc[i][j][r];
+                }
             if (a.act) {
                 wtk_silu_scaled_run<NV>(v);
             }
-            store_run_h<NV>(out + pixj[j] * a.out_ld + a.out_coff + cb, v);
+            if constexpr (SPLIT)
+                wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out) + pixj[j] * a.out_ld + a.out_coff, cb, v);
+            else
+                store_run_h<NV>(out + pixj[j] * a.out_ld + a.out_coff + cb, v);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last chunk's duplicate requests must not outlive the block's LDS
 }
 
-template <int BMT> hipError_t launch_s2(HaloArgs a, hipStream_t stream) {
+template <int BMT, bool SPLIT = false> hipError_t launch_s2(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.blocks_per_strip * (a.CoutPad / 128);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     a.d_nct = make_fastdiv((unsigned)(a.CoutPad / 128));
@@ -1500,7 +1536,7 @@ template <int BMT> hipError_t launch_s2(HaloArgs a, hipStream_t stream) {
     a.d_pitch = make_fastdiv((unsigned)a.pitch);
     a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
     a.grid = (int)blocks;
-    hipLaunchKernelGGL((conv3x3_s2_kernel<BMT>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((conv3x3_s2_kernel<BMT, SPLIT>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1592,6 +1628,20 @@ hipError_t launch_conv3x3_s2(const HaloArgs &a, hipStream_t stream) {
     if (a.strips != 1 || a.S != a.W || a.pitch != a.W + 1 || bm + a.pitch + 2 > kS2Rows) return hipErrorInvalidValue;
     if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
     return bm == 128 ? launch_s2<128>(a, stream) : launch_s2<256>(a, stream);
+}
+
+// split-fp16 operands: real channel counts here
+bool split_s2win_eligible(int k, int stride, int cin, int cout, int cout_pad, int wo, bool plain) {
+    return k == 3 && stride == 2 && cin % 32 == 0 && cout_pad % 128 == 0 && cout == cout_pad && plain && 256 + (wo + 1) + 2 <= kS2Rows;
+}
+// a.Cin / Kpad / in_ld / in_coff / out_ld / out_coff in pseudo-channels (2 x real), a.Cout real
+hipError_t launch_conv3x3_s2_split(const HaloArgs &a, hipStream_t stream) {
+    if (a.Cin % 64 || a.CoutPad % 128 || a.Cout != a.CoutPad || a.out2 || a.tail_w || a.res || a.Kpad != 9 * a.Cin) return hipErrorInvalidValue;
+    if (a.in_ld % 64 || a.in_coff % 64 || a.out_ld % 64 || a.out_coff % 64) return hipErrorInvalidValue;
+    const int bm = a.bm == 128 ? 128 : 256;
+    if (a.strips != 1 || a.S != a.W || a.pitch != a.W + 1 || bm + a.pitch + 2 > kS2Rows) return hipErrorInvalidValue;
+    if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
+    return bm == 128 ? launch_s2<128, true>(a, stream) : launch_s2<256, true>(a, stream);
 }
 
 int ws64_rows_max() { return kWsRows; }

@@ -1317,7 +1317,27 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 a.res_ld *= 2, a.res_coff *= 2, a.out2_ld *= 2, a.out2_coff *= 2;
                 if (!a.out_f32) a.out_ld *= 2, a.out_coff *= 2;
             }
-            if (h->split && !op.halo) {
+            if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
+                split_s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0 && !ob.f32)) {
+                // strided 3x3, split operands: the parity-plane window kernel on pseudo-channels
+                HaloArgs g;
+                std::memset(&g, 0, sizeof(g));
+                g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
+                g.N = B, g.H = ob.h, g.W = ob.w, g.Cin = a.Cin;
+                g.Cout = op.cout, g.CoutPad = op.cout_pad;
+                g.w = op.w, g.bias = op.bias;
+                g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
+                g.act = op.act, g.Kpad = a.Kpad;
+                g.S = ob.w, g.pitch = ob.w + 1, g.strips = 1;
+                g.bm = 256;
+                g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 255) / 256);
+                if (2LL * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus) {
+                    g.bm = 128;
+                    g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 127) / 128);
+                }
+                g.zeros = h->zero_page;
+                HIP_TRY(launch_conv3x3_s2_split(g, st));
+            } else if (h->split && !op.halo) {
                 HIP_TRY(launch_conv_split(a, op.cfg, st));
             } else if (op.halo) {
                 HaloArgs g;

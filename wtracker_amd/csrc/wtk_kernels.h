@@ -222,6 +222,8 @@ bool halo_eligible(int k, int stride, int cin, int is_f16);
 bool split_halo_eligible(int k, int stride, int cin, int cout); // split-fp16 operands (real channel counts)
 int split_halo_cout_tile(int cout_stored);
 hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream); // channel counts / offsets but Cout in pseudo-channels
+bool split_s2win_eligible(int k, int stride, int cin, int cout, int cout_pad, int wo, bool plain); // real channel counts
+hipError_t launch_conv3x3_s2_split(const HaloArgs &a, hipStream_t stream);
 int halo_rows_max(int cout_stored, int slabs); // window rows the kernel variant for this Cout can hold
 void halo_geometry(int H, int W, int rows_max, int *S, int *pitch, int *strips, int *blocks_per_strip, int bm = 256); // per image (conv3x3_c32)
 // conv3x3_halo.hip: the N images of a strip are stacked vertically with ONE shared zero row between neighbours, and a map that
