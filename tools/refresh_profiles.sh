@@ -14,3 +14,8 @@ python tools/traffic_from_pmc.py profiles/${R}_pmc_fetch_size.csv profiles/${R}_
 python tools/mfma_util_from_pmc.py gpurun_out/pf_mfma/p_counter_collection.csv profiles/${R}_pmc_mfma_util.json > profiles/${R}_pmc_mfma_util.txt
 cp gpurun_out/pf_mfma/p_counter_collection.csv profiles/${R}_pmc_mfma_util.csv
 tail -1 gpurun_out/bench_default.log > profiles/${R}_bench_default.json
+# split-fp16 mode (tools/gpu_sessions/x3_trace.sh final): per-op table and per-kernel stats of the single-stream forward
+if [ -f gpurun_out/x3_layers_final.txt ]; then
+  cp gpurun_out/x3_layers_final.txt profiles/${R}_layer_table_f16x3_b64.txt
+  python tools/stats_from_trace.py gpurun_out/trx_final/t_kernel_trace.csv > profiles/${R}_kernel_stats_single_stream_f16x3_b64.csv
+fi
