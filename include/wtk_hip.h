@@ -250,11 +250,17 @@ int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_
  * reports a decision margin per frame (wtk_yolo_margin_buffer); the K frames of a batch with the smallest margins are
  * detected again by a full-precision handle (WTK_F16X3 / WTK_F32, e.g. through wtk_yolo_predict_views with
  * frame_index = slots) and replace the fast rows where margin < `margin`.  No host synchronisation: K is fixed.
- *   wtk_recheck_select  slots[k] = batch row of the k-th smallest margin (ties: lower row first; NaN = +inf), k < K
+ *   wtk_recheck_select  slots[k] = batch row of the k-th smallest margin (ties: lower row first; NaN = +inf), k < K;
+ *                       *n_weak (nullable) = min(K, rows with margin < `margin`): the leading slots that will be merged
+ *   wtk_yolo_set_dynamic_batch  the handle reads the number of batch rows that matter from DEVICE memory at run time
+ *                       (nullptr: off): kernels skip the tiles of images beyond it, rows beyond it hold scratch.  With
+ *                       n_dev = n_weak the second look costs what the weak frames cost, with no host round trip.
  *   wtk_recheck_merge   row slots[k] of dst_* = row k of src_* where margins[slots[k]] < margin; *n_replaced += count
  * Replaces nothing in the reference (yolo_controller.py:62-90 computes every frame in fp32).
  * ------------------------------------------------------------------------------------------ */
-int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, int32_t *slots_dev, void *stream);
+int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev,
+                       int32_t *n_weak_dev, void *stream);
+int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev);
 int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin,
                       const float *src_xywh, const float *src_conf, const int32_t *src_anchor, float *dst_xywh,
                       float *dst_conf, int32_t *dst_anchor, int32_t *n_replaced_dev, void *stream);

@@ -145,3 +145,33 @@ def test_closed_loop_controller_in_auto_precision_equals_oracle_controller(hip_l
     for a, b in zip(rows_g, rows_o):
         assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
         np.testing.assert_allclose([a["wrm_x"], a["wrm_y"], a["wrm_w"], a["wrm_h"]], [b["wrm_x"], b["wrm_y"], b["wrm_w"], b["wrm_h"]], atol=F32_BOX_ATOL)
+
+
+@pytest.mark.parametrize("dtype,size,B,n", [("f16x3", 256, 8, 3), ("f16x3", 640, 6, 1), ("fp16", 256, 8, 5), ("fp32", 160, 6, 2), ("f16x3", 128, 4, 0)])
+def test_dynamic_batch_rows_equal_the_static_run(hip_lib, dtype, size, B, n):
+    """wtk_yolo_set_dynamic_batch: the handle reads the number of batch rows that matter from device memory; kernels skip the tiles of
+    the images behind it.  The first n rows must be bit-identical to a static run of the same batch (tiles straddling the limit are
+    computed whole; rows behind it are scratch)."""
+    w, det, _ = _det("s", (size, size), dtype, B)
+    frames, _ = fr.synthetic_frames(B, size, seed=5)
+    dev = torch.from_numpy(frames).cuda()
+    out = [torch.empty((B, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    cf = [torch.empty((B,), dtype=torch.float32, device="cuda") for _ in range(2)]
+    an = [torch.empty((B,), dtype=torch.int32, device="cuda") for _ in range(2)]
+    det.predict(dev, B, size, size, 1, out[0], cf[0], an[0], conf=0.1)
+    torch.cuda.synchronize()
+    box_s, cls_s = det.debug_head(B)
+    n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
+    det.set_dynamic_batch(n_dev)
+    det.predict(dev, B, size, size, 1, out[1], cf[1], an[1], conf=0.1)
+    torch.cuda.synchronize()
+    box_d, cls_d = det.debug_head(B)
+    np.testing.assert_array_equal(cls_d[:n], cls_s[:n])
+    np.testing.assert_array_equal(box_d[:n], box_s[:n])
+    np.testing.assert_array_equal(out[1][:n].cpu().numpy(), out[0][:n].cpu().numpy())
+    np.testing.assert_array_equal(an[1][:n].cpu().numpy(), an[0][:n].cpu().numpy())
+    det.set_dynamic_batch(None)  # back to static: the whole batch again
+    det.predict(dev, B, size, size, 1, out[1], cf[1], an[1], conf=0.1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out[1].cpu().numpy(), out[0].cpu().numpy())
+    det.close()

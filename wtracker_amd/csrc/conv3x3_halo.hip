@@ -238,7 +238,15 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     const int lr = lane & 15, lg = lane >> 4;
 
     // ---- block -> (cout tile, row block, strip, image); XCD-aware bijective remap
-    const int nwg = a.grid;
+    const int nct = a.CoutPad / BN;
+    int nwg = a.grid;
+    if (a.n_dyn) { // dynamic batch: only the row blocks that start inside the first *n_dyn images exist; the remap runs over them, so
+                   // the surviving tiles stay spread over all XCDs (block-uniform exit for the rest)
+        const int lim = min(max(*a.n_dyn, 0), a.N) * (a.H + 1) * a.pitch;
+        const int live = ((lim + BMT - 1) / BMT) * a.strips * nct;
+        if ((int)blockIdx.x >= live) return;
+        nwg = min(nwg, live);
+    }
     int L;
     {
         const int bid = blockIdx.x;
@@ -247,7 +255,6 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
     // launch-invariant divisors go through FastDiv: a runtime integer division is ~40 instructions, and the ~25 of them this
     // kernel used to execute before its first LDS-DMA request cost every block 1.3-1.9 us (stamped) of an 11-33 us life
-    const int nct = a.CoutPad / BN;
     const unsigned t = fdiv((unsigned)L, a.d_nct);
     const int n0 = (L - (int)t * nct) * BN;
     const int rb = (int)fdiv(t, a.d_strips); // row blocks major, strips minor: the strips of a row block share input rows (L2)
@@ -1315,14 +1322,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_p = wave / WAVES_C, wave_c = wave % WAVES_C;
     const int lr = lane & 15, lg = lane >> 4;
-    const int nwg = a.grid;
+    const int nct = a.CoutPad / BN;
+    int nwg = a.grid;
+    if (a.n_dyn) { // dynamic batch (see conv3x3_halo_kernel)
+        const int lim = min(max(*a.n_dyn, 0), a.N) * (a.H + 1) * a.pitch;
+        const int live = ((lim + BMT - 1) / BMT) * nct;
+        if ((int)blockIdx.x >= live) return;
+        nwg = min(nwg, live);
+    }
     int L;
     {
         const int bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int nct = a.CoutPad / BN;
     const unsigned t = fdiv((unsigned)L, a.d_nct);
     const int n0 = (L - (int)t * nct) * BN;
     const int o0 = (int)t * BMT; // one strip: row blocks only

@@ -155,7 +155,13 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     // heuristic only); the blocks of a label walk their range with stride = #blocks of that label, so at
     // any moment an XCD works on neighbouring tiles (shared 3x3 halos, shared weights).
     const int nct = a.CoutPad / BN;
-    const int total_tiles = a.ptiles * nct;
+    int ptiles_eff = a.ptiles;
+    if (a.n_dyn) { // dynamic batch: only the pixel tiles that start inside the first *n_dyn images (rows behind them are scratch)
+        const long long n_eff = min(max(*a.n_dyn, 0), a.N);
+        const long long pt = a.tile_w == 0 ? (n_eff * a.Ho * a.Wo + BM - 1) / BM : n_eff * a.tiles_x * a.tiles_y;
+        ptiles_eff = (int)min((long long)a.ptiles, pt);
+    }
+    const int total_tiles = ptiles_eff * nct;
     int t_begin, my_tiles, t_stride;
     {
         const int G = gridDim.x, bid = blockIdx.x;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
     t /= tiles_x;
     const int ty = t % tiles_y;
     const int n = t / tiles_y;
+    if (a.n_dyn && n >= *a.n_dyn) return; // dynamic batch: images beyond the device-side count are not computed (block-uniform)
     const int oy0 = ty * 16, ox0 = tx * 16;
     const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
 

@@ -212,6 +212,11 @@ __global__ __launch_bounds__(256) void recheck_select_kernel(const RecheckArgs a
         for (int j = 0; j < a.B; ++j) rank += (m[j] < mi || (m[j] == mi && j < i)) ? 1 : 0;
         if (rank < a.K) a.slots[rank] = i;
     }
+    if (a.n_weak && threadIdx.x == 0) {
+        int n = 0;
+        for (int j = 0; j < a.B; ++j) n += m[j] < a.thr ? 1 : 0;
+        *a.n_weak = n < a.K ? n : a.K;
+    }
 }
 
 __global__ __launch_bounds__(64) void recheck_merge_kernel(const RecheckArgs a) {

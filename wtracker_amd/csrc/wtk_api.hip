@@ -297,12 +297,12 @@ extern "C" int wtk_track_training_pairs(const void *track_dev, int32_t track_is_
     return 0;
 }
 
-extern "C" int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, int32_t *slots_dev, void *stream) {
+extern "C" int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev, int32_t *n_weak_dev, void *stream) {
     if (!margins_dev || !slots_dev) return fail("wtk_recheck_select: null argument");
     if (B <= 0 || B > 1024 || K <= 0 || K > B) return fail("wtk_recheck_select: need 1 <= K <= B <= 1024");
     RecheckArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.margins = margins_dev, a.B = B, a.K = K, a.slots = slots_dev;
+    a.margins = margins_dev, a.B = B, a.K = K, a.slots = slots_dev, a.thr = margin, a.n_weak = n_weak_dev;
     HIP_TRY(launch_recheck_select(a, (hipStream_t)stream));
     return 0;
 }
@@ -466,6 +466,7 @@ struct wtk_yolo {
     // WTK_F16X3: split-fp16 storage (wtk_kernels.h, kSplitScale).  Planned like the fp32 mode (is_f16 = 0, esize = 4: a split tensor
     // takes the same 4 bytes per value), launched on the SPLIT instantiations of the fp16 kernels with pseudo-channel arguments.
     int split = 0;
+    const int *n_dyn = nullptr; // wtk_yolo_set_dynamic_batch: device-side count of the batch rows that matter (<= B of the call)
     int S_h = 0, S_w = 0, max_batch = 0;
     ModelDims dims;
     std::vector<Buf> bufs;
@@ -1249,6 +1250,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.Cout = op.cout;
             a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
             a.out_split = h->split; // fp32 arithmetic (pixels / 255 are not fp16 numbers), split store
+            a.n_dyn = h->n_dyn;
             HIP_TRY(launch_stem(a, h->is_f16, st));
             ++launches[0];
             flops[0] += op_flops(op);
@@ -1283,6 +1285,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.out_ld = ob.C;
             a.out_coff = op.out_coff;
             a.out_f32 = ob.f32;
+            a.n_dyn = h->n_dyn;
             if (op.out2_buf >= 0) {
                 a.out2 = h->bufs[op.out2_buf].ptr;
                 a.out2_ld = h->bufs[op.out2_buf].C;
@@ -1328,6 +1331,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.w = op.w, g.bias = op.bias;
                 g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
                 g.act = op.act, g.Kpad = a.Kpad;
+                g.n_dyn = h->n_dyn;
                 g.S = ob.w, g.pitch = ob.w + 1, g.strips = 1;
                 g.bm = 256;
                 g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 255) / 256);
@@ -1350,6 +1354,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.out2 = a.out2, g.out2_ld = a.out2_ld, g.out2_coff = a.out2_coff;
                 g.res = a.res, g.res_ld = a.res_ld, g.res_coff = a.res_coff;
                 g.act = op.act, g.Kpad = op.Kpad;
+                g.n_dyn = h->n_dyn;
                 g.slabs = h->halo_slabs;
                 if (h->split) g.Cin = a.Cin, g.Kpad = a.Kpad, g.slabs = 3; // pseudo-channels
                 if (op.tail_op >= 0) {
@@ -1412,6 +1417,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.w = op.w, g.bias = op.bias;
                 g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
                 g.act = op.act, g.Kpad = op.Kpad;
+                g.n_dyn = h->n_dyn;
                 g.S = ob.w, g.pitch = ob.w + 1, g.strips = 1;
                 g.bm = 256;
                 g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 255) / 256);
@@ -1578,6 +1584,14 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
     if (out_conf) HIP_TRY(hipMemcpyAsync(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost, st));
     if (out_anchor) HIP_TRY(hipMemcpyAsync(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev) {
+    if (!h) return fail("wtk_yolo_set_dynamic_batch: null handle");
+    h->n_dyn = n_dev;
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec); // captured launches carry the old pointer
+    h->graphs.clear();
     return 0;
 }
 

@@ -164,6 +164,7 @@ struct ConvArgs {
     const float *tail_bias; // [128]
     void *tail_out;
     int tail_kpad, tail_ld, tail_coff, tail_act;
+    const int *n_dyn; // nullable: device-side image count <= N; pixel tiles that start beyond its last image are never visited
     int out_f32; // fp16 kernels only: `out` is an fp32 tensor (the six Detect output convs: head logits are never rounded to fp16)
     // split mode (launch_conv_split): in / in2 / res / out / out2 are split-fp16 tensors; in_ld, in_coff, Cin, K, Kpad, in2_*, res_*, out_ld,
     // out_coff are given in PSEUDO-channels (2 x the real ones); Cout / CoutPad stay real (an fp32 `out` keeps real out_ld / out_coff)
@@ -216,6 +217,7 @@ struct HaloArgs {
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
     int grid; // blocks of the launch (filled by the launchers: reading gridDim.x costs the set-up one more scalar-load round trip)
+    const int *n_dyn; // nullable: device-side image count <= N (conv3x3_halo_kernel, conv3x3_s2_kernel): blocks whose tile starts beyond its last image exit at once
     FastDiv d_bps, d_strips, d_pitch, d_nct, d_h1; // filled by the launchers (d_h1: H + 1, conv3x3_halo.hip's stacked rows)
 };
 bool halo_eligible(int k, int stride, int cin, int is_f16);
@@ -256,6 +258,7 @@ struct StemArgs {
     int Cout;
     int Ho, Wo;
     int out_split; // fp32 kernel only: store split-fp16 pairs (Cout % 32 == 0)
+    const int *n_dyn; // nullable: device-side image count <= N (wtk_yolo_set_dynamic_batch): blocks of images beyond it exit at once
 };
 hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream);
 
@@ -485,6 +488,7 @@ struct RecheckArgs {
     float *dst_xywh, *dst_conf;
     int *dst_anchor;
     int *n_replaced;      // nullable: += number of rows replaced
+    int *n_weak;          // select, nullable: = min(K, number of rows with margin < thr) — the leading slots (the input of wtk_yolo_set_dynamic_batch)
 };
 hipError_t launch_recheck_select(const RecheckArgs &a, hipStream_t stream);
 hipError_t launch_recheck_merge(const RecheckArgs &a, hipStream_t stream);

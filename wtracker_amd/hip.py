@@ -57,7 +57,7 @@ SYMBOLS = [
     "wtk_yolo_predict_nms", "wtk_yolo_decode_nms_host",
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
-    "wtk_recheck_select", "wtk_recheck_merge",
+    "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch",
 ]
 
 
@@ -107,7 +107,8 @@ def load() -> C.CDLL:
     lib.wtk_yolo_decode_nms_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp]
     lib.wtk_yolo_margin_buffer.argtypes = [vp, C.POINTER(vp)]
     lib.wtk_yolo_last_margins_host.argtypes = [vp, i32, vp]
-    lib.wtk_recheck_select.argtypes = [vp, i32, i32, vp, vp]
+    lib.wtk_recheck_select.argtypes = [vp, i32, i32, f32, vp, vp, vp]
+    lib.wtk_yolo_set_dynamic_batch.argtypes = [vp, vp]
     lib.wtk_recheck_merge.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.wtk_comm_unique_id.argtypes = [vp, C.c_size_t]
     lib.wtk_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
@@ -152,9 +153,9 @@ def crop_views(frames_dev, N: int, H: int, W: int, Cc: int, pos_xy_dev, view_w: 
                                  C.c_void_p(stream)), "wtk_crop_views")
 
 
-def recheck_select(margins_dev, B: int, K: int, slots_dev, stream: int = 0):
-    """slots[k] = batch row of the k-th smallest decision margin (device int32 [K]); asynchronous on `stream`."""
-    _check(load().wtk_recheck_select(_ptr(margins_dev), B, K, _ptr(slots_dev), C.c_void_p(stream)), "wtk_recheck_select")
+def recheck_select(margins_dev, B: int, K: int, margin: float, slots_dev, n_weak_dev=None, stream: int = 0):
+    """slots[k] = batch row of the k-th smallest decision margin (device int32 [K]); n_weak = min(K, rows below `margin`); asynchronous on `stream`."""
+    _check(load().wtk_recheck_select(_ptr(margins_dev), B, K, margin, _ptr(slots_dev), _ptr(n_weak_dev), C.c_void_p(stream)), "wtk_recheck_select")
 
 
 def recheck_merge(margins_dev, slots_dev, B: int, K: int, margin: float, src_xywh, src_conf, src_anchor, dst_xywh, dst_conf=None, dst_anchor=None,
@@ -375,6 +376,10 @@ class HipYolo:
         """Device pointers / torch CUDA tensors; asynchronous on `stream`."""
         _check(load().wtk_yolo_predict(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh),
                                        _ptr(out_conf), _ptr(out_anchor), C.c_void_p(stream)), "wtk_yolo_predict")
+
+    def set_dynamic_batch(self, n_dev):
+        """`n_dev`: device int32 scalar (tensor / pointer) holding the number of batch rows that matter in the following calls, or None."""
+        _check(load().wtk_yolo_set_dynamic_batch(self._h, _ptr(n_dev)), "wtk_yolo_set_dynamic_batch")
 
     def last_margins(self, B: int) -> np.ndarray:
         """Decision margins (class-logit units) of the B frames of the last max_det = 1 call: min(best - second-best anchor logit,

@@ -6,7 +6,9 @@ best logit and the confidence threshold: wtk_yolo_margin_buffer).  Where that ma
 fp32 arithmetic picks (yolo/yolo_train_config.yaml:51 `half: False`).  HybridDetector runs the fp16 handle on the whole batch,
 then — without a host round trip — the K frames with the smallest margins through a full-precision handle ("f16x3": split-fp16
 operands, fp32-grade results at 2.4x the fp32 mode's rate; or "fp32"), and merges the rows whose margin is below `margin`.
-K is fixed, so the step is a constant sequence of launches on one stream.
+K is fixed, so the step is a constant sequence of launches on one stream; the full-precision handle reads the number of weak frames
+from device memory (wtk_yolo_set_dynamic_batch) and its kernels skip the tiles of the slots beyond it, so the second look costs what
+the weak frames cost, not what K frames cost.
 
 It has the detector interface TrackPipeline uses (predict / predict_views / device / max_batch), so `dets=[HybridDetector(...)]`
 turns the open-loop pipeline into the hybrid mode.  torch: device memory only.
@@ -37,6 +39,8 @@ class HybridDetector:
         self._idx_tmp = torch.empty((self.k,), dtype=torch.int32, device=dev)
         self._pos_tmp = torch.empty((self.k, 2), dtype=torch.int32, device=dev)
         self.replaced = torch.zeros((1,), dtype=torch.int32, device=dev)  # rows replaced so far (device counter)
+        self._n_weak = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows of the current batch: the second look's dynamic batch size
+        exact.set_dynamic_batch(self._n_weak)
 
     # -- the detector interface -------------------------------------------------------------------------------------------
     def predict(self, frames_dev, B: int, H: int, W: int, Cc: int, out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1,
@@ -46,7 +50,7 @@ class HybridDetector:
         self.fast.predict(frames_dev, B, H, W, Cc, out_xywh, out_conf, out_anchor, conf=conf, iou=iou, max_det=1, stream=stream)
         k = min(self.k, B)
         m = self.fast.margin_buffer()
-        hip.recheck_select(m, B, k, self._slots, stream=stream)
+        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream)
         if self._pos is None or self._pos[0] != (H, W):
             # wtk_yolo_predict_views cuts frame[y0 : y0 + view_w, x0 : x0 + view_h] with (x0, y0) = pos - (view_w // 2, view_h // 2)
             # (view_controller.py:158-172): view (H, W) centred there is the frame itself
@@ -64,7 +68,7 @@ class HybridDetector:
                                 iou=iou, max_det=1, stream=stream)
         k = min(self.k, B)
         m = self.fast.margin_buffer()
-        hip.recheck_select(m, B, k, self._slots, stream=stream)
+        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream)
         # the weak rows' (frame, position): gathered by torch on the caller's stream (it must be torch's current stream)
         sl = self._slots[:k].long()
         if frame_index_dev is None:
@@ -87,4 +91,5 @@ class HybridDetector:
 
     def close(self):
         self.fast.close()
+        self.exact.set_dynamic_batch(None)
         self.exact.close()
