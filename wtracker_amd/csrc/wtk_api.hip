@@ -1590,7 +1590,11 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
 extern "C" int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev) {
     if (!h) return fail("wtk_yolo_set_dynamic_batch: null handle");
     h->n_dyn = n_dev;
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec); // captured launches carry the old pointer
+    if (!h->graphs.empty()) { // captured launches of the host entry points carry the old pointer
+        DEVICE_GUARD(h);
+        if (h->host_stream) HIP_TRY(hipStreamSynchronize(h->host_stream));
+    }
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
     return 0;
 }
