@@ -170,7 +170,7 @@ template <bool NT> __global__ __launch_bounds__(256, 2) void conv1x1_wide_kernel
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r];
-            if (a.act) wtk_silu_scaled_run<16>(v);
+            if (a.act) wtk_silu_scaled_run<16, (WTK_SILU_SCALAR_MASK & 4) != 0>(v);
             _Float16 *o = out + pix * a.out_ld + a.out_coff + cb;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

@@ -1192,11 +1192,14 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r];
             if (a.act) {
-                wtk_silu_scaled_run<NV>(v);
+                wtk_silu_scaled_run<NV, (WTK_SILU_SCALAR_MASK & 1) != 0>(v);
             }
             if (res) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) v[i] += (float)rraw[j][i >> 3][i & 7];
+                for (int i = 0; i < NV; ++i) {
+                    v[i] += (float)rraw[j][i >> 3][i & 7];
+                    if constexpr ((WTK_SILU_SCALAR_MASK & 1) != 0) v[i] = wtk_pin_f32(v[i]);
+                }
             }
             if (pixj[j] >= 0) store_run_h<NV>(out + pixj[j] * a.out_ld + a.out_coff + cb, v);
         }

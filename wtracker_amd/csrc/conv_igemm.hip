@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
                 for (int t = 0; t < TC; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][j][r];
-                if (a.act) wtk_silu_scaled_run<NV>(v);
+                if (a.act) wtk_silu_scaled_run<NV, (WTK_SILU_SCALAR_MASK & 2) != 0>(v);
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
                     h8 hv;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
                             v[t * 4 + r] = acc[t][j][r]; // bias already inside
                     }
                 if (a.act) {
-                    wtk_silu_scaled_run<NV>(v);
+                    wtk_silu_scaled_run<NV, (WTK_SILU_SCALAR_MASK & 2) != 0>(v);
                 }
                 if (res) {
                     float rv[NV];

@@ -66,9 +66,24 @@ __device__ __forceinline__ float wtk_silu_scaled(float a) {
 // SiLU of a run of values, two at a time: the add and the multiply go through v_pk_add_f32 / v_pk_mul_f32 (two IEEE fp32
 // operations per instruction — the same results as the scalar form), so a pair costs 2 v_exp + 2 v_rcp + 2 packed ops instead of
 // 2 v_exp + 2 v_rcp + 4 scalar ops in epilogues whose only work is this.
+#ifndef WTK_SILU_SCALAR_MASK
+#define WTK_SILU_SCALAR_MASK 0 // bit 0: conv3x3_ws64_kernel, bit 1: conv_igemm_kernel, bit 2: conv1x1_wide_kernel (A/B builds)
+#endif
 typedef float wtk_f2 __attribute__((ext_vector_type(2)));
-template <int NV> __device__ __forceinline__ void wtk_silu_scaled_run(float (&v)[NV]) {
+// SCALAR: v_add_f32 / v_mul_f32 instead of the packed forms (the sums are pinned so that the SLP pass cannot re-pack them).  For epilogues
+// that run BESIDE a wave issuing MFMAs: there a packed fp32 instruction costs 27-32 issue cycles against 6 alone (tools/ubench/valu_cost.hip).
+// Same IEEE operations, bit-identical results.
+template <int NV, bool SCALAR = false> __device__ __forceinline__ void wtk_silu_scaled_run(float (&v)[NV]) {
     static_assert(NV % 2 == 0, "pairs");
+    if constexpr (SCALAR) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float e = __builtin_amdgcn_exp2f(-v[i]);
+            const float d = wtk_pin_f32(1.0f + e);
+            v[i] = wtk_pin_f32(v[i] * __builtin_amdgcn_rcpf(d));
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; i += 2) {
         const wtk_f2 a = {v[i], v[i + 1]};
