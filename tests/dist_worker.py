@@ -12,8 +12,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16"):
-    """Shared by the rank processes and by the single-rank comparison run in the test."""
+import numpy as np  # noqa: E402
+
+
+def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16", hybrid=False):
+    """Shared by the rank processes and by the single-rank comparison run in the test.  `hybrid`: scale-s HybridDetector lanes (fp16 +
+    an f16x3 second look at every row below the margin: ceiling = batch, so the replaced rows do not depend on how frames are batched)."""
     import torch
 
     from wtracker_amd import hip, resmlp
@@ -21,10 +25,20 @@ def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, sca
     from wtracker_amd.pipeline import TrackPipeline
 
     folded = resmlp.load_npz(os.path.join(ROOT, "tests", "golden", "resmlp_100ms.npz"))
+    if hybrid:
+        scale = "s"
     w = ys.synthetic_weights(scale, 1, seed=0)
     depth, width, maxch = ys.SCALES[scale]
-    dets = [hip.HipYolo(w, (size, size), batch, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch, device=device.index or 0)
-            for _ in range(lanes)]
+
+    def handle(dt):
+        return hip.HipYolo(w, (size, size), batch, dtype=dt, nc=1, width=width, depth=depth, max_channels=maxch, device=device.index or 0)
+
+    if hybrid:
+        from wtracker_amd.hybrid import HybridDetector
+
+        dets = [HybridDetector(handle("fp16"), handle("f16x3"), margin=0.5, k=batch) for _ in range(lanes)]  # wide margin: plenty of rows take the second look
+    else:
+        dets = [handle(dtype) for _ in range(lanes)]
     mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=device.index or 0)
     total = steps * batch * world
     pipe = TrackPipeline(dets, mlp, folded, batch, total, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9, conf=0.1,
@@ -36,6 +50,8 @@ def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, sca
     pipe.synchronize()
     torch.cuda.synchronize(device)
     out = dict(track=pipe.track.cpu().numpy(), moves=pipe.moves.cpu().numpy(), valid=pipe.valid.cpu().numpy())
+    if hybrid:
+        out["replaced"] = np.array([sum(int(d.replaced.item()) for d in dets)])
     for d in dets:
         d.close()
     return out
@@ -48,6 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--hybrid", action="store_true")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
@@ -65,7 +82,7 @@ def main():
     else:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     frames_np, _ = fr.synthetic_frames(args.steps * args.batch * world, 128, seed=4)
-    out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes)
+    out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes, hybrid=args.hybrid)
     np.savez(args.out, **out)
     dist.barrier()
     dist.destroy_process_group()

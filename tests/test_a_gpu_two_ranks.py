@@ -25,27 +25,29 @@ def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
 
     assert not torch.cuda.is_initialized(), "this test must run before anything touches the GPU in this process"
     world, B, steps = 2, 32, 4
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--out", str(tmp_path / f"rank{r}.npz"),
-               "--batch", str(B), "--steps", str(steps), "--lanes", "2", "--backend", "gloo"]
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=420)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(o)
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    for tag, extra in (("rank", []), ("hyb", ["--hybrid"])):  # two worlds of two ranks, one after the other, both before this process touches the GPU
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+            cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--out", str(tmp_path / f"{tag}{r}.npz"),
+                   "--batch", str(B), "--steps", str(steps), "--lanes", "2", "--backend", "gloo"] + extra
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=420)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            outs.append(o)
+        for r, p in enumerate(procs):
+            assert p.returncode == 0, f"{tag} {r} failed:\n{outs[r][-3000:]}"
+        assert not torch.cuda.is_initialized()
 
     # single-rank run of the same 2*B*steps frames in this process (first GPU use of the parent)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,3 +62,14 @@ def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
         np.testing.assert_array_equal(z["track"], one["track"])  # NaN rows compare equal position-wise
         np.testing.assert_array_equal(z["valid"], one["valid"])
         np.testing.assert_array_equal(z["moves"], one["moves"])
+    # the hybrid lanes (fp16 + device-side f16x3 second look, merged BEFORE the exchange): the same rows are replaced however the frames are batched
+    hyb = run_pipeline(frames_np, B * world, steps, 0, 1, None, torch.device("cuda", 0), lanes=1, hybrid=True)
+    assert int(hyb["replaced"][0]) > 0
+    replaced = 0
+    for r in range(world):
+        z = np.load(tmp_path / f"hyb{r}.npz")
+        np.testing.assert_array_equal(z["track"], hyb["track"])
+        np.testing.assert_array_equal(z["valid"], hyb["valid"])
+        np.testing.assert_array_equal(z["moves"], hyb["moves"])
+        replaced += int(z["replaced"][0])
+    assert replaced == int(hyb["replaced"][0])  # every rank replaces the weak rows of its own share

@@ -70,3 +70,18 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_one_hip_runtime_whatever_the_import_order(hip_lib):
+    """libwtk_hip.so loaded BEFORE torch must not bring a second HIP / HSA runtime into the process (the one that initialises second
+    would see no GPU): hip.load() maps torch's copies first, so both orders end with exactly one libamdhip64 and one libhsa-runtime64."""
+    import subprocess
+    import sys
+
+    probe = ("import sys; sys.path.insert(0, %r); %s; "
+             "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'amdhip64' in l or 'hsa-runtime64' in l)))")
+    for order in ("from wtracker_amd import hip; hip.load(); import torch", "import torch; from wtracker_amd import hip; hip.load()"):
+        out = subprocess.run([sys.executable, "-c", probe % (ROOT, order)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        libs = eval(out.stdout.strip().splitlines()[-1])
+        assert len([p for p in libs if "amdhip64" in p]) == 1 and len([p for p in libs if "hsa-runtime64" in p]) == 1, (order, libs)

@@ -65,6 +65,33 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP / HSA runtime per process.  PyTorch-ROCm ships its own libamdhip64.so / libhsa-runtime64.so (same sonames as
+    /opt/rocm's).  Loaded AFTER `import torch`, libwtk_hip.so binds to torch's copies (soname match) and both share one runtime;
+    loaded BEFORE it, /opt/rocm's copies come in first, torch later maps its own by path, and the second runtime to initialise
+    finds no GPU ("No HIP GPUs are available").  So when torch is installed but not imported yet, its runtime libraries are
+    mapped first (without importing torch)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return  # fall back to the system runtime: nothing else to do here
+
+
 def load() -> C.CDLL:
     """Load libwtk_hip.so (built in-tree by `python -m wtracker_amd._build` / __graft_entry__.build())."""
     global _lib
@@ -73,6 +100,7 @@ def load() -> C.CDLL:
     if not os.path.exists(_LIB_PATH):
         raise WtkError(f"{_LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                        "there is no CPU fallback")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(_LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     lib.wtk_last_error.restype = C.c_char_p
