@@ -43,7 +43,7 @@ import torch  # noqa: E402
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  f16x3 (split-fp16 operands): a product is three fp16 MFMAs, so the
 # ALGORITHMIC flop rate (2 per multiply-accumulate of the model) is bounded by a third of the fp16 peak.
-PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0}
+PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0, "hybrid": 2500.0}  # hybrid: the profiled handle is its fp16 one
 HBM_PEAK_GBPS = 8000.0
 # the hybrid sub-object: decisions with a margin below 0.04 get a second, full-precision look (at most 24 per 64 frames).  Every survivor mismatch of the
 # fp16 mode measured so far (20 in 768 frames, tools/margin_study.py) has a margin below 0.019; 16.5 % of the frames are below 0.04, at most 16 per batch.
@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=10, help="timed windows of --steps steps each (median reported)")
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config 3: 64)")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "f16x3"], help="precision of the headline value")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "f16x3", "hybrid"], help="precision mode of the headline value")
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline / parity sample (0 = skip both)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing (no roofline object)")
