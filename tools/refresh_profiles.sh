@@ -19,3 +19,7 @@ if [ -f gpurun_out/x3_layers_final.txt ]; then
   cp gpurun_out/x3_layers_final.txt profiles/${R}_layer_table_f16x3_b64.txt
   python tools/stats_from_trace.py gpurun_out/trx_final/t_kernel_trace.csv > profiles/${R}_kernel_stats_single_stream_f16x3_b64.csv
 fi
+# split-fp16 mode, MFMA-busy counters (tools/gpu_sessions/mfma_util_x3.sh)
+if [ -f gpurun_out/pf_mfma_x3/p_counter_collection.csv ]; then
+  python tools/mfma_util_from_pmc.py gpurun_out/pf_mfma_x3/p_counter_collection.csv | sed 's/forward, fp16, 640x640/forward, f16x3 (three MFMAs per product), 640x640/' > profiles/${R}_pmc_mfma_util_f16x3.txt
+fi
