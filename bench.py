@@ -46,7 +46,7 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0, "hybrid": 2500.0}  # hybrid: the profiled handle is its fp16 one
 HBM_PEAK_GBPS = 8000.0
 # the hybrid sub-object: decisions with a margin below 0.04 get a second, full-precision look (at most 24 per 64 frames).  Every survivor mismatch of the
-# fp16 mode measured so far (20 in 768 frames, tools/margin_study.py) has a margin below 0.019; 16.5 % of the frames are below 0.04, at most 16 per batch.
+# fp16 mode measured so far (30 in 1 792 frames, tools/margin_study.py) has a margin below 0.019; 16.5 % of the frames are below 0.04, at most 16 per batch.
 # The second look's cost follows the NUMBER of weak frames (device-side dynamic batch, wtk_yolo_set_dynamic_batch), so K is only a ceiling.
 HYBRID_MARGIN, HYBRID_K_PER_64 = 0.04, 24
 PROFILE_ROUND = "r02"
