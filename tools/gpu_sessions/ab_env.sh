@@ -1,13 +1,12 @@
-# A/B an environment switch in one GPU session: usage ab_env.sh VAR valA valB
+# A/B of environment settings under the default two-lane bench, round-robin: `ab_env.sh ROUNDS "K=V" "K=V" ...` (use X=0 for the default)
 R=$GRAFT_REPO_ROOT
-VAR=$1; A=$2; B=$3
-for rep in 1 2 3; do
-  for val in $A $B; do
-    env $VAR=$val WTK_NO_SIDE_STREAM=1 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --cpu-frames 0 --lanes 1 > gpurun_out/ab_env.log 2>&1
-    echo $rep $VAR=$val $(python -c "import json; d=json.loads(open('gpurun_out/ab_env.log').read().strip().splitlines()[-1]); print(round(d['value']), round(d['roofline']['class_ms_per_step']['conv'],4))")
+N=$1; shift
+cd $R
+for i in $(seq 1 $N); do
+  for kv in "$@"; do
+    env $kv timeout -k 10 200 python3 bench.py --no-fp32 --cpu-frames 0 --no-profile > gpurun_out/abenv_tmp.log 2>&1 || { echo "failed $kv"; tail -3 gpurun_out/abenv_tmp.log; continue; }
+    python3 -c "
+import json
+j=json.loads(open('gpurun_out/abenv_tmp.log').read().strip().splitlines()[-1]); print('%-28s %6.0f frames/s  median window %.2f ms' % ('$kv', j['value'], j['windows']['median_ms']))"
   done
-done
-cd /tmp && export TMPDIR=/tmp WTK_NO_SIDE_STREAM=1
-for val in $A $B; do
-  env $VAR=$val timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_ab_$val -o bench -- python3 $R/bench.py --steps 8 --warmup 3 --cpu-frames 0 --lanes 1 --no-profile > $R/gpurun_out/prof_ab_$val.log 2>&1 || echo fail $val
 done

@@ -451,6 +451,8 @@ struct Op {
     int side = 0;        // 1: runs on the handle's side stream (Detect towers of P3 / P4)
     int wait_feat = -1;  // side ops: feature event (0: P3 ready, 1: P4 ready) to wait for before the first one
     int signal_feat = -1; // main ops: record this feature event after the op
+    int signal_d1 = -1;   // Detect first conv of level i: record d1_ev[i] on its stream after the op
+    int wait_d1 = -1;     // first op of a class tower: wait for d1_ev[i]
     void *w = nullptr; // packed device weights
     float *bias = nullptr;
     double macs_per_image = 0;
@@ -508,9 +510,13 @@ struct wtk_yolo {
     static constexpr int kProfKernels = 7, kProfEvents = 96;
     hipEvent_t ev[kProfEvents];
     // concurrency: the P3 / P4 Detect towers run on a side stream next to the PAN path
-    hipStream_t side_stream = nullptr;
-    hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done = nullptr;
+    // Side streams of one forward pass (op.side = index, 0 = the caller's stream): 1 / 2 = P3 / P4 Detect towers (they only need t15 / t18),
+    // 3 / 4 / 5 = the class towers of P3 / P4 / P5 (independent of the box tower behind the shared first conv)
+    static constexpr int kSideStreams = 6;
+    hipStream_t side_stream[kSideStreams] = {};
+    hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done[kSideStreams] = {}, d1_ev[3] = {};
     int use_side = 1;
+    int side_streams = 2; // WTK_SIDE_STREAMS (A/B switch): 1: P3 and P4 towers share one side stream; 2 (default): one each (+0.5..1.6 %); 3: + class towers on their own streams (-11 %: more streams than hardware queues)
     // launch-bound regime (small batches): the whole forward is captured once per argument set and replayed
     struct GraphEntry {
         const void *frames;
@@ -740,8 +746,12 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; ++i)
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
-    if (h->side_done) (void)hipEventDestroy(h->side_done);
-    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    for (int i = 0; i < wtk_yolo::kSideStreams; ++i) {
+        if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
+        if (h->side_stream[i]) (void)hipStreamDestroy(h->side_stream[i]);
+    }
+    for (int i = 0; i < 3; ++i)
+        if (h->d1_ev[i]) (void)hipEventDestroy(h->d1_ev[i]);
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     delete h;
@@ -785,6 +795,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     h->dims = dims;
     if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
     if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
+    if (const char *e = std::getenv("WTK_SIDE_STREAMS")) h->side_streams = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 3);
     if (const char *e = std::getenv("WTK_HALO_SLABS")) h->halo_slabs = e[0] == '2' ? 2 : 3;
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
@@ -940,8 +951,13 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             }
         }
         if (!P.failed && i < 2) { // P3 and P4 towers only need t15 / t18: independent of the rest of the PAN path
-            for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = 1;
+            for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = (i == 1 && h->side_streams >= 2) ? 2 : 1; // P4 tower: its own side stream
             h->ops[first_op].wait_feat = i;
+        }
+        if (!P.failed && h->side_streams >= 3) { // class tower (ops +2, +4) on its own stream behind the shared first conv (op +0)
+            h->ops[first_op].signal_d1 = i;
+            h->ops[first_op + 2].side = h->ops[first_op + 4].side = 3 + i;
+            h->ops[first_op + 2].wait_d1 = i;
         }
     }
     // A strided 3x3 conv (128 couts, implicit GEMM, fp16) whose ONLY reader is the 1x1 conv 128 -> 128 right behind it (model.3 ->
@@ -1019,10 +1035,14 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         return fail("wtk_yolo_create: stream creation failed");
     }
     if (h->use_side) {
-        if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->feat_ev[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->feat_ev[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming) != hipSuccess) {
+        bool ok = hipEventCreateWithFlags(&h->feat_ev[0], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->feat_ev[1], hipEventDisableTiming) == hipSuccess;
+        const int n_side = h->side_streams >= 3 ? wtk_yolo::kSideStreams - 1 : h->side_streams; // only the streams the plan uses (a stream takes a hardware queue slot)
+        for (int i = 1; i <= n_side && ok; ++i)
+            ok = hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreateWithFlags(&h->d1_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             wtk_yolo_destroy(h);
             return fail("wtk_yolo_create: side stream / event creation failed");
         }
@@ -1189,8 +1209,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
     // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
     // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
-    const bool two_lanes = h->use_side && h->side_stream && !h->profiling;
-    bool side_used = false;
+    const bool two_lanes = h->use_side && h->side_stream[1] && !h->profiling;
+    unsigned side_used = 0; // bit i: side_stream[i] carries work of this pass
     hipStream_t main_st = st;
     size_t first_op = 0;
     if (h->use_front && reinterpret_cast<uintptr_t>(net_in) % 4 == 0) {
@@ -1235,9 +1255,10 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         }
         st = main_st;
         if (two_lanes && op.side) {
-            st = h->side_stream;
+            st = h->side_stream[op.side];
             if (op.wait_feat >= 0) HIP_TRY(hipStreamWaitEvent(st, h->feat_ev[op.wait_feat], 0));
-            side_used = true;
+            if (op.wait_d1 >= 0) HIP_TRY(hipStreamWaitEvent(st, h->d1_ev[op.wait_d1], 0));
+            side_used |= 1u << op.side;
         }
         if (op.kind == OP_STEM) {
             if (mark(0)) return 1;
@@ -1440,13 +1461,15 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             ++launches[kid];
             flops[kid] += op_flops(op) + (op.tail_op >= 0 ? op_flops(h->ops[op.tail_op]) : 0.0);
             if (two_lanes && op.signal_feat >= 0) HIP_TRY(hipEventRecord(h->feat_ev[op.signal_feat], main_st));
+            if (two_lanes && op.signal_d1 >= 0) HIP_TRY(hipEventRecord(h->d1_ev[op.signal_d1], st));
         }
     }
     st = main_st;
-    if (side_used) {
-        HIP_TRY(hipEventRecord(h->side_done, h->side_stream));
-        HIP_TRY(hipStreamWaitEvent(main_st, h->side_done, 0));
-    }
+    for (int i = 1; i < wtk_yolo::kSideStreams; ++i)
+        if (side_used & (1u << i)) {
+            HIP_TRY(hipEventRecord(h->side_done[i], h->side_stream[i]));
+            HIP_TRY(hipStreamWaitEvent(main_st, h->side_done[i], 0));
+        }
     if (mark(3)) return 1;
     if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st, nms)) return 1;
     ++launches[3];
