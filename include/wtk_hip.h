@@ -261,6 +261,10 @@ int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_
 int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev,
                        int32_t *n_weak_dev, void *stream);
 int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev);
+/* Concurrency inside one forward pass: n = 2 (default) runs the P3 and the P4 Detect tower on a side stream each next to the PAN path,
+ * 1 puts both on one side stream, 0 keeps every launch on the caller's stream.  A process that keeps several handles busy at once
+ * (two lanes, a second-look handle) can have too many streams in flight: the hybrid's full-precision handle runs with 0. */
+int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n);
 int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin,
                       const float *src_xywh, const float *src_conf, const int32_t *src_anchor, float *dst_xywh,
                       float *dst_conf, int32_t *dst_anchor, int32_t *n_replaced_dev, void *stream);

@@ -951,7 +951,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             }
         }
         if (!P.failed && i < 2) { // P3 and P4 towers only need t15 / t18: independent of the rest of the PAN path
-            for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = (i == 1 && h->side_streams >= 2) ? 2 : 1; // P4 tower: its own side stream
+            for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = i == 1 ? 2 : 1; // P4 tower: side stream 2 (folded onto stream 1 at launch time when the handle runs with one side stream)
             h->ops[first_op].wait_feat = i;
         }
         if (!P.failed && h->side_streams >= 3) { // class tower (ops +2, +4) on its own stream behind the shared first conv (op +0)
@@ -1209,7 +1209,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
     // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
     // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
-    const bool two_lanes = h->use_side && h->side_stream[1] && !h->profiling;
+    const bool two_lanes = h->use_side && h->side_streams > 0 && h->side_stream[1] && !h->profiling;
     unsigned side_used = 0; // bit i: side_stream[i] carries work of this pass
     hipStream_t main_st = st;
     size_t first_op = 0;
@@ -1255,10 +1255,11 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         }
         st = main_st;
         if (two_lanes && op.side) {
-            st = h->side_stream[op.side];
+            const int sidx = op.side <= 2 ? std::min(op.side, h->side_streams) : op.side; // wtk_yolo_set_side_streams(1): both towers on side stream 1
+            st = h->side_stream[sidx];
             if (op.wait_feat >= 0) HIP_TRY(hipStreamWaitEvent(st, h->feat_ev[op.wait_feat], 0));
             if (op.wait_d1 >= 0) HIP_TRY(hipStreamWaitEvent(st, h->d1_ev[op.wait_d1], 0));
-            side_used |= 1u << op.side;
+            side_used |= 1u << sidx;
         }
         if (op.kind == OP_STEM) {
             if (mark(0)) return 1;
@@ -1607,6 +1608,24 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
     if (out_conf) HIP_TRY(hipMemcpyAsync(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost, st));
     if (out_anchor) HIP_TRY(hipMemcpyAsync(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
+    if (!h || n < 0 || n > 2) return fail("wtk_yolo_set_side_streams: n must be 0, 1 or 2");
+    if (h->side_streams >= 3) return fail("wtk_yolo_set_side_streams: the handle was planned with WTK_SIDE_STREAMS=3");
+    DEVICE_GUARD(h);
+    for (int i = 1; i <= n; ++i) { // streams the handle was created without (WTK_NO_SIDE_STREAM / WTK_SIDE_STREAMS=1)
+        if (!h->side_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
+        if (!h->side_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; ++i)
+        if (n > 0 && !h->feat_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->feat_ev[i], hipEventDisableTiming));
+    if (!h->graphs.empty() && h->host_stream) HIP_TRY(hipStreamSynchronize(h->host_stream)); // captured launches carry the old stream layout
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    h->side_streams = n;
+    h->use_side = n > 0;
     return 0;
 }
 

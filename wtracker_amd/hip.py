@@ -57,7 +57,7 @@ SYMBOLS = [
     "wtk_yolo_predict_nms", "wtk_yolo_decode_nms_host",
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
-    "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch",
+    "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch", "wtk_yolo_set_side_streams",
 ]
 
 
@@ -137,6 +137,7 @@ def load() -> C.CDLL:
     lib.wtk_yolo_last_margins_host.argtypes = [vp, i32, vp]
     lib.wtk_recheck_select.argtypes = [vp, i32, i32, f32, vp, vp, vp]
     lib.wtk_yolo_set_dynamic_batch.argtypes = [vp, vp]
+    lib.wtk_yolo_set_side_streams.argtypes = [vp, i32]
     lib.wtk_recheck_merge.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.wtk_comm_unique_id.argtypes = [vp, C.c_size_t]
     lib.wtk_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
@@ -408,6 +409,10 @@ class HipYolo:
     def set_dynamic_batch(self, n_dev):
         """`n_dev`: device int32 scalar (tensor / pointer) holding the number of batch rows that matter in the following calls, or None."""
         _check(load().wtk_yolo_set_dynamic_batch(self._h, _ptr(n_dev)), "wtk_yolo_set_dynamic_batch")
+
+    def set_side_streams(self, n: int):
+        """Streams the forward pass spreads over besides the caller's: 2 (default: P3 / P4 Detect towers on a side stream each), 1 or 0."""
+        _check(load().wtk_yolo_set_side_streams(self._h, n), "wtk_yolo_set_side_streams")
 
     def last_margins(self, B: int) -> np.ndarray:
         """Decision margins (class-logit units) of the B frames of the last max_det = 1 call: min(best - second-best anchor logit,
