@@ -93,7 +93,7 @@ def cpu_baseline(weights, dims, size: int, folded_path: str, frames64: np.ndarra
 class Workload:
     """One precision mode of the benched workload on this rank: `lanes` detector handles, the ResMLP, the pipeline."""
 
-    def __init__(self, args, dtype, lanes, weights, dims3, folded, local_rank, rank, world, group, dev, n_steps):
+    def __init__(self, args, dtype, lanes, weights, dims3, folded, local_rank, rank, world, group, dev, n_steps, streams=None):
         from wtracker_amd import hip
         from wtracker_amd.pipeline import TrackPipeline
 
@@ -112,7 +112,7 @@ class Workload:
         self.mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
         # 60 fps, 100/40/50 ms timing (BASELINE config 3): imaging 6, pred 3, moving 3 frames
         self.pipe = TrackPipeline(self.dets, self.mlp, folded, args.batch, n_steps * args.batch * world, imaging_frame_num=6,
-                                  pred_frame_num=3, cycle_frame_num=9, conf=args.conf, rank=rank, world=world, group=group, device=dev)
+                                  pred_frame_num=3, cycle_frame_num=9, conf=args.conf, rank=rank, world=world, group=group, device=dev, streams=streams)
         self.dtype, self.lanes = dtype, lanes
 
     def close(self):
@@ -187,6 +187,8 @@ def main():
     frames = torch.from_numpy(frames_np).to(dev)
     n_pool_batches = pool // args.batch
 
+    lane_streams: dict = {}  # the same lane streams for every mode measured in this process
+
     def fence(pipe):
         pipe.synchronize()
         torch.cuda.synchronize(dev)
@@ -198,7 +200,8 @@ def main():
         """Warm-up, `repeats` timed windows of args.steps steps, then (optionally) the per-kernel profile pass."""
         prof_steps = max(min(args.steps, 10), 1) if profile else 0
         n_steps = args.warmup + repeats * args.steps + 2 * prof_steps + lanes
-        wl = Workload(args, dtype, lanes, weights, (width, depth, maxch), folded, local_rank, rank, world, None, dev, n_steps)
+        wl = Workload(args, dtype, lanes, weights, (width, depth, maxch), folded, local_rank, rank, world, None, dev, n_steps,
+                      streams=lane_streams.setdefault(lanes, [torch.cuda.Stream(device=dev) for _ in range(lanes)]) if lanes > 1 else None)
         pipe = wl.pipe
 
         def run(s: int):

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace wtk;
@@ -473,7 +475,7 @@ struct wtk_yolo {
     ModelDims dims;
     std::vector<Buf> bufs;
     std::vector<Op> ops;
-    std::vector<void *> dev_allocs;
+    std::vector<std::pair<void *, size_t>> dev_allocs; // (pointer, bytes) of every dev_alloc: returned to the block cache on destroy
     int box_buf[3] = {-1, -1, -1}, cls_buf[3] = {-1, -1, -1};
     int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
     int cls_ld = 32;
@@ -516,6 +518,7 @@ struct wtk_yolo {
     hipStream_t side_stream[kSideStreams] = {};
     hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done[kSideStreams] = {}, d1_ev[3] = {};
     int use_side = 1;
+    int side_shared = 0;
     int side_streams = 2; // WTK_SIDE_STREAMS (A/B switch): 1: P3 and P4 towers share one side stream; 2 (default): one each (+0.5..1.6 %); 3: + class towers on their own streams (-11 %: more streams than hardware queues)
     // launch-bound regime (small batches): the whole forward is captured once per argument set and replayed
     struct GraphEntry {
@@ -556,9 +559,87 @@ extern "C" int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t ma
     return 0;
 }
 
+// Block cache of the detector handles' device memory.  A process that creates and destroys handles (bench.py measures four precision
+// modes one after the other; a controller re-creates its detector when the frame shape changes) used to hipFree ~10 GB and hipMalloc
+// again: memory handed back to the driver and re-allocated comes back measurably worse placed — the same hybrid workload ran at 14.8 k
+// frames/s after three other modes had been created and destroyed and at 17.7 k in a fresh process (tools/gpu_sessions/order_probe.py).
+// Freed blocks are kept per (device, size) and handed to the next handle that asks for exactly that size; what is never returned
+// never fragments.  wtk_release_cached_memory() gives everything back; WTK_NO_ALLOC_CACHE=1 disables the cache (A/B switch).
+namespace {
+struct CachedBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_block_mu;
+std::vector<CachedBlock> g_blocks;
+bool block_cache_on() {
+    static const bool on = !(std::getenv("WTK_NO_ALLOC_CACHE") && std::getenv("WTK_NO_ALLOC_CACHE")[0] == '1');
+    return on;
+}
+} // namespace
+
+// Side streams come from a per-process pool and go back to it (never destroyed): the HIP runtime binds a stream to one of its few hardware
+// queues when the stream is created, and after handles have come and gone the streams of a NEW handle can land on the queue of the
+// caller's stream — the towers then run behind the PAN path instead of next to it (the whole benefit of the side streams, 14 %, was
+// lost for the fourth workload of bench.py).  Reused streams keep the queues they got when the process was young.
+namespace {
+std::mutex g_stream_mu;
+std::vector<std::pair<int, hipStream_t>> g_free_streams; // (device, stream)
+hipError_t pooled_stream(int device, hipStream_t *s) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = 0; i < g_free_streams.size(); ++i)
+            if (g_free_streams[i].first == device) {
+                *s = g_free_streams[i].second;
+                g_free_streams.erase(g_free_streams.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void unpool_stream(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_free_streams.insert(g_free_streams.begin(), {device, s}); // LIFO: the next handle gets the streams of the last one destroyed
+}
+} // namespace
+
 static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
-    HIP_TRY(hipMalloc(p, bytes));
-    h->dev_allocs.push_back(*p);
+    *p = nullptr;
+    if (block_cache_on()) {
+        std::lock_guard<std::mutex> lk(g_block_mu);
+        for (size_t i = 0; i < g_blocks.size(); ++i)
+            if (g_blocks[i].device == h->device && g_blocks[i].bytes == bytes) {
+                *p = g_blocks[i].p;
+                g_blocks.erase(g_blocks.begin() + (long)i);
+                break;
+            }
+    }
+    if (!*p) HIP_TRY(hipMalloc(p, bytes));
+    h->dev_allocs.emplace_back(*p, bytes);
+    return 0;
+}
+
+static void dev_release(wtk_yolo *h) {
+    if (block_cache_on()) {
+        std::lock_guard<std::mutex> lk(g_block_mu);
+        for (auto &a : h->dev_allocs) g_blocks.push_back({a.first, a.second, h->device});
+    } else {
+        for (auto &a : h->dev_allocs) (void)hipFree(a.first);
+    }
+    h->dev_allocs.clear();
+}
+
+extern "C" int wtk_release_cached_memory(void) {
+    std::lock_guard<std::mutex> lk(g_block_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &b : g_blocks) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    g_blocks.clear();
+    (void)hipSetDevice(cur);
     return 0;
 }
 
@@ -737,7 +818,8 @@ struct Planner {
 
 extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     if (!h) return;
-    for (void *p : h->dev_allocs) (void)hipFree(p);
+    (void)hipDeviceSynchronize(); // as the hipFree calls did implicitly: nothing of this handle may still be running when its blocks go back to the cache
+    dev_release(h);
     (void)hipFree(h->frames_dev);
     (void)hipFree(h->lb_dev);
     (void)hipFree(h->nms_score);
@@ -748,12 +830,12 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
     for (int i = 0; i < wtk_yolo::kSideStreams; ++i) {
         if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
-        if (h->side_stream[i]) (void)hipStreamDestroy(h->side_stream[i]);
+        if (h->side_stream[i] && !(h->side_shared && i <= 2)) unpool_stream(h->device, h->side_stream[i]);
     }
     for (int i = 0; i < 3; ++i)
         if (h->d1_ev[i]) (void)hipEventDestroy(h->d1_ev[i]);
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+    if (h->host_stream) unpool_stream(h->device, h->host_stream);
     delete h;
 }
 
@@ -1030,23 +1112,8 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         wtk_yolo_destroy(h);
         return fail("wtk_yolo_create: hipMemset failed");
     }
-    if (hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking) != hipSuccess) {
-        wtk_yolo_destroy(h);
-        return fail("wtk_yolo_create: stream creation failed");
-    }
-    if (h->use_side) {
-        bool ok = hipEventCreateWithFlags(&h->feat_ev[0], hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&h->feat_ev[1], hipEventDisableTiming) == hipSuccess;
-        const int n_side = h->side_streams >= 3 ? wtk_yolo::kSideStreams - 1 : h->side_streams; // only the streams the plan uses (a stream takes a hardware queue slot)
-        for (int i = 1; i <= n_side && ok; ++i)
-            ok = hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreateWithFlags(&h->d1_ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            wtk_yolo_destroy(h);
-            return fail("wtk_yolo_create: side stream / event creation failed");
-        }
-    }
+    // streams (side streams, the host entry points' stream) are taken from the process pool at first use: a handle that never runs
+    // with side streams (the hybrid's second look) or never sees a host call does not occupy a hardware queue slot
     *out = h;
     return 0;
 }
@@ -1158,6 +1225,39 @@ static int ensure_nms_scratch(wtk_yolo *h, hipStream_t st) {
 
 // Enqueue one forward pass (letterbox, stem, convs, pool, head) on `st`.  No allocation, no synchronisation
 // (profiling mode excepted): safe inside stream capture.
+// side streams and their events, taken at the first forward pass that uses them
+static int ensure_side_streams(wtk_yolo *h) {
+    const int n_side = h->side_streams >= 3 ? wtk_yolo::kSideStreams - 1 : h->side_streams;
+    // ONE pair of side streams per process and device, shared by every handle (WTK_SHARED_SIDE=0: a pair per handle from the pool).  The HIP
+    // runtime multiplexes streams onto four hardware queues; with two lanes (two caller streams) a pair per handle made six streams, and which
+    // of them shared a queue depended on the order in which streams had been created in the process: the same workload ran at 24.5 .. 27 k
+    // frames/s (fp16) or 14.8 .. 17.7 k (hybrid) depending on what had run before it (tools/gpu_sessions/order_probe.py).  Two callers + one
+    // shared pair = four streams: every stream has a queue of its own, and the rate no longer depends on the history of the process.
+    // The towers of different handles then run one after the other on a side stream; lanes are out of phase, nothing is lost (26.8 k / 17.6 k).
+    static const bool shared = !(std::getenv("WTK_SHARED_SIDE") && std::getenv("WTK_SHARED_SIDE")[0] == '0');
+    for (int i = 1; i <= n_side; ++i) {
+        if (!h->side_stream[i] && shared && i <= 2) {
+            static std::mutex mu;
+            static std::vector<std::pair<int, hipStream_t>> g_shared[2]; // per slot: (device, stream)
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &e : g_shared[i - 1])
+                if (e.first == h->device) h->side_stream[i] = e.second;
+            if (!h->side_stream[i]) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
+                g_shared[i - 1].emplace_back(h->device, h->side_stream[i]);
+            }
+            h->side_shared = 1;
+        }
+        if (!h->side_stream[i]) HIP_TRY(pooled_stream(h->device, &h->side_stream[i]));
+        if (!h->side_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!h->feat_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->feat_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i)
+        if (h->side_streams >= 3 && !h->d1_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->d1_ev[i], hipEventDisableTiming));
+    return 0;
+}
+
 // `vs` != nullptr: the batch rows are camera views of full frames (wtk_yolo_predict_views) — crop + letterbox in one kernel.
 struct ViewSrc {
     const int32_t *pos_xy, *frame_index;
@@ -1209,6 +1309,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
     // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
     // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
+    if (h->use_side && h->side_streams > 0 && !h->profiling && ensure_side_streams(h)) return 1;
     const bool two_lanes = h->use_side && h->side_streams > 0 && h->side_stream[1] && !h->profiling;
     unsigned side_used = 0; // bit i: side_stream[i] carries work of this pass
     hipStream_t main_st = st;
@@ -1520,6 +1621,7 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
             return 0;
         }
     hipGraph_t graph = nullptr;
+    if (h->use_side && h->side_streams > 0 && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
     HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
     const hipError_t ec = hipStreamEndCapture(st, &graph);
@@ -1601,6 +1703,7 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
         HIP_TRY(hipMalloc(&h->frames_dev, cap));
         h->frames_cap = cap;
     }
+    if (!h->host_stream) HIP_TRY(pooled_stream(h->device, &h->host_stream));
     hipStream_t st = h->host_stream;
     HIP_TRY(hipMemcpyAsync(h->frames_dev, frames_host, need, hipMemcpyHostToDevice, st));
     if (wtk_yolo_predict(h, h->frames_dev, B, H, W, C, conf, iou, max_det, h->o_xywh, h->o_conf, h->o_anchor, st)) return 1;
@@ -1615,12 +1718,6 @@ extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
     if (!h || n < 0 || n > 2) return fail("wtk_yolo_set_side_streams: n must be 0, 1 or 2");
     if (h->side_streams >= 3) return fail("wtk_yolo_set_side_streams: the handle was planned with WTK_SIDE_STREAMS=3");
     DEVICE_GUARD(h);
-    for (int i = 1; i <= n; ++i) { // streams the handle was created without (WTK_NO_SIDE_STREAM / WTK_SIDE_STREAMS=1)
-        if (!h->side_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
-        if (!h->side_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming));
-    }
-    for (int i = 0; i < 2; ++i)
-        if (n > 0 && !h->feat_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->feat_ev[i], hipEventDisableTiming));
     if (!h->graphs.empty() && h->host_stream) HIP_TRY(hipStreamSynchronize(h->host_stream)); // captured launches carry the old stream layout
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();

@@ -58,6 +58,7 @@ SYMBOLS = [
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
     "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch", "wtk_yolo_set_side_streams",
+    "wtk_release_cached_memory",
 ]
 
 
@@ -180,6 +181,11 @@ def crop_views(frames_dev, N: int, H: int, W: int, Cc: int, pos_xy_dev, view_w: 
     with replicate borders.  All arguments are device tensors / pointers."""
     _check(load().wtk_crop_views(_ptr(frames_dev), N, H, W, Cc, _ptr(pos_xy_dev), view_w, view_h, _ptr(views_dev),
                                  C.c_void_p(stream)), "wtk_crop_views")
+
+
+def release_cached_memory():
+    """Give the device memory of destroyed detector handles (kept for reuse) back to the driver."""
+    _check(load().wtk_release_cached_memory(), "wtk_release_cached_memory")
 
 
 def recheck_select(margins_dev, B: int, K: int, margin: float, slots_dev, n_weak_dev=None, stream: int = 0):

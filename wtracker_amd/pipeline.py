@@ -77,7 +77,7 @@ class TrackPipeline:
 
     def __init__(self, dets, mlp: hip.HipMLP, folded: FoldedResMLP, batch: int, total_frames: int,
                  imaging_frame_num: int, pred_frame_num: int, cycle_frame_num: int, conf: float = 0.1,
-                 rank: int = 0, world: int = 1, group=None, device: Optional[torch.device] = None, comm=None):
+                 rank: int = 0, world: int = 1, group=None, device: Optional[torch.device] = None, comm=None, streams=None):
         self.dets = list(dets) if isinstance(dets, (list, tuple)) else [dets]
         self.mlp, self.folded = mlp, folded
         self.rank, self.world, self.group, self.comm = rank, world, group, comm
@@ -88,7 +88,11 @@ class TrackPipeline:
         if len(self.dets) > 1 and self.plan.super_batch < lookback:
             raise ValueError("two lanes need super-batches of at least the predictor's look-back")
         n_lanes = len(self.dets)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 else [None]
+        # `streams`: one torch stream per lane from the caller (a process that builds several pipelines keeps the same lane streams: torch hands
+        # out pooled streams round-robin, and which hardware queue a stream sits on changes what runs concurrently with what)
+        if streams is not None and len(streams) != n_lanes:
+            raise ValueError("one stream per lane")
+        self.streams = list(streams) if streams is not None else ([torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 else [None])
         self.det_done = [torch.cuda.Event() for _ in range(n_lanes)]
         # device-resident track of the whole run: xywh per frame (NaN = no detection yet / none found)
         self.track = torch.full((total_frames, 4), float("nan"), dtype=torch.float32, device=self.device)
