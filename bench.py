@@ -38,6 +38,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# One hardware queue per stream: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues.  This process keeps five
+# streams busy (two lanes, the shared pair of side streams, torch's default stream); with four queues two of them share one and serialise:
+# 26.2 k frames/s against 27.1 k with 5, 6 or 8 queues (profiles/r02_notes.md §8).  Read by the runtime when it initialises: set before torch loads.
+# (Not for the one-GPU rehearsal of the multi-rank path, `--backend gloo`: there several processes share a device and their queues add up.)
+if not ("--backend" in sys.argv and sys.argv[sys.argv.index("--backend") + 1 : sys.argv.index("--backend") + 2] != ["nccl"]):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
