@@ -265,9 +265,8 @@ int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev);
  * 1 puts both on one side stream, 0 keeps every launch on the caller's stream.  A process that keeps several handles busy at once
  * (two lanes, a second-look handle) can have too many streams in flight: the hybrid's full-precision handle runs with 0. */
 int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n);
-/* Detector handles return their device memory to a per-process block cache (reused by the next handle that needs a block of
- * exactly that size) instead of the driver: memory that is freed and allocated again comes back worse placed (measured: up to
- * -17 % on a latency-bound workload).  This gives the cached blocks back to the driver. */
+/* With WTK_ALLOC_CACHE=1 destroyed detector handles keep their device memory in a per-process block cache (reused by the next
+ * handle that needs a block of exactly that size) instead of returning it to the driver.  This gives the cached blocks back. */
 int wtk_release_cached_memory(void);
 int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin,
                       const float *src_xywh, const float *src_conf, const int32_t *src_anchor, float *dst_xywh,

@@ -559,12 +559,11 @@ extern "C" int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t ma
     return 0;
 }
 
-// Block cache of the detector handles' device memory.  A process that creates and destroys handles (bench.py measures four precision
-// modes one after the other; a controller re-creates its detector when the frame shape changes) used to hipFree ~10 GB and hipMalloc
-// again: memory handed back to the driver and re-allocated comes back measurably worse placed — the same hybrid workload ran at 14.8 k
-// frames/s after three other modes had been created and destroyed and at 17.7 k in a fresh process (tools/gpu_sessions/order_probe.py).
-// Freed blocks are kept per (device, size) and handed to the next handle that asks for exactly that size; what is never returned
-// never fragments.  wtk_release_cached_memory() gives everything back; WTK_NO_ALLOC_CACHE=1 disables the cache (A/B switch).
+// Optional block cache of the detector handles' device memory (WTK_ALLOC_CACHE=1; off by default).  Built while looking for the reason
+// why a workload's rate depended on what the process had run before (the reason was the stream layout, see ensure_side_streams; the
+// cache changed nothing measurable).  With it, destroyed handles keep their blocks per (device, size) for the next handle that asks
+// for exactly that size instead of paying hipFree + hipMalloc; a failed hipMalloc releases the cache and tries again;
+// wtk_release_cached_memory() gives everything back.
 namespace {
 struct CachedBlock {
     void *p;
@@ -574,7 +573,7 @@ struct CachedBlock {
 std::mutex g_block_mu;
 std::vector<CachedBlock> g_blocks;
 bool block_cache_on() {
-    static const bool on = !(std::getenv("WTK_NO_ALLOC_CACHE") && std::getenv("WTK_NO_ALLOC_CACHE")[0] == '1');
+    static const bool on = std::getenv("WTK_ALLOC_CACHE") && std::getenv("WTK_ALLOC_CACHE")[0] == '1';
     return on;
 }
 } // namespace
@@ -604,6 +603,7 @@ void unpool_stream(int device, hipStream_t s) {
 }
 } // namespace
 
+extern "C" int wtk_release_cached_memory(void);
 static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
     *p = nullptr;
     if (block_cache_on()) {
@@ -615,7 +615,11 @@ static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
                 break;
             }
     }
-    if (!*p) HIP_TRY(hipMalloc(p, bytes));
+    if (!*p && hipMalloc(p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)wtk_release_cached_memory(); // cached blocks of other sizes may be what is in the way
+        HIP_TRY(hipMalloc(p, bytes));
+    }
     h->dev_allocs.emplace_back(*p, bytes);
     return 0;
 }
