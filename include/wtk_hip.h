@@ -263,7 +263,8 @@ int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float mar
 int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev);
 /* Concurrency inside one forward pass: n = 2 (default) runs the P3 and the P4 Detect tower on a side stream each next to the PAN path,
  * 1 puts both on one side stream, 0 keeps every launch on the caller's stream.  A process that keeps several handles busy at once
- * (two lanes, a second-look handle) can have too many streams in flight: the hybrid's full-precision handle runs with 0. */
+ * (two lanes, a second-look handle) can have too many streams in flight; the side streams themselves are ONE pair per process and
+ * device, shared by all handles. */
 int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n);
 /* With WTK_ALLOC_CACHE=1 destroyed detector handles keep their device memory in a per-process block cache (reused by the next
  * handle that needs a block of exactly that size) instead of returning it to the driver.  This gives the cached blocks back. */

@@ -41,9 +41,8 @@ class HybridDetector:
         self.replaced = torch.zeros((1,), dtype=torch.int32, device=dev)  # rows replaced so far (device counter)
         self._n_weak = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows of the current batch: the second look's dynamic batch size
         exact.set_dynamic_batch(self._n_weak)
-        # the second look runs next to other forward passes (the other lane, the next fp16 batch): with side streams of its own the process
-        # has more streams in flight than the hardware queues take well (measured: 14.8 k -> 17.9 k frames/s without them)
-        exact.set_side_streams(0)
+        # (the second look keeps the default concurrency: with ONE pair of side streams per process, shared by every handle, its towers cost no
+        # extra streams — 17.7 k frames/s against 17.1 k with wtk_yolo_set_side_streams(0); with a pair per handle it was the other way round)
 
     # -- the detector interface -------------------------------------------------------------------------------------------
     def predict(self, frames_dev, B: int, H: int, W: int, Cc: int, out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1,
