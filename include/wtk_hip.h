@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WTK_ABI_VERSION 3 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_* (additive: every earlier entry point is unchanged) */
+#define WTK_ABI_VERSION 4 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted (additive: every earlier entry point is unchanged) */
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
@@ -252,6 +252,10 @@ int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_
  * frame_index = slots) and replace the fast rows where margin < `margin`.  No host synchronisation: K is fixed.
  *   wtk_recheck_select  slots[k] = batch row of the k-th smallest margin (ties: lower row first; NaN = +inf), k < K;
  *                       *n_weak (nullable) = min(K, rows with margin < `margin`): the leading slots that will be merged
+ *   wtk_recheck_select_counted  the same, and *n_overflow (nullable) += max(rows with margin < `margin` - K, 0): the weak rows
+ *                       the ceiling K cut off.  They keep their fast-pass result WITHOUT a second look, so a caller that
+ *                       promises full-precision decisions must either use K = B (no row can be cut off; with the dynamic
+ *                       batch below the cost still follows the number of weak rows) or check this counter.
  *   wtk_yolo_set_dynamic_batch  the handle reads the number of batch rows that matter from DEVICE memory at run time
  *                       (nullptr: off): kernels skip the tiles of images beyond it, rows beyond it hold scratch.  With
  *                       n_dev = n_weak the second look costs what the weak frames cost, with no host round trip.
@@ -260,6 +264,8 @@ int wtk_track_training_pairs(const void *track_dev, int32_t track_is_f64, int32_
  * ------------------------------------------------------------------------------------------ */
 int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev,
                        int32_t *n_weak_dev, void *stream);
+int wtk_recheck_select_counted(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev,
+                               int32_t *n_weak_dev, int32_t *n_overflow_dev, void *stream);
 int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev);
 /* Concurrency inside one forward pass: n = 2 (default) runs the P3 and the P4 Detect tower on a side stream each next to the PAN path,
  * 1 puts both on one side stream, 0 keeps every launch on the caller's stream.  A process that keeps several handles busy at once

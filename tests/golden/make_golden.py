@@ -26,6 +26,16 @@ Round 2 (`--r2`: writes ONLY these, the fixtures above stay byte-identical):
   polyfit_cases.json                    per-cycle (dx, dy) of the reference PolyfitController for several PolyfitConfigs,
                                         among them UNSORTED sample_times with non-uniform weights (polyfit_controller.py:28
                                         sorts the times, not the weights), and the weights / sample_times the config ends up with
+Round 3 (`--r3`: writes ONLY these):
+  dropin_reference_driver.json          the PRODUCT's host controllers (wtracker_amd.controllers.CsvController / OptimalController /
+                                        PolyfitController, and HipMLPController's CPU twin is not needed: the MLP log is pinned
+                                        above) driven by the REAL reference's Simulator + LoggingController
+                                        (simulator.py:140-194, logging_controller.py:64-224): for every controller the sha256 and
+                                        row count of the bboxes.csv the reference's LoggingController wrote with the reference's
+                                        own controller inside and with the product's controller inside, and whether the two files
+                                        are byte-equal — the "simulate.ipynb is a drop-in" claim checked where it can be checked
+  polyfit_highdeg.json                  numpy-identical fits at the highest degree the device solver admits (7, 16 sample times on
+                                        both sides of zero): the reference PolyfitController's per-cycle integer moves
 """
 import hashlib
 import json
@@ -311,8 +321,112 @@ def main_r2():
     json.dump(out, open(os.path.join(HERE, "polyfit_cases.json"), "w"))
 
 
+def dropin_check(verbose: bool = True) -> dict:
+    """Run the reference's own driver objects (Simulator.run + LoggingController) twice per controller kind — once around the
+    reference's controller, once around the product's — on the seeded track, and compare the bboxes.csv files byte for byte.
+    Importable: tests/test_dropin_reference.py calls it when /root/reference is present."""
+    _register_placeholders()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    repo = os.path.dirname(os.path.dirname(HERE))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from wtracker.sim.config import ExperimentConfig, TimingConfig
+    from wtracker.sim.sim_controllers.csv_controller import CsvController as RefCsv
+    from wtracker.sim.sim_controllers.logging_controller import LogConfig, LoggingController
+    from wtracker.sim.sim_controllers.optimal_controller import OptimalController as RefOptimal
+    from wtracker.sim.sim_controllers.polyfit_controller import PolyfitConfig as RefPolyfitConfig
+    from wtracker.sim.sim_controllers.polyfit_controller import PolyfitController as RefPolyfit
+    from wtracker.sim.simulator import Simulator
+
+    from wtracker_amd import controllers as ours
+
+    exp_cfg_json = json.load(open(os.path.join(REF, "experiments/exp0/exp_config.json")))
+    init_csv = os.path.join(HERE, "sim_init_bboxes.csv")
+    pf = dict(degree=2, sample_times=[2, -9, 0, -3, 4, -6], weights=[1, 1, 2, 3, 4, 5])
+    kinds = {
+        "csv": (lambda tc: RefCsv(tc, init_csv), lambda tc: ours.CsvController(tc, init_csv)),
+        "optimal": (lambda tc: RefOptimal(tc, init_csv), lambda tc: ours.OptimalController(tc, init_csv)),
+        "polyfit": (lambda tc: RefPolyfit(tc, RefPolyfitConfig(**pf), init_csv), lambda tc: ours.PolyfitController(tc, ours.PolyfitConfig(**pf), init_csv)),
+    }
+    out = {"driver": "wtracker.sim.simulator.Simulator.run + wtracker.sim.sim_controllers.logging_controller.LoggingController (the real reference)",
+           "track": "tests/golden/sim_init_bboxes.csv", "timings_ms": [[100, 40, 50], [200, 40, 50]], "controllers": {}}
+    for name, (make_ref, make_ours) in kinds.items():
+        for timing in ((100, 40, 50), (200, 40, 50)):
+            logs = []
+            for make in (make_ref, make_ours):
+                ec = ExperimentConfig(name="exp0", num_frames=200, frames_per_sec=exp_cfg_json["frames_per_sec"],
+                                      orig_resolution=tuple(exp_cfg_json["orig_resolution"]), px_per_mm=exp_cfg_json["px_per_mm"],
+                                      init_position=tuple(exp_cfg_json["init_position"]))
+                tc = TimingConfig(ec, *timing, (4, 4), (0.32, 0.32))
+                tmp = tempfile.mkdtemp(prefix="wtk_dropin_")
+                try:
+                    lc = LogConfig(root_folder=tmp, save_mic_view=False, save_cam_view=False, save_err_view=False, save_wrm_view=False)
+                    Simulator(tc, ec, LoggingController(make(tc), lc)).run()
+                    logs.append(open(lc.bbox_file_path, "rb").read())
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
+            key = f"{name}_{timing[0]}ms"
+            out["controllers"][key] = {"reference_sha256": hashlib.sha256(logs[0]).hexdigest(), "product_sha256": hashlib.sha256(logs[1]).hexdigest(),
+                                       "rows": logs[0].count(b"\n") - 1, "bytes": len(logs[0]), "byte_equal": logs[0] == logs[1]}
+            if verbose:
+                print("dropin", key, out["controllers"][key])
+    return out
+
+
+def main_r3():
+    """Round-3 fixtures (see the module docstring)."""
+    out = dropin_check()
+    assert all(c["byte_equal"] for c in out["controllers"].values()), "a product controller's log differs from the reference controller's"
+    json.dump(out, open(os.path.join(HERE, "dropin_reference_driver.json"), "w"), indent=1)
+
+    from wtracker.sim.config import ExperimentConfig, TimingConfig
+    from wtracker.sim.sim_controllers.logging_controller import LogConfig, LoggingController
+    from wtracker.sim.sim_controllers.polyfit_controller import PolyfitConfig, PolyfitController
+    from wtracker.sim.simulator import Simulator
+
+    exp_cfg_json = json.load(open(os.path.join(REF, "experiments/exp0/exp_config.json")))
+    init_csv = os.path.join(HERE, "sim_init_bboxes.csv")
+    cases = {
+        # the widest problem the device solver admits: degree 7, 16 sample times on both sides of zero (scaled Vandermonde condition ~1e9)
+        "deg7_16_times": dict(degree=7, sample_times=[-45, -40, -36, -31, -27, -22, -18, -15, -12, -9, -6, -3, 0, 2, 4, 5], weights=None),
+        "deg5_weighted": dict(degree=5, sample_times=[-27, -20, -18, -11, -9, -6, -3, 0, 2, 4], weights=[0.3, 0.5, 0.8, 1, 1, 2, 2, 3, 4, 6]),
+        # more coefficients than samples in the first cycles (history not there yet): minimum-norm solutions
+        "deg4_short_history": dict(degree=4, sample_times=[-30, -20, -10, 0, 3], weights=None),
+    }
+    res = {}
+    for name, kw in cases.items():
+        ec = ExperimentConfig(name="exp0", num_frames=200, frames_per_sec=exp_cfg_json["frames_per_sec"],
+                              orig_resolution=tuple(exp_cfg_json["orig_resolution"]), px_per_mm=exp_cfg_json["px_per_mm"],
+                              init_position=tuple(exp_cfg_json["init_position"]))
+        tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.32, 0.32))
+        cfg = PolyfitConfig(**kw)
+        ctrl = PolyfitController(tc, cfg, init_csv)
+        rec = []
+        orig = ctrl.provide_movement_vector
+
+        def wrapped(sim, orig=orig, rec=rec):
+            dx, dy = orig(sim)
+            rec.append([int(sim.frame_number), int(dx), int(dy)])
+            return dx, dy
+
+        ctrl.provide_movement_vector = wrapped
+        tmp = tempfile.mkdtemp(prefix="wtk_golden_")
+        try:
+            lc = LogConfig(root_folder=tmp, save_mic_view=False, save_cam_view=False, save_err_view=False, save_wrm_view=False)
+            Simulator(tc, ec, LoggingController(ctrl, lc)).run()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        res[name] = dict(config=dict(degree=kw["degree"], sample_times=kw["sample_times"], weights=kw["weights"]),
+                         sample_times_after=[int(t) for t in cfg.sample_times], weights_after=[float(w) for w in cfg.weights], moves=rec)
+        print(name, "cycles", len(rec), "last", rec[-1])
+    json.dump(res, open(os.path.join(HERE, "polyfit_highdeg.json"), "w"))
+
+
 if __name__ == "__main__":
-    if "--r2" in sys.argv:
+    if "--r3" in sys.argv:
+        main_r3()
+    elif "--r2" in sys.argv:
         main_r2()
     else:
         main()

@@ -159,3 +159,19 @@ def test_polyfit_unsorted_times_and_weights_match_reference(golden_dir):
         assert moves == c["moves"], name
     assert cases["unsorted_weighted"]["sample_times_after"] == [-9, -6, -3, 0, 2, 4]
     assert cases["unsorted_weighted"]["weights_after"] == [1, 1, 2, 3, 4, 5]
+
+
+def test_polyfit_at_the_highest_admitted_degree_matches_reference(golden_dir):
+    """Degree 7 over 16 sample times on both sides of zero, a weighted quintic, and a quartic whose first cycles have fewer
+    samples than coefficients (tests/golden/polyfit_highdeg.json, the real reference's PolyfitController): integer moves equal."""
+    import warnings
+
+    init = os.path.join(golden_dir, "sim_init_bboxes.csv")
+    cases = json.load(open(os.path.join(golden_dir, "polyfit_highdeg.json")))
+    assert set(cases) == {"deg7_16_times", "deg5_weighted", "deg4_short_history"}
+    for name, c in cases.items():
+        cfg = PolyfitConfig(**c["config"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # numpy's RankWarning on the under-determined first cycles (the reference gets it too)
+            _, moves = run(lambda tc: PolyfitController(tc, cfg, init))
+        assert moves == c["moves"], name

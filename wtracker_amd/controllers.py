@@ -32,49 +32,81 @@ def _read_track_csv(path: str) -> np.ndarray:
     return pd.read_csv(path, usecols=["wrm_x", "wrm_y", "wrm_w", "wrm_h"]).to_numpy(dtype=float)
 
 
+class _CameraRing:
+    """The camera boxes (x, y, w, h) of the most recent `capacity` camera frames, in one preallocated float64 array written
+    round-robin.  `oldest_first(i)` is the i-th oldest box still held — the element order of the bounded queue the reference
+    keeps (csv_controller.py:18,23) — and asking for a position that is not held yet is an IndexError, as it is there."""
+
+    def __init__(self, capacity: int):
+        self.capacity = int(capacity)
+        self.boxes = np.zeros((self.capacity, 4), dtype=np.float64)
+        self.pushed = 0  # boxes written since the last reset
+
+    def reset(self):
+        self.pushed = 0
+
+    def push(self, box):
+        self.boxes[self.pushed % self.capacity] = box
+        self.pushed += 1
+
+    def oldest_first(self, positions: np.ndarray) -> np.ndarray:
+        held = min(self.pushed, self.capacity)
+        if positions.size and (int(positions.max()) >= held or int(positions.min()) < 0):
+            raise IndexError(f"camera history holds {held} frames; position {int(positions.max())} requested")
+        return self.boxes[(self.pushed - held + positions) % self.capacity]
+
+
 class CsvController(SimController):
-    """Replays pre-detected boxes (the record/replay feeder under MLPController)."""
+    """Replays pre-detected head boxes from a bboxes.csv log: the record/replay feeder under the ResMLP, polynomial and look-ahead
+    controllers.  Same constructor, methods and results as csv_controller.py:11-73 (pinned by the real reference's logs,
+    tests/test_sim_golden.py), stated over two small structures of this module: the track as a table with one extra all-NaN row
+    that every out-of-range frame number is mapped to, and the camera history as a round-robin array (_CameraRing)."""
 
     def __init__(self, timing_config: TimingConfig, csv_path: str):
         super().__init__(timing_config)
         self.csv_path = csv_path
-        self._csv_data = _read_track_csv(csv_path)
-        self._camera_bboxes = deque(maxlen=timing_config.cycle_frame_num)
+        self.track = _read_track_csv(csv_path)                       # [N,4] float64 xywh, NaN row = missed detection
+        self._table = np.vstack([self.track, np.full((1, 4), np.nan)])  # row N: what a frame outside the log reads
+        self._cameras = _CameraRing(timing_config.cycle_frame_num)
+
+    @property
+    def n_frames(self) -> int:
+        return self.track.shape[0]
 
     def on_sim_start(self, sim):
-        self._camera_bboxes.clear()
+        self._cameras.reset()
 
     def on_camera_frame(self, sim):
-        self._camera_bboxes.append(sim.view.camera_position)
+        self._cameras.push(sim.view.camera_position)
 
     def predict(self, frame_nums: Collection[int], relative: bool = True) -> np.ndarray:
+        """Boxes of the given frames, [k,4] float64 (fresh array); frames outside the log are NaN rows.  relative=True: x, y are
+        measured from the corner of the camera view of that frame's slot in the current cycle (csv_controller.py:39-47: only
+        meaningful for frames of the cycle being replayed — the reference's own TODO)."""
         assert len(frame_nums) > 0
-        frame_nums = np.asanyarray(frame_nums, dtype=int)
-        valid = (frame_nums >= 0) & (frame_nums < self._csv_data.shape[0])
-        boxes = np.full((frame_nums.shape[0], 4), np.nan)
-        boxes[valid] = self._csv_data[frame_nums[valid], :]
-        if not relative:
-            return boxes
-        n = self.timing_config.cycle_frame_num
-        cams = np.asanyarray([self._camera_bboxes[f % n] for f in frame_nums], dtype=float)
-        boxes[:, 0] -= cams[:, 0]
-        boxes[:, 1] -= cams[:, 1]
-        return boxes
+        wanted = np.asanyarray(frame_nums, dtype=int)
+        inside = (wanted >= 0) & (wanted < self.n_frames)
+        rows = self._table[np.where(inside, wanted, self.n_frames)]
+        if relative:
+            rows[:, :2] -= self._cameras.oldest_first(wanted % self.timing_config.cycle_frame_num)[:, :2]
+        return rows
 
     def begin_movement_prediction(self, sim) -> None:
         pass
 
     def provide_movement_vector(self, sim) -> tuple:
-        box = self.predict([sim.frame_number - self.timing_config.pred_frame_num])[0, :]
-        if not np.isfinite(box).all():
+        """Centre the camera on the head as it was seen `pred_frame_num` frames ago (csv_controller.py:54-68); (0, 0) when that frame has no box."""
+        x, y, w, h = self.predict([sim.frame_number - self.timing_config.pred_frame_num])[0]
+        if not (np.isfinite(x) and np.isfinite(y) and np.isfinite(w) and np.isfinite(h)):
             return 0, 0
-        cx, cy = box[0] + box[2] / 2, box[1] + box[3] / 2
-        return round(cx - sim.view.camera_size[0] / 2), round(cy - sim.view.camera_size[1] / 2)
+        cam_w, cam_h = sim.view.camera_size
+        return round((x + w / 2) - cam_w / 2), round((y + h / 2) - cam_h / 2)  # Python's banker's rounding on float64, as the reference
 
     def _cycle_predict_all(self, sim) -> np.ndarray:
-        start = (sim.cycle_number - 1) * self.timing_config.cycle_frame_num
-        end = min(start + self.timing_config.cycle_frame_num, len(self._csv_data))
-        return self.predict(np.arange(start, end))
+        """The finished cycle's boxes relative to their camera views (what LoggingController logs, logging_controller.py:145-154)."""
+        n = self.timing_config.cycle_frame_num
+        first = (sim.cycle_number - 1) * n
+        return self.predict(np.arange(first, min(first + n, self.n_frames)))
 
 
 class OptimalController(CsvController):
@@ -84,7 +116,7 @@ class OptimalController(CsvController):
 
     def __init__(self, timing_config: TimingConfig, csv_path: str):
         super().__init__(timing_config, csv_path)
-        d = self._csv_data
+        d = self.track
         self._csv_centers = np.stack([d[:, 0] + d[:, 2] / 2, d[:, 1] + d[:, 3] / 2], axis=1)
 
     def provide_movement_vector(self, sim) -> tuple:
@@ -155,8 +187,8 @@ class _DeviceTrackMixin:
         import torch
 
         self._dev = torch.device("cuda", device)
-        self._track_dev = torch.from_numpy(np.ascontiguousarray(self._csv_data, dtype=np.float64)).to(self._dev)
-        n_cycles = len(self._csv_data) // self.timing_config.cycle_frame_num + 2
+        self._track_dev = torch.from_numpy(np.ascontiguousarray(self.track, dtype=np.float64)).to(self._dev)
+        n_cycles = self.n_frames // self.timing_config.cycle_frame_num + 2
         self._cycles_dev = torch.arange(n_cycles, dtype=torch.int32, device=self._dev)
         self._pred_dev = torch.zeros((n_cycles, 2), dtype=torch.float64, device=self._dev)
         self._valid_dev = torch.zeros((n_cycles,), dtype=torch.int32, device=self._dev)
@@ -179,7 +211,7 @@ class HipOptimalController(_DeviceTrackMixin, CsvController):
 
         n = self._upload_track(device)
         with torch.cuda.device(self._dev):
-            hip.track_median_centers(self._track_dev, len(self._csv_data), self._cycles_dev, n, timing_config.cycle_frame_num,
+            hip.track_median_centers(self._track_dev, self.n_frames, self._cycles_dev, n, timing_config.cycle_frame_num,
                                      timing_config.imaging_frame_num, self._pred_dev, self._valid_dev,
                                      stream=torch.cuda.current_stream(self._dev).cuda_stream)
         self._targets, self._has_target = self._download()
@@ -207,7 +239,7 @@ class HipPolyfitController(_DeviceTrackMixin, CsvController):
         n = self._upload_track(device)
         t_eval = timing_config.cycle_frame_num + timing_config.imaging_frame_num // 2
         with torch.cuda.device(self._dev):
-            hip.track_polyfit(self._track_dev, len(self._csv_data), self._cycles_dev, n, timing_config.cycle_frame_num,
+            hip.track_polyfit(self._track_dev, self.n_frames, self._cycles_dev, n, timing_config.cycle_frame_num,
                               polyfit_config.sample_times, polyfit_config.weights, polyfit_config.degree, t_eval, self._pred_dev,
                               self._valid_dev, stream=torch.cuda.current_stream(self._dev).cuda_stream)
         self._targets, self._has_target = self._download()

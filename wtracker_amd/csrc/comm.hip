@@ -71,8 +71,14 @@ extern "C" int wtk_comm_create(wtk_comm **out, int32_t device, int32_t rank, int
         return wtk_set_error("wtk_comm_create: no such HIP device (is a GPU visible?)");
     }
     if (load_rccl()) return 1;
+    int prev = -1;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) return wtk_set_error(std::string("wtk_comm_create: hipSetDevice: ") + hipGetErrorString(he));
+    struct Restore { // the caller's current device is left as it was found (PyTorch tracks the same thread-local state)
+        int prev; bool on;
+        ~Restore() { if (on) (void)hipSetDevice(prev); }
+    } restore{prev, have_prev && prev != device};
     ncclUniqueId uid;
     std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
     wtk_comm *c = new wtk_comm();

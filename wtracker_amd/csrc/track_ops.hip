@@ -56,46 +56,46 @@ template <typename T> __global__ __launch_bounds__(64) void track_median_kernel(
     a.valid[i] = 1;
 }
 
-// Symmetric eigen-decomposition of a K x K matrix (K <= kTrackMaxCoef) by cyclic Jacobi rotations, fp64.
-__device__ void jacobi_eig(double (&A)[kTrackMaxCoef][kTrackMaxCoef], double (&V)[kTrackMaxCoef][kTrackMaxCoef], int K) {
+// Singular value decomposition of the n x K matrix A (n <= kTrackMaxTimes, K <= kTrackMaxCoef) by one-sided Jacobi (Hestenes)
+// rotations of its COLUMNS, fp64: on return the columns of A are mutually orthogonal (A = U diag(s) as columns, s_p = |A[:,p]|)
+// and V holds the accumulated rotations, so A_in = U diag(s) V^T.  Working on the matrix itself (not on the Gram matrix) keeps
+// singular values down to ~eps * s_max resolved, which is what numpy's rcond = len(t) * eps needs.
+__device__ void jacobi_svd_columns(double (&A)[kTrackMaxTimes][kTrackMaxCoef], double (&V)[kTrackMaxCoef][kTrackMaxCoef], int n, int K) {
     for (int i = 0; i < K; ++i)
         for (int j = 0; j < K; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < K; ++p)
-            for (int q = p + 1; q < K; ++q) off += A[p][q] * A[p][q];
-        if (off < 1e-300) break;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
         for (int p = 0; p < K; ++p)
             for (int q = p + 1; q < K; ++q) {
-                if (fabs(A[p][q]) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < K; ++k) { // columns p, q of A
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq;
-                    A[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < K; ++k) { // rows p, q of A
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk;
-                    A[q][k] = s * apk + c * aqk;
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int j = 0; j < n; ++j) alpha += A[j][p] * A[j][p], beta += A[j][q] * A[j][q], gamma += A[j][p] * A[j][q];
+                if (!(fabs(gamma) > 1e-16 * sqrt(alpha * beta)) || gamma == 0.0) continue; // already orthogonal to working precision
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int j = 0; j < n; ++j) {
+                    const double ap = A[j][p], aq = A[j][q];
+                    A[j][p] = c * ap - sn * aq;
+                    A[j][q] = sn * ap + c * aq;
                 }
                 for (int k = 0; k < K; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq;
-                    V[k][q] = s * vkp + c * vkq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - sn * vq;
+                    V[k][q] = sn * vp + c * vq;
                 }
             }
+        if (!rotated) break;
     }
 }
 
 // PolyfitController.provide_movement_vector (polyfit_controller.py:54-84) up to the camera offsets (the fit commutes with the
 // translation by the camera corner): numpy.polynomial.polynomial.polyfit(t, centres, deg, w=weights) restated — weighted
-// Vandermonde with columns scaled to unit norm, minimum-norm least squares — then polyval at `t_eval`.  The least-squares
-// problem (<= 16 x 8) is solved through the eigen-decomposition of the scaled Gram matrix, directions with
-// lambda <= 1e-13 * lambda_max treated as null space (numpy: singular values <= len(t) * eps * s_max).  Agreement with
-// numpy's LAPACK gelsd: ~1e-10 px on pixel-scale positions; the controllers round to whole pixels.
+// Vandermonde with columns scaled to unit norm, minimum-norm least squares (numpy.linalg.lstsq = LAPACK gelsd: singular values
+// <= rcond * s_max are treated as zero, rcond = len(t) * eps with len(t) = the finite samples) — then polyval at `t_eval`.
+// The (<= 16 x 8) problem is solved through a one-sided Jacobi SVD of the scaled matrix itself, so the cut-off is numpy's at
+// every admitted degree (an eigen-decomposition of the Gram matrix, which round 2 used, only resolves singular-value ratios
+// down to ~3e-7 and truncated directions numpy keeps at degree >= 4-5 over tens of frames).
 template <typename T> __global__ __launch_bounds__(64) void track_polyfit_kernel(const TrackPolyfitArgs a) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n_samples) return;
@@ -126,32 +126,27 @@ template <typename T> __global__ __launch_bounds__(64) void track_polyfit_kernel
         }
     }
     for (int p = 0; p < K; ++p) scl[p] = scl[p] > 0.0 ? sqrt(scl[p]) : 1.0;
-    double G[kTrackMaxCoef][kTrackMaxCoef], V[kTrackMaxCoef][kTrackMaxCoef], bx[kTrackMaxCoef], by[kTrackMaxCoef];
-    for (int p = 0; p < K; ++p) {
-        bx[p] = by[p] = 0.0;
-        for (int q = 0; q < K; ++q) G[p][q] = 0.0;
-    }
+    double L[kTrackMaxTimes][kTrackMaxCoef], V[kTrackMaxCoef][kTrackMaxCoef];
     for (int j = 0; j < n; ++j) {
-        double row[kTrackMaxCoef];
         double tp = 1.0;
-        for (int p = 0; p < K; ++p) row[p] = ww[j] * tp / scl[p], tp *= tt[j];
-        for (int p = 0; p < K; ++p) {
-            bx[p] += row[p] * (ww[j] * px[j]);
-            by[p] += row[p] * (ww[j] * py[j]);
-            for (int q = 0; q < K; ++q) G[p][q] += row[p] * row[q];
-        }
+        for (int p = 0; p < K; ++p) L[j][p] = ww[j] * tp / scl[p], tp *= tt[j];
     }
-    jacobi_eig(G, V, K);
-    double lmax = 0.0;
-    for (int p = 0; p < K; ++p) lmax = fmax(lmax, G[p][p]);
+    jacobi_svd_columns(L, V, n, K);
+    double s2[kTrackMaxCoef], s2max = 0.0;
+    for (int e = 0; e < K; ++e) {
+        double q = 0.0;
+        for (int j = 0; j < n; ++j) q += L[j][e] * L[j][e];
+        s2[e] = q;
+        s2max = fmax(s2max, q);
+    }
+    const double rcond = (double)n * 2.220446049250313e-16; // numpy: len(x) * finfo(float64).eps
     double cx[kTrackMaxCoef], cy[kTrackMaxCoef];
     for (int p = 0; p < K; ++p) cx[p] = cy[p] = 0.0;
     for (int e = 0; e < K; ++e) {
-        const double lam = G[e][e];
-        if (!(lam > 1e-13 * lmax)) continue; // null-space direction: minimum-norm solution leaves it at zero
-        double dx = 0.0, dy = 0.0;
-        for (int p = 0; p < K; ++p) dx += V[p][e] * bx[p], dy += V[p][e] * by[p];
-        dx /= lam, dy /= lam;
+        if (!(s2[e] > rcond * rcond * s2max)) continue; // s_e <= rcond * s_max: null-space direction, the minimum-norm solution leaves it at zero
+        double dx = 0.0, dy = 0.0; // (u_e . rhs) / s_e = (L_rot[:,e] . rhs) / s_e^2
+        for (int j = 0; j < n; ++j) dx += L[j][e] * (ww[j] * px[j]), dy += L[j][e] * (ww[j] * py[j]);
+        dx /= s2[e], dy /= s2[e];
         for (int p = 0; p < K; ++p) cx[p] += V[p][e] * dx, cy[p] += V[p][e] * dy;
     }
     // polyval (Horner, highest power first) of c / scl at t_eval
@@ -198,24 +193,35 @@ template <typename T> __global__ __launch_bounds__(64) void track_pairs_kernel(c
     a.keep[i] = ok ? 1 : 0;
 }
 
-// rank of every margin among the batch's (ties broken by row): the K smallest go to slots[rank]; NaN counts as +inf
+// rank of every margin among the batch's (ties broken by row): the K smallest go to slots[rank]; NaN counts as +inf.
+// The weak rows (margin < thr) are counted by all 256 threads (wave ballots + one LDS add per wave); what the ceiling K cuts
+// off is ADDED to *n_overflow, so that a caller with K < B can see that rows kept their fast result without a second look.
 __global__ __launch_bounds__(256) void recheck_select_kernel(const RecheckArgs a) {
     __shared__ float m[1024];
+    __shared__ int weak;
+    if (threadIdx.x == 0) weak = 0;
     for (int i = threadIdx.x; i < a.B; i += 256) {
         const float v = a.margins[i];
         m[i] = v == v ? v : 3.4e38f;
     }
     __syncthreads();
+    int mine = 0;
     for (int i = threadIdx.x; i < a.B; i += 256) {
         const float mi = m[i];
         int rank = 0;
         for (int j = 0; j < a.B; ++j) rank += (m[j] < mi || (m[j] == mi && j < i)) ? 1 : 0;
         if (rank < a.K) a.slots[rank] = i;
+        mine += mi < a.thr ? 1 : 0;
     }
-    if (a.n_weak && threadIdx.x == 0) {
-        int n = 0;
-        for (int j = 0; j < a.B; ++j) n += m[j] < a.thr ? 1 : 0;
-        *a.n_weak = n < a.K ? n : a.K;
+    if (a.n_weak || a.n_overflow) {
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&weak, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n = weak;
+            if (a.n_weak) *a.n_weak = n < a.K ? n : a.K;
+            if (a.n_overflow && n > a.K) *a.n_overflow += n - a.K;  // one block per launch, launches of a stream are ordered: a plain add
+        }
     }
 }
 

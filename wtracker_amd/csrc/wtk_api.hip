@@ -56,9 +56,11 @@ extern "C" int wtk_debug_stamps(unsigned long long *host, size_t n_words) {
 #endif
 
 // Kernel attributes (dynamic LDS above 64 KiB) are per device: initialise them once for every device a handle is created on.
-static unsigned long long g_attr_done = 0; // bit d = device d initialised
+static unsigned long long g_attr_done = 0; // bit d = device d initialised (guarded by g_attr_mu: handles may be created from several host threads)
+static std::mutex g_attr_mu;
 static int ensure_attributes(int device) {
     if (device < 0 || device >= 64) return fail("device id out of range");
+    std::lock_guard<std::mutex> lk(g_attr_mu);
     if (g_attr_done & (1ull << device)) return 0;
     HIP_TRY(conv_init_attributes());
     HIP_TRY(pool_init_attributes());
@@ -120,7 +122,7 @@ extern "C" int wtk_mlp_create(wtk_mlp **out, const wtk_mlp_desc *d) {
     if (d->n_layers != 2 + d->n_blocks * d->layers_per_block) return fail("wtk_mlp_create: n_layers != 2 + n_blocks*layers_per_block");
     if (d->n_layers > kMlpMaxLayers) return fail("wtk_mlp_create: too many layers");
     if (wtk_device_count() <= d->device) return fail("wtk_mlp_create: no such HIP device (is a GPU visible?)");
-    HIP_TRY(hipSetDevice(d->device));
+    DEVICE_GUARD(d);
     std::vector<MlpLayerDev> L(d->n_layers);
     std::vector<float> blob;
     for (int i = 0; i < d->n_layers; ++i) {
@@ -209,7 +211,7 @@ extern "C" int wtk_mlp_forward(wtk_mlp *h, const float *x_dev, int32_t batch, fl
 extern "C" int wtk_mlp_forward_host(wtk_mlp *h, const float *x_host, int32_t batch, float *y_host) {
     if (!h || !x_host || !y_host) return fail("wtk_mlp_forward_host: null argument");
     if (batch <= 0) return batch == 0 ? 0 : fail("wtk_mlp_forward_host: negative batch");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     if (batch > h->scratch_cap) {
         (void)hipFree(h->x_dev);
         (void)hipFree(h->y_dev);
@@ -299,14 +301,19 @@ extern "C" int wtk_track_training_pairs(const void *track_dev, int32_t track_is_
     return 0;
 }
 
-extern "C" int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev, int32_t *n_weak_dev, void *stream) {
+extern "C" int wtk_recheck_select_counted(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev, int32_t *n_weak_dev,
+                                          int32_t *n_overflow_dev, void *stream) {
     if (!margins_dev || !slots_dev) return fail("wtk_recheck_select: null argument");
     if (B <= 0 || B > 1024 || K <= 0 || K > B) return fail("wtk_recheck_select: need 1 <= K <= B <= 1024");
     RecheckArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.margins = margins_dev, a.B = B, a.K = K, a.slots = slots_dev, a.thr = margin, a.n_weak = n_weak_dev;
+    a.margins = margins_dev, a.B = B, a.K = K, a.slots = slots_dev, a.thr = margin, a.n_weak = n_weak_dev, a.n_overflow = n_overflow_dev;
     HIP_TRY(launch_recheck_select(a, (hipStream_t)stream));
     return 0;
+}
+
+extern "C" int wtk_recheck_select(const float *margins_dev, int32_t B, int32_t K, float margin, int32_t *slots_dev, int32_t *n_weak_dev, void *stream) {
+    return wtk_recheck_select_counted(margins_dev, B, K, margin, slots_dev, n_weak_dev, nullptr, stream);
 }
 
 extern "C" int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin, const float *src_xywh,
@@ -636,14 +643,15 @@ static void dev_release(wtk_yolo *h) {
 
 extern "C" int wtk_release_cached_memory(void) {
     std::lock_guard<std::mutex> lk(g_block_mu);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     for (auto &b : g_blocks) {
         (void)hipSetDevice(b.device);
+        (void)hipDeviceSynchronize(); // a cached block may have been released by a handle whose kernels were enqueued from another thread
         (void)hipFree(b.p);
     }
     g_blocks.clear();
-    (void)hipSetDevice(cur);
+    if (have_cur) (void)hipSetDevice(cur);
     return 0;
 }
 
@@ -822,6 +830,7 @@ struct Planner {
 
 extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     if (!h) return;
+    DeviceGuard guard(h->device); // the synchronise and the releases below are about the HANDLE's device, whatever the caller's current device is
     (void)hipDeviceSynchronize(); // as the hipFree calls did implicitly: nothing of this handle may still be running when its blocks go back to the cache
     dev_release(h);
     (void)hipFree(h->frames_dev);
@@ -867,7 +876,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             if (dims.c[i] % 64 != 0 && !(i == 0 && dims.c[0] == 32)) return fail("wtk_yolo_create: WTK_F16X3 needs channel widths in multiples of 64 (stem: 32)");
         if (dims.hb % 32 || dims.hc % 32) return fail("wtk_yolo_create: WTK_F16X3 needs head widths in multiples of 32");
     }
-    HIP_TRY(hipSetDevice(d->device));
+    DEVICE_GUARD(d);
     if (ensure_attributes(d->device)) return 1;
 
     wtk_yolo *h = new wtk_yolo();
@@ -1229,6 +1238,13 @@ static int ensure_nms_scratch(wtk_yolo *h, hipStream_t st) {
 
 // Enqueue one forward pass (letterbox, stem, convs, pool, head) on `st`.  No allocation, no synchronisation
 // (profiling mode excepted): safe inside stream capture.
+// The pair of side streams is shared by every handle of the process on a device (ensure_side_streams).  Handles driven from different host
+// threads (ctypes releases the GIL) must not interleave on it: a stream capture in one thread (the graph path of wtk_yolo_predict pulls the side
+// streams into a hipStreamCaptureModeThreadLocal capture through the event waits) would swallow or reject the other thread's launches.  Every
+// enqueue that touches the shared pair, and the whole capture bracket, holds this lock; a single-threaded caller (the bench, the controllers)
+// never contends on it.
+static std::recursive_mutex g_side_mu;
+
 // side streams and their events, taken at the first forward pass that uses them
 static int ensure_side_streams(wtk_yolo *h) {
     const int n_side = h->side_streams >= 3 ? wtk_yolo::kSideStreams - 1 : h->side_streams;
@@ -1315,6 +1331,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
     if (h->use_side && h->side_streams > 0 && !h->profiling && ensure_side_streams(h)) return 1;
     const bool two_lanes = h->use_side && h->side_streams > 0 && h->side_stream[1] && !h->profiling;
+    std::unique_lock<std::recursive_mutex> side_lock;
+    if (two_lanes && h->side_shared) side_lock = std::unique_lock<std::recursive_mutex>(g_side_mu);
     unsigned side_used = 0; // bit i: side_stream[i] carries work of this pass
     hipStream_t main_st = st;
     size_t first_op = 0;
@@ -1626,9 +1644,11 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
         }
     hipGraph_t graph = nullptr;
     if (h->use_side && h->side_streams > 0 && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
+    std::unique_lock<std::recursive_mutex> capture_lock(g_side_mu); // no other thread may touch the shared side streams while they are captured
     HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
     const hipError_t ec = hipStreamEndCapture(st, &graph);
+    capture_lock.unlock();
     if (rc) {
         if (graph) (void)hipGraphDestroy(graph);
         return 1;
@@ -1697,7 +1717,7 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
     if (B <= 0) return fail("wtk_yolo_predict_host: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
     if (B > h->max_batch) return fail("wtk_yolo_predict_host: batch exceeds max_batch");
     if (H <= 0 || W <= 0 || (C != 1 && C != 3)) return fail("wtk_yolo_predict_host: bad frame shape");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     const size_t need = (size_t)B * H * W * C;
     if (need > h->frames_cap) {
         (void)hipFree(h->frames_dev);
@@ -1750,7 +1770,7 @@ extern "C" int wtk_yolo_margin_buffer(wtk_yolo *h, const float **margins_dev) {
 
 extern "C" int wtk_yolo_last_margins_host(wtk_yolo *h, int32_t B, float *margins_host) {
     if (!h || !margins_host || B <= 0 || B > h->max_batch) return fail("wtk_yolo_last_margins_host: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(margins_host, h->o_margin, sizeof(float) * B, hipMemcpyDeviceToHost));
     return 0;
@@ -1767,7 +1787,7 @@ static void to_f32(const void *src, float *dst, size_t n, int is_f16) {
 
 extern "C" int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float *box_host, float *cls_host) {
     if (!h || level < 0 || level > 2 || B <= 0 || B > h->max_batch) return fail("wtk_yolo_debug_head: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t A = (size_t)h->lh[level] * h->lw[level];
     if (box_host) {
@@ -1795,7 +1815,7 @@ extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B,
     if (!out_host) return 0;
     const size_t px = (size_t)B * b.h * b.w;
     if (out_cap < px * op->cout) return fail("wtk_yolo_debug_tensor: output buffer too small");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<char> tmp(px * b.C * (b.f32 ? 4 : h->esize));
     HIP_TRY(hipMemcpy(tmp.data(), b.ptr, tmp.size(), hipMemcpyDeviceToHost));
@@ -1821,7 +1841,7 @@ static int upload_head_logits(wtk_yolo *h, const float *box_host, const float *c
 extern "C" int wtk_yolo_decode_nms_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf, float iou,
                                         int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls, int32_t *out_anchor, int32_t *out_count) {
     if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch || max_det < 1) return fail("wtk_yolo_decode_nms_host: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(hipDeviceSynchronize());
     if (upload_head_logits(h, box_host, cls_host, B)) return 1;
     if (ensure_nms_scratch(h, nullptr)) return 1;
@@ -1850,7 +1870,7 @@ extern "C" int wtk_yolo_decode_nms_host(wtk_yolo *h, const float *box_host, cons
 extern "C" int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf,
                                     float *out_xywh, float *out_conf, int32_t *out_anchor) {
     if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch) return fail("wtk_yolo_decode_host: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DEVICE_GUARD(h);
     HIP_TRY(hipDeviceSynchronize());
     if (upload_head_logits(h, box_host, cls_host, B)) return 1;
     if (run_head(h, B, H, W, conf, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;

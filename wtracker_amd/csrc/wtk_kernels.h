@@ -504,6 +504,7 @@ struct RecheckArgs {
     int *dst_anchor;
     int *n_replaced;      // nullable: += number of rows replaced
     int *n_weak;          // select, nullable: = min(K, number of rows with margin < thr) — the leading slots (the input of wtk_yolo_set_dynamic_batch)
+    int *n_overflow;      // select, nullable: += max(rows with margin < thr - K, 0): weak rows that get NO second look because the ceiling K cut them off
 };
 hipError_t launch_recheck_select(const RecheckArgs &a, hipStream_t stream);
 hipError_t launch_recheck_merge(const RecheckArgs &a, hipStream_t stream);

@@ -58,7 +58,7 @@ SYMBOLS = [
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
     "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch", "wtk_yolo_set_side_streams",
-    "wtk_release_cached_memory",
+    "wtk_release_cached_memory", "wtk_recheck_select_counted",
 ]
 
 
@@ -137,6 +137,7 @@ def load() -> C.CDLL:
     lib.wtk_yolo_margin_buffer.argtypes = [vp, C.POINTER(vp)]
     lib.wtk_yolo_last_margins_host.argtypes = [vp, i32, vp]
     lib.wtk_recheck_select.argtypes = [vp, i32, i32, f32, vp, vp, vp]
+    lib.wtk_recheck_select_counted.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
     lib.wtk_yolo_set_dynamic_batch.argtypes = [vp, vp]
     lib.wtk_yolo_set_side_streams.argtypes = [vp, i32]
     lib.wtk_recheck_merge.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -188,9 +189,11 @@ def release_cached_memory():
     _check(load().wtk_release_cached_memory(), "wtk_release_cached_memory")
 
 
-def recheck_select(margins_dev, B: int, K: int, margin: float, slots_dev, n_weak_dev=None, stream: int = 0):
-    """slots[k] = batch row of the k-th smallest decision margin (device int32 [K]); n_weak = min(K, rows below `margin`); asynchronous on `stream`."""
-    _check(load().wtk_recheck_select(_ptr(margins_dev), B, K, margin, _ptr(slots_dev), _ptr(n_weak_dev), C.c_void_p(stream)), "wtk_recheck_select")
+def recheck_select(margins_dev, B: int, K: int, margin: float, slots_dev, n_weak_dev=None, stream: int = 0, n_overflow_dev=None):
+    """slots[k] = batch row of the k-th smallest decision margin (device int32 [K]); n_weak = min(K, rows below `margin`);
+    n_overflow += the weak rows beyond the ceiling K (they get no second look); asynchronous on `stream`."""
+    _check(load().wtk_recheck_select_counted(_ptr(margins_dev), B, K, margin, _ptr(slots_dev), _ptr(n_weak_dev), _ptr(n_overflow_dev), C.c_void_p(stream)),
+           "wtk_recheck_select_counted")
 
 
 def recheck_merge(margins_dev, slots_dev, B: int, K: int, margin: float, src_xywh, src_conf, src_anchor, dst_xywh, dst_conf=None, dst_anchor=None,

@@ -10,6 +10,12 @@ K is fixed, so the step is a constant sequence of launches on one stream; the fu
 from device memory (wtk_yolo_set_dynamic_batch) and its kernels skip the tiles of the slots beyond it, so the second look costs what
 the weak frames cost, not what K frames cost.
 
+K is a CEILING on the rows that can get a second look.  The default is K = the batch size (k=None): then no weak row can be cut
+off, whatever the data — 288 GB of HBM hold a full-batch f16x3 workspace easily (6.8 GB at 64 frames of 640x640) and the cost
+still follows the number of weak rows.  A caller that passes a smaller K trades memory for a bound: weak rows beyond K keep their
+fp16 result, and `overflow` (device counter, `overflow_count()` on the host) says how many did — it must read 0 for the
+"full-precision decisions" claim to hold on that run.
+
 It has the detector interface TrackPipeline uses (predict / predict_views / device / max_batch), so `dets=[HybridDetector(...)]`
 turns the open-loop pipeline into the hybrid mode.  torch: device memory only.
 """
@@ -21,9 +27,11 @@ from . import hip
 
 
 class HybridDetector:
-    def __init__(self, fast: hip.HipYolo, exact: hip.HipYolo, margin: float = 0.04, k: int = 16):
+    def __init__(self, fast: hip.HipYolo, exact: hip.HipYolo, margin: float = 0.04, k: int | None = None):
         if fast.device != exact.device:
             raise hip.WtkError("HybridDetector: both handles must live on the same device")
+        if k is None:
+            k = min(fast.max_batch, exact.max_batch)
         if k < 1 or k > exact.max_batch:
             raise hip.WtkError("HybridDetector: 1 <= k <= max_batch of the full-precision handle")
         self.fast, self.exact, self.margin, self.k = fast, exact, float(margin), int(k)
@@ -40,6 +48,7 @@ class HybridDetector:
         self._pos_tmp = torch.empty((self.k, 2), dtype=torch.int32, device=dev)
         self.replaced = torch.zeros((1,), dtype=torch.int32, device=dev)  # rows replaced so far (device counter)
         self._n_weak = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows of the current batch: the second look's dynamic batch size
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows so far that the ceiling k cut off (0 by construction when k >= B)
         exact.set_dynamic_batch(self._n_weak)
         # (the second look keeps the default concurrency: with ONE pair of side streams per process, shared by every handle, its towers cost no
         # extra streams — 17.7 k frames/s against 17.1 k with wtk_yolo_set_side_streams(0); with a pair per handle it was the other way round)
@@ -52,7 +61,7 @@ class HybridDetector:
         self.fast.predict(frames_dev, B, H, W, Cc, out_xywh, out_conf, out_anchor, conf=conf, iou=iou, max_det=1, stream=stream)
         k = min(self.k, B)
         m = self.fast.margin_buffer()
-        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream)
+        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream, n_overflow_dev=self.overflow)
         if self._pos is None or self._pos[0] != (H, W):
             # wtk_yolo_predict_views cuts frame[y0 : y0 + view_w, x0 : x0 + view_h] with (x0, y0) = pos - (view_w // 2, view_h // 2)
             # (view_controller.py:158-172): view (H, W) centred there is the frame itself
@@ -70,7 +79,7 @@ class HybridDetector:
                                 iou=iou, max_det=1, stream=stream)
         k = min(self.k, B)
         m = self.fast.margin_buffer()
-        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream)
+        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream, n_overflow_dev=self.overflow)
         # the weak rows' (frame, position): gathered by torch on the caller's stream (it must be torch's current stream)
         sl = self._slots[:k].long()
         if frame_index_dev is None:
@@ -81,6 +90,10 @@ class HybridDetector:
         self.exact.predict_views(frames_dev, n_frames, H, W, Cc, self._idx_tmp, self._pos_tmp, k, view_w, view_h, self._xywh, self._conf, self._anchor,
                                  conf=conf, iou=iou, max_det=1, stream=stream)
         hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
+
+    def overflow_count(self) -> int:
+        """Weak rows (margin below the threshold) that kept their fp16 result because more than k rows of a batch were weak.  Synchronises."""
+        return int(self.overflow.item())
 
     def set_profiling(self, enabled: bool):
         self.fast.set_profiling(enabled)
