@@ -11,17 +11,23 @@ vectors of the cycles that became computable are produced (wtracker_amd/pipeline
       --master-port P bench.py --gpus N --steps K --warmup W
 
 What the line carries (everything measured inside this one command):
-  value / ms_per_step   fp16 mode (BASELINE.md §4 allows it with an accuracy report): `--repeats` timed windows of EXACTLY
-                        `--steps` steps each, every window bracketed by barrier + device synchronisation, MAX over ranks per
-                        window; value = frames of one window / MEDIAN window; `windows` holds min / median / max
-  roofline              dominant kernel, algorithmic FLOPs / live HIP-event launch time (wtk_yolo_get_kernel_profile)
-  hybrid                fp16 on every frame + a full-precision (f16x3) second look at the weakest decisions of each batch   (N = 1 only)
-  f16x3                 the same workload with split-fp16 operands (fp32-grade results from the fp16 matrix pipe)   (N = 1 only)
-  fp32                  the same workload in the reference's precision (yolo/yolo_train_config.yaml:51 `half: False`),
-                        its own value / windows / roofline against the fp32 matrix peak                       (N = 1 only)
-  parity                survivor-index match rate and IoU distribution of BOTH modes against the fp32 CPU restatement on
+  value / ms_per_step   the HEADLINE mode (`dtype`): with the default `--dtype auto` the fastest mode whose survivor indices equal
+                        the fp32 CPU restatement's on EVERY parity frame of this run — "hybrid" (fp16 on every frame + a
+                        full-precision second look at every weak decision, no row cut off: `hybrid_overflow` must be 0), else
+                        "f16x3", else "fp32"; the choice is made from the `parity` object measured in this very command (N = 1).
+                        The reference computes in fp32 and keeps the arg-max anchor (yolo/yolo_train_config.yaml:51,
+                        yolo_controller.py:76): a mode that picks another survivor on some frames is not the headline.
+                        `--repeats` timed windows of EXACTLY `--steps` steps each, every window bracketed by barrier + device
+                        synchronisation, MAX over ranks per window; value = frames of one window / MEDIAN window
+  roofline              dominant kernel of the headline mode, algorithmic FLOPs / live HIP-event launch time
+  value_fp16 / value_hybrid / value_f16x3 / value_fp32, parity_index_match_<mode>, hybrid_overflow, hybrid_second_look_share
+                        flat copies of the per-mode numbers (N = 1 only)
+  fp16_throughput       the plain fp16 mode: labelled, NOT the headline (survivor index differs on ~2 % of the frames)     (N = 1 only)
+  hybrid / f16x3 / fp32 per-mode objects: value / windows / roofline                                                        (N = 1 only)
+  parity                survivor-index match rate and IoU distribution of ALL modes against the fp32 CPU restatement on
                         the CPU leg's frames, computed outside the timed regions                               (N = 1 only)
   cpu_baseline          oracle/ (kind "port") timed on the host cores at B = 64, 15 and 1                      (N = 1 only)
+  dist                  N > 1: world size and backend as torch.distributed reports them + a checksum of the gathered track
 Fields that cannot be measured from inside the process (HBM bytes and MFMA-busy share come from rocprofv3 PMC passes) are
 read from profiles/*.json ONLY when that file was collected on exactly these kernel sources (`src_sha`), and then carry a
 `provenance` entry; otherwise they are null.
@@ -41,8 +47,13 @@ if ROOT not in sys.path:
 # One hardware queue per stream: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues.  This process keeps five
 # streams busy (two lanes, the shared pair of side streams, torch's default stream); with four queues two of them share one and serialise:
 # 26.2 k frames/s against 27.1 k with 5, 6 or 8 queues (profiles/r02_notes.md §8).  Read by the runtime when it initialises: set before torch loads.
-# (Not for the one-GPU rehearsal of the multi-rank path, `--backend gloo`: there several processes share a device and their queues add up.)
-if not ("--backend" in sys.argv and sys.argv[sys.argv.index("--backend") + 1 : sys.argv.index("--backend") + 2] != ["nccl"]):
+# wtracker_amd.hip.load() sets the same default for any user of the library; it is spelled out here because torch loads first.
+# N > 1 with RCCL (`--backend nccl`): one process per GPU, so the eight queues are per DEVICE exactly as at N = 1; RCCL adds its own
+# stream(s) for the one 1-KiB all-gather per step, which is why the value is 8 and not 5.  The one-GPU rehearsal of the multi-rank path
+# (`--backend gloo`, every rank on cuda:0) keeps the runtime default: there the processes share a device and their queues add up (19.5 k -> 4.9 k).
+_pre = argparse.ArgumentParser(add_help=False)
+_pre.add_argument("--backend", default="nccl")
+if _pre.parse_known_args()[0].backend == "nccl":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
@@ -55,8 +66,10 @@ HBM_PEAK_GBPS = 8000.0
 # the hybrid sub-object: decisions with a margin below 0.04 get a second, full-precision look (at most 24 per 64 frames).  Every survivor mismatch of the
 # fp16 mode measured so far (30 in 1 792 frames, tools/margin_study.py) has a margin below 0.019; 16.5 % of the frames are below 0.04, at most 16 per batch.
 # The second look's cost follows the NUMBER of weak frames (device-side dynamic batch, wtk_yolo_set_dynamic_batch), so K is only a ceiling.
-HYBRID_MARGIN, HYBRID_K_PER_64 = 0.04, 24
-PROFILE_ROUND = "r02"
+# Ceiling = the whole batch (K = B): NO weak row can be cut off, by construction (ADVICE r02 / VERDICT r02 item 4); the overflow counter of
+# wtk_recheck_select_counted is reported anyway and must read 0.
+HYBRID_MARGIN = 0.04
+PROFILE_ROUND = "r03"
 
 
 def cpu_baseline(weights, dims, size: int, folded_path: str, frames64: np.ndarray, conf: float) -> tuple:
@@ -112,8 +125,7 @@ class Workload:
         if dtype == "hybrid":  # fp16 on every frame + the K weakest decisions of each batch again in f16x3, merged on the device
             from wtracker_amd.hybrid import HybridDetector
 
-            k = max(args.batch * HYBRID_K_PER_64 // 64, 1)
-            self.dets = [HybridDetector(handle("fp16", args.batch), handle("f16x3", k), margin=HYBRID_MARGIN, k=k) for _ in range(lanes)]
+            self.dets = [HybridDetector(handle("fp16", args.batch), handle("f16x3", args.batch), margin=HYBRID_MARGIN, k=args.batch) for _ in range(lanes)]
         else:
             self.dets = [handle(dtype, args.batch) for _ in range(lanes)]
         self.mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
@@ -136,7 +148,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=10, help="timed windows of --steps steps each (median reported)")
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config 3: 64)")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "f16x3", "hybrid"], help="precision mode of the headline value")
+    ap.add_argument("--dtype", default="auto", choices=["auto", "fp16", "fp32", "f16x3", "hybrid"],
+                    help="precision mode of the headline value; auto = the fastest mode whose survivors equal the fp32 restatement's on every parity frame of this run")
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic frames kept in HBM per rank")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline / parity sample (0 = skip both)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing (no roofline object)")
@@ -251,7 +264,16 @@ def main():
         if dtype == "hybrid":  # how many rows the second look replaced (device counters, read after the last window)
             n_rep = sum(int(d.replaced.item()) for d in wl.dets)
             res["second_look"] = {"rows_replaced": n_rep, "of_frames": s * args.batch, "share": n_rep / max(s * args.batch, 1),
-                                  "ceiling_per_batch": wl.dets[0].k, "margin": wl.dets[0].margin}
+                                  "ceiling_per_batch": wl.dets[0].k, "margin": wl.dets[0].margin,
+                                  "overflow_rows": sum(d.overflow_count() for d in wl.dets)}  # weak rows WITHOUT a second look: 0 by construction at K = B
+        if world > 1:  # evidence that the collective saw N ranks: a checksum of the gathered track, equal on every rank
+            tr = torch.nan_to_num(pipe.track[: s * args.batch * world].double(), nan=-1.0)
+            cs = torch.stack([tr.sum(), (tr * torch.arange(1, tr.shape[0] + 1, device=dev, dtype=torch.float64)[:, None]).sum()])
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            res["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "track_rows": int(tr.shape[0]),
+                           "track_checksum": [float(v) for v in cs.cpu()], "checksum_equal_on_all_ranks": bool(torch.equal(lo, hi))}
         wl.close()
         return res
 
@@ -268,8 +290,9 @@ def main():
 
     def roofline_object(prof: dict, kprof: dict, prof_steps: int, dtype: str) -> dict:
         peak = PEAK_TFLOPS[dtype]
-        tj, tprov = committed("conv_traffic") if dtype == "fp16" else (None, None)
-        uj, uprov = committed("pmc_mfma_util") if dtype == "fp16" else (None, None)
+        # (hybrid: the profiled handle is its fp16 one — the same kernels on the same shapes as the plain fp16 mode)
+        tj, tprov = committed("conv_traffic") if dtype in ("fp16", "hybrid") else (None, None)
+        uj, uprov = committed("pmc_mfma_util") if dtype in ("fp16", "hybrid") else (None, None)
 
         def kernel_line(name, k):
             avg_ms = k["total_ms"] / max(k["launches"], 1)
@@ -309,7 +332,69 @@ def main():
                 "kernels": lines, "class_ms_per_step": {k: v["total_ms"] / prof_steps for k, v in prof.items()},
                 "provenance": prov or None}
 
-    head = measure(args.dtype, args.lanes, args.repeats, not args.no_profile)
+    profile = not args.no_profile
+    modes: dict = {}
+    if world > 1 or args.dtype != "auto":
+        head_dtype = "hybrid" if args.dtype == "auto" else args.dtype  # N > 1 has no CPU leg: hybrid's exactness is asserted at N = 1 and in tests/
+        modes[head_dtype] = measure(head_dtype, args.lanes, args.repeats, profile)
+    else:
+        modes["hybrid"] = measure("hybrid", args.lanes, args.repeats, profile)
+    if world == 1 and not args.no_fp32:
+        # every other mode of the same workload, in the same command (fewer windows where a window is long)
+        for dt, rep in (("fp16", args.repeats), ("hybrid", max(min(args.repeats, 5), 1)), ("f16x3", max(min(args.repeats, 5), 1)), ("fp32", max(min(args.repeats, 3), 1))):
+            if dt not in modes:
+                modes[dt] = measure(dt, args.lanes, rep, profile)
+
+    par = None
+    cpu_obj = None
+    if world == 1 and args.cpu_frames > 0:
+        # ---- CPU baseline (oracle, kind 'port') + parity of every mode against it on the same frames, outside any timed region
+        n = max(args.cpu_frames // 64, 1) * 64
+        sample = fr.diverse_frames(n, args.size, seed=2000)
+        cpu_obj, (xo, co, ao) = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, golden, sample, args.conf)
+        par = {"checker": "oracle/yolo_oracle.py (fp32 torch-CPU restatement; parity unpinned: no ultralytics, no trained weights)",
+               "frames": f"{n} synthetic {args.size}x{args.size} frames from {n // 4} seeded tracks, conf {args.conf}",
+               "floors_asserted_in_tests": "tests/test_gpu_configs.py: fp16 index match >= 0.96, matched IoU min >= 0.99 (256 frames); fp32 / f16x3 / hybrid index match == 1; "
+                                           "tests/test_gpu_hybrid_validation.py: hybrid == f16x3 survivors on 2 048 out-of-sample frames x 3 weight seeds, overflow 0"}
+        mk = lambda dt, mb: hip.HipYolo(weights, (args.size, args.size), mb, dtype=dt, nc=nc, width=width, depth=depth, max_channels=maxch, device=local_rank)
+        for dtype in ("fp16", "fp32", "f16x3"):
+            det = mk(dtype, 64)
+            res = [det.predict_host(sample[i : i + 64], conf=args.conf) for i in range(0, n, 64)]
+            det.close()
+            xg, cg, ag = (np.concatenate([r[k] for r in res]) for k in range(3))
+            par[dtype] = metrics.accuracy_report(xg, ag, xo, ao, cg, co)
+        from wtracker_amd.hybrid import HybridDetector
+
+        hyb = HybridDetector(mk("fp16", 64), mk("f16x3", 64), margin=HYBRID_MARGIN, k=64)
+        sdev = torch.from_numpy(sample).to(dev)
+        ox, oc, oa = (torch.empty((n, 4), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+                      torch.empty((n,), dtype=torch.int32, device=dev))
+        for i in range(0, n, 64):
+            hyb.predict(sdev[i : i + 64], 64, args.size, args.size, 1, ox[i : i + 64], oc[i : i + 64], oa[i : i + 64], conf=args.conf)
+        torch.cuda.synchronize(dev)
+        par["hybrid"] = metrics.accuracy_report(ox.cpu().numpy(), oa.cpu().numpy(), xo, ao, oc.cpu().numpy(), co)
+        par["hybrid"]["rows_replaced"] = int(hyb.replaced.item())
+        par["hybrid"]["overflow_rows"] = hyb.overflow_count()
+        hyb.close()
+
+    def exact(dt: str) -> bool:
+        """The mode returned the fp32 restatement's survivor on every parity frame of this run (and, hybrid: no weak row was cut off)."""
+        if par is None or dt not in par or par[dt]["index_match_rate"] != 1.0:
+            return False
+        if dt == "hybrid":
+            return par[dt]["overflow_rows"] == 0 and modes.get("hybrid", {}).get("second_look", {}).get("overflow_rows", 0) == 0
+        return True
+
+    if args.dtype != "auto" or world > 1:
+        head_dtype = next(iter(modes))
+        head_reason = "requested with --dtype" if args.dtype != "auto" else "N > 1: hybrid (exactness asserted at N = 1 and in tests/test_gpu_hybrid_validation.py)"
+    else:
+        head_dtype = next((dt for dt in ("hybrid", "f16x3", "fp32") if dt in modes and exact(dt)), None)
+        head_reason = "fastest mode with parity.index_match_rate == 1.0 on this run's parity frames"
+        if head_dtype is None:  # no parity leg (--cpu-frames 0 / --no-fp32) or no exact mode: say so instead of guessing
+            head_dtype = "hybrid"
+            head_reason = "parity leg skipped or no mode exact on it: hybrid reported, exactness NOT established by this run"
+    head = modes[head_dtype]
 
     out = {
         "metric": f"frames/sec YOLOv8s+ResMLP sim loop @{args.size}x{args.size}",
@@ -322,64 +407,48 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": args.dtype,
+        "dtype": head_dtype,
         "data": "synthetic",
         "config": {"workload": ("BASELINE configs[2]" if args.size == 640 else f"BASELINE configs[4] per-GPU shape ({args.size}x{args.size})")
                                + ": full sim loop, YOLOv8s (nc=1, seeded synthetic weights) + ResMLP(imaging-100ms_pred-40ms_moving-50ms, reference weights)",
                    "frame": f"{args.size}x{args.size} uint8 gray, resident in HBM", "batch_per_gpu": args.batch, "lanes_per_gpu": args.lanes,
                    "global_batch": args.batch * world, "timing_ms": [100, 40, 50], "conf": args.conf,
+                   "headline_mode": head_dtype, "headline_reason": head_reason,
                    "parallelism": f"frame-sharded x{world}, one RCCL all-gather of [B,4] tracks per step" if world > 1 else "single GPU"},
         "windows": head["windows"],
         "roofline": head.get("roofline"),
     }
-
-    if world == 1:
-        # ---- the reference's precision, same workload, same command (fewer windows: a window is 6x longer)
-        if args.dtype == "fp16" and not args.no_fp32:
-            f32 = measure("fp32", args.lanes, max(min(args.repeats, 3), 1), not args.no_profile)
-            out["fp32"] = {k: f32[k] for k in ("dtype", "value", "unit", "ms_per_step", "windows")}
-            out["fp32"]["roofline"] = f32.get("roofline")
-            out["fp32"]["note"] = "reference precision (ultralytics half: False): exact-fp32 v_mfma_f32_16x16x4_f32 through the same kernels"
-            # ---- fp32-grade results from the fp16 matrix pipe: split-fp16 operands (hi + lo * 2^-11), three fp16 MFMAs per product
-            x3 = measure("f16x3", args.lanes, max(min(args.repeats, 5), 1), not args.no_profile)
-            out["f16x3"] = {k: x3[k] for k in ("dtype", "value", "unit", "ms_per_step", "windows")}
-            out["f16x3"]["roofline"] = x3.get("roofline")
-            hy = measure("hybrid", args.lanes, max(min(args.repeats, 5), 1), False)
-            out["hybrid"] = {k: hy[k] for k in ("dtype", "value", "unit", "ms_per_step", "windows", "second_look")}
-            out["hybrid"]["note"] = (f"wtracker_amd.hybrid.HybridDetector: fp16 on every frame, then the {HYBRID_K_PER_64} frames per 64 with the smallest decision "
-                                     f"margins again through f16x3 handles and merged where the margin is below {HYBRID_MARGIN} — all on the device, fixed launch "
-                                     "sequence; the parity object shows what it buys")
-            out["f16x3"]["note"] = ("split-fp16 storage and three v_mfma_f32_16x16x32_f16 per product: every conv tensor within 4e-6 of the exact-fp32 "
-                                    "mode's (tests/test_gpu_f16x3.py), survivor indices equal the fp32 restatement's; roofline peak = fp16 peak / 3")
-        # ---- CPU baseline (oracle, kind 'port') + parity of both modes against it on the same frames, outside any timed region
-        if args.cpu_frames > 0:
-            n = max(args.cpu_frames // 64, 1) * 64
-            sample = fr.diverse_frames(n, args.size, seed=2000)
-            out["cpu_baseline"], (xo, co, ao) = cpu_baseline(weights, ys.model_dims(width, depth, maxch, nc), args.size, golden, sample, args.conf)
-            par = {"checker": "oracle/yolo_oracle.py (fp32 torch-CPU restatement; parity unpinned: no ultralytics, no trained weights)",
-                   "frames": f"{n} synthetic {args.size}x{args.size} frames from {n // 4} seeded tracks, conf {args.conf}",
-                   "floors_asserted_in_tests": "tests/test_gpu_configs.py: fp16 index match >= 0.93, matched IoU min >= 0.99 (256 frames); fp32 index match == 1"}
-            for dtype in ("fp16", "fp32", "f16x3"):
-                det = hip.HipYolo(weights, (args.size, args.size), 64, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=local_rank)
-                res = [det.predict_host(sample[i : i + 64], conf=args.conf) for i in range(0, n, 64)]
-                det.close()
-                xg, cg, ag = (np.concatenate([r[k] for r in res]) for k in range(3))
-                par[dtype] = metrics.accuracy_report(xg, ag, xo, ao, cg, co)
-            if args.dtype == "fp16" and not args.no_fp32:
-                from wtracker_amd.hybrid import HybridDetector
-
-                mk = lambda dt, mb: hip.HipYolo(weights, (args.size, args.size), mb, dtype=dt, nc=nc, width=width, depth=depth, max_channels=maxch, device=local_rank)
-                hyb = HybridDetector(mk("fp16", 64), mk("f16x3", HYBRID_K_PER_64), margin=HYBRID_MARGIN, k=HYBRID_K_PER_64)
-                sdev = torch.from_numpy(sample).to(dev)
-                ox, oc, oa = (torch.empty((n, 4), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
-                              torch.empty((n,), dtype=torch.int32, device=dev))
-                for i in range(0, n, 64):
-                    hyb.predict(sdev[i : i + 64], 64, args.size, args.size, 1, ox[i : i + 64], oc[i : i + 64], oa[i : i + 64], conf=args.conf)
-                torch.cuda.synchronize(dev)
-                par["hybrid"] = metrics.accuracy_report(ox.cpu().numpy(), oa.cpu().numpy(), xo, ao, oc.cpu().numpy(), co)
-                par["hybrid"]["rows_replaced"] = int(hyb.replaced.item())
-                hyb.close()
-            out["parity"] = par
+    if "dist" in head:
+        out["dist"] = head["dist"]
+    # flat per-mode keys (a record that keeps only top-level scalars still carries every mode and its exactness)
+    for dt, m in modes.items():
+        out[f"value_{dt}"] = m["value"]
+        out[f"ms_per_step_{dt}"] = m["ms_per_step"]
+        if m.get("roofline"):
+            out[f"roofline_frac_{dt}"] = m["roofline"]["frac"]
+    if par is not None:
+        for dt in ("fp16", "hybrid", "f16x3", "fp32"):
+            if dt in par:
+                out[f"parity_index_match_{dt}"] = par[dt]["index_match_rate"]
+    if "hybrid" in modes:
+        out["hybrid_overflow"] = modes["hybrid"]["second_look"]["overflow_rows"] + (par["hybrid"]["overflow_rows"] if par and "hybrid" in par else 0)
+        out["hybrid_second_look_share"] = modes["hybrid"]["second_look"]["share"]
+        out["hybrid_margin"] = HYBRID_MARGIN
+    notes = {
+        "fp16": "plain fp16 mode (throughput only): its survivor differs from the fp32 restatement's on ~2 % of the frames, so it is not the headline",
+        "hybrid": (f"wtracker_amd.hybrid.HybridDetector: fp16 on every frame, then EVERY frame whose decision margin is below {HYBRID_MARGIN} again through an f16x3 handle "
+                   "(ceiling = the whole batch, device-side dynamic batch: the cost follows the number of weak frames) and merged on the device; fixed launch sequence, no host round trip"),
+        "f16x3": ("split-fp16 storage and three v_mfma_f32_16x16x32_f16 per product: every conv tensor within 4e-6 of the exact-fp32 "
+                  "mode's (tests/test_gpu_f16x3.py), survivor indices equal the fp32 restatement's; roofline peak = fp16 peak / 3"),
+        "fp32": "reference precision (ultralytics half: False): exact-fp32 v_mfma_f32_16x16x4_f32 through the same kernels",
+    }
+    for dt, m in modes.items():
+        key = "fp16_throughput" if dt == "fp16" else dt
+        out[key] = {k: m[k] for k in ("dtype", "value", "unit", "ms_per_step", "windows", "second_look", "roofline") if k in m}
+        out[key]["note"] = notes[dt]
+    if cpu_obj is not None:
+        out["cpu_baseline"] = cpu_obj
+        out["parity"] = par
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

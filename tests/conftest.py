@@ -15,8 +15,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """test_a_gpu_two_ranks.py starts rank processes and must do so before this process has touched the GPU: keep it first."""
-    items.sort(key=lambda it: 0 if "test_a_gpu_two_ranks" in it.nodeid else 1)
+    """test_a_gpu_*.py start rank processes and must do so before this process has touched the GPU: keep them first
+    (the RCCL multi-device module before the one-device gloo rehearsal, whose comparison run initialises the GPU here)."""
+    items.sort(key=lambda it: 0 if "test_a_gpu_multi_device" in it.nodeid else 1 if "test_a_gpu_two_ranks" in it.nodeid else 2)
 
 
 @pytest.fixture(scope="session")

@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16", hybrid=False):
+def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16", hybrid=False, comm=None):
     """Shared by the rank processes and by the single-rank comparison run in the test.  `hybrid`: scale-s HybridDetector lanes (fp16 +
     an f16x3 second look at every row below the margin: ceiling = batch, so the replaced rows do not depend on how frames are batched)."""
     import torch
@@ -42,7 +42,7 @@ def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, sca
     mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=device.index or 0)
     total = steps * batch * world
     pipe = TrackPipeline(dets, mlp, folded, batch, total, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9, conf=0.1,
-                         rank=rank, world=world, group=group, device=device)
+                         rank=rank, world=world, group=group, device=device, comm=comm)
     frames = torch.from_numpy(frames_np).to(device)
     for s in range(steps):
         f0, f1 = pipe.plan.local_range(s, rank)
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--hybrid", action="store_true")
+    ap.add_argument("--wtkcomm", default="", help="rendezvous file: exchange tracks through the C ABI's own RCCL communicator (hip.WtkComm) instead of torch.distributed")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
@@ -77,6 +78,27 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", rank))
     dev = torch.device("cuda", local if args.backend == "nccl" else 0)
     torch.cuda.set_device(dev)
+    if args.wtkcomm:
+        # no torch.distributed at all: rank 0 writes the 128-byte RCCL token to a file (the out-of-band hand-over wtk_hip.h describes), the others pick it up
+        import time
+
+        from wtracker_amd import hip
+
+        if rank == 0:
+            with open(args.wtkcomm + ".tmp", "wb") as f:
+                f.write(hip.comm_unique_id())
+            os.replace(args.wtkcomm + ".tmp", args.wtkcomm)
+        t0 = time.time()
+        while not os.path.exists(args.wtkcomm):
+            if time.time() - t0 > 120:
+                raise SystemExit("rendezvous token never appeared")
+            time.sleep(0.05)
+        comm = hip.WtkComm(dev.index, rank, world, open(args.wtkcomm, "rb").read())
+        frames_np, _ = fr.synthetic_frames(args.steps * args.batch * world, 128, seed=4)
+        out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes, hybrid=args.hybrid, comm=comm)
+        np.savez(args.out, **out)
+        comm.close()
+        return
     if args.backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 # ---- the floors this build holds in fp16 mode at 640x640 (measured: 248 / 256 = 0.969 index match, every mismatch with an
 # oracle top-1 / top-2 logit gap below 0.02; matched-frame IoU min 0.9974) -----------------------------------------------
-F16_INDEX_MATCH_MIN = 0.93      # 3 sigma below the measured rate at n = 256
+F16_INDEX_MATCH_MIN = 0.96      # measured 250 / 256 = 0.977 (0.973 on a second set): one and a half sigma of head-room, a real regression fails
 F16_IOU_MATCHED_MIN = 0.99      # every matched frame
 F16_IOU_MATCHED_P01 = 0.995
 F16_CONF_ATOL = 0.02
@@ -80,7 +80,7 @@ def test_fp16_accuracy_vs_fp32_oracle_at_640_b64(hip_lib, capsys):
     assert rep["conf_abs_err_max"] <= F16_CONF_ATOL
     assert rep["nan_row_agreement"] >= 0.98 and rep["nan_row_agreement_at_median_conf"] >= 0.95
     # a differing survivor only ever happens where the oracle itself is nearly tied
-    assert rep["mismatch_oracle_logit_gap_max"] < 0.1
+    assert rep["mismatch_oracle_logit_gap_max"] < 0.03  # measured 0.019 at most (1 792 frames)
     # reference precision: the fp32 mode and the split-fp16 mode ("f16x3") are index-exact on all 256 frames
     for exact in ("fp32", "f16x3"):
         _, _, det32 = _s_models(size, exact, B)

@@ -17,8 +17,12 @@ pytestmark = pytest.mark.gpu
 # fp32 mode: exact-fp32 MFMA vs torch-CPU fp32 — only summation order and expf differ
 F32_LOGIT_ATOL = 2e-3
 F32_BOX_ATOL = 2e-2   # pixels
-# fp16 mode: fp16 storage of every activation; logits are O(1..10)
-F16_LOGIT_ATOL = 0.35
+# fp16 mode: fp16 storage of every activation; logits are O(1..10).  FIXED bounds (round 3: no tolerance is derived from the run under test,
+# so a kernel that got noisier fails): the largest class-logit error over all anchors of a batch, and — for a frame whose survivor differs
+# from the fp32 restatement's — how far below the restatement's best logit the chosen anchor's restatement logit may lie.  Measured on this
+# build: logit error <= 0.11 (128^2 .. 1280^2), mismatch gaps <= 0.019 (1 792 frames at 640^2, profiles/r02_margin_study.json).
+F16_LOGIT_ATOL = 0.15
+F16_MISMATCH_GAP_MAX = 0.05
 F16_IOU_MIN = 0.90
 
 
@@ -63,14 +67,16 @@ def test_fp32_head_logits_and_boxes_match_oracle(hip_lib, scale, size, B):
 
 def _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, net_hw, hw, conf):
     """fp16 mode against the fp32 oracle, with NO escape for frames whose survivor differs: (1) the selection the
-    GPU made from ITS OWN logits is bit-exact in index vs the oracle's selection logic on those logits; (2) every
-    frame whose survivor differs from the fp32 oracle's is counted, and must be explained by the measured logit
-    error eps = max|cls_gpu - cls_oracle|: an arg-max under a perturbation of at most eps can only move to an
-    anchor whose oracle logit lies within 2 eps of the oracle's best; (3) matched survivors have IoU > F16_IOU_MIN.
-    Returns the number of mismatching frames (the rate itself is asserted at BASELINE scale in test_gpu_configs.py)."""
+    GPU made from ITS OWN logits is bit-exact in index vs the oracle's selection logic on those logits; (2) the class- and
+    box-logit error over ALL anchors stays below the fixed F16_LOGIT_ATOL; (3) every frame whose survivor differs from the
+    fp32 oracle's is counted, and the anchor it chose must lie within the fixed F16_MISMATCH_GAP_MAX of the oracle's best logit
+    (a NaN row on one side only: the oracle's best within that distance of the threshold); (4) matched survivors have
+    IoU > F16_IOU_MIN.  Returns the number of mismatching frames (the rate is asserted at BASELINE scale in test_gpu_configs.py)."""
     cls_o_np, box_o_np = cls_o.numpy(), box_o.numpy()
-    eps = float(np.abs(cls_g - cls_o_np).max())
-    assert eps < F16_LOGIT_ATOL and np.abs(box_g - box_o_np).max() < F16_LOGIT_ATOL
+    eps = F16_MISMATCH_GAP_MAX / 2
+    measured = float(np.abs(cls_g - cls_o_np).max())
+    print(f"\nfp16 logit error over all anchors: cls {measured:.4f}, box {float(np.abs(box_g - box_o_np).max()):.4f} (bound {F16_LOGIT_ATOL})")
+    assert measured < F16_LOGIT_ATOL and np.abs(box_g - box_o_np).max() < F16_LOGIT_ATOL
     xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), net_hw, hw, conf=conf)
     np.testing.assert_array_equal(anchor, anchor_s)
     np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=2e-2)
@@ -88,7 +94,7 @@ def _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, n
         if anchor[n] >= 0 and anchor_o[n] >= 0:
             assert top - best_o[n, anchor[n]] <= 2 * eps, (n, anchor[n], anchor_o[n], top - best_o[n, anchor[n]], eps)
         else:  # a NaN row on one side only: the oracle's best score sits within eps of the threshold
-            assert abs(top - thr) <= eps + 1e-6, (n, top, thr, eps)
+            assert abs(top - thr) <= 2 * eps, (n, top, thr, eps)
     return mismatches
 
 
@@ -290,6 +296,57 @@ def test_full_size_640_matches_oracle(hip_lib, dtype, B):
         np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=F32_BOX_ATOL)
     else:
         _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, (size, size), hw, 0.1)
+
+
+_SEED_ORACLE: dict = {}
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_exact_modes_match_oracle_on_other_weight_draws(hip_lib, seed):
+    """The detector's oracle is parity-unpinned (no ultralytics, no trained weights), so the evidence it can give is breadth: besides
+    the weight draw every other test uses (seed 0), three more draws of all 63 convs at BASELINE's frame size — fp32 and f16x3 head
+    logits within 2e-3 of the restatement's and the survivor index equal on every frame (the per-conv gains stored for seed 0 are a
+    variance correction, not a fit: they transfer, and the test checks that both outcomes — detection and NaN row — stay reachable)."""
+    size, B = 640, 4
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    frames = fr.diverse_frames(B, size, seed=30000 + 10 * seed, per_seed=1)
+    oracle, det = _models("s", size, "fp32", seed=seed, max_batch=B)
+    box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
+    xywh_o, conf_o, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.1)
+    best = cls_o.numpy().max(axis=(1, 2))
+    assert np.isfinite(best).all() and -12 < best.min() and best.max() < 12, best  # logits at unit scale: nothing saturated
+    for dtype in ("fp32", "f16x3"):
+        if dtype != "fp32":
+            det.close()
+            _, det = _models("s", size, dtype, seed=seed, max_batch=B)
+        xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+        box_g, cls_g = det.debug_head(B)
+        assert np.abs(cls_g - cls_o.numpy()).max() < F32_LOGIT_ATOL and np.abs(box_g - box_o.numpy()).max() < F32_LOGIT_ATOL, dtype
+        np.testing.assert_array_equal(anchor, anchor_o)
+        ok = anchor_o >= 0
+        np.testing.assert_allclose(xywh[ok], xywh_o[ok], rtol=0, atol=F32_BOX_ATOL)
+        np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
+    det.close()
+
+
+def test_widest_class_count_at_scale_s_640(hip_lib):
+    """nc = 32, the widest head this library admits (wtk_yolo_create refuses more: the fused class-tower tail stores 32 padded
+    channels; the reference trains with single_cls, yolo/yolo_train_config.yaml:27): every class logit within 2e-3 of the
+    restatement's, survivor index equal, at BASELINE's frame size."""
+    size, B, nc = 640, 2, 32
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    oracle, det = _models("s", size, "fp32", nc=nc, max_batch=B)
+    frames = fr.diverse_frames(B, size, seed=31000, per_seed=1)
+    box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.01)
+    box_g, cls_g = det.debug_head(B)
+    assert cls_g.shape == (B, 8400, nc)
+    assert np.abs(cls_g - cls_o.numpy()).max() < F32_LOGIT_ATOL and np.abs(box_g - box_o.numpy()).max() < F32_LOGIT_ATOL
+    _, _, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.01)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    det.close()
+    with pytest.raises(hip.WtkError, match="nc"):
+        _models("s", size, "fp32", nc=80, max_batch=1)
 
 
 def test_letterbox_360_to_384_like_the_reference_workflow(hip_lib):

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Out-of-sample validation of the hybrid detector (wtracker_amd/hybrid.py) — VERDICT r02 "next" item 1c.
+
+The hybrid's claim: with fp16 on every frame and an f16x3 second look at every frame whose fp16 decision margin is below MARGIN,
+the survivor anchor is the full-precision one on EVERY frame.  That holds iff no fp16 survivor mismatch ever has a margin >= MARGIN.
+MARGIN = 0.04 was chosen from tools/margin_study.py on frame seeds 1000 / 5000 / 7000 / 9000 with weight seed 0; this script
+measures the same thing on frames and weights that study never saw:
+
+  frames   --frames per weight seed from fr.diverse_frames(seed=--frame-seed): seeds 20000.. by default (the study used 1000-9127,
+           bench.py uses 2000-2031 and 3000-3031)
+  weights  --weight-seeds (default 1 2 3; the stored per-conv gains were calibrated on seed 0: the report says what the scores look like)
+
+Per weight seed it reports: fp16 survivor mismatches against the f16x3 handle (GPU, every frame) and their fp16 margins (the largest
+one is THE number to hold against MARGIN), hybrid == f16x3 on every frame, the overflow counter (K = batch: 0 by construction), the
+share of frames that took the second look; and, with --oracle-frames N > 0, f16x3 / hybrid against the fp32 CPU restatement
+(oracle/yolo_oracle.py) on the first N frames.  Writes one JSON (default profiles/r03_hybrid_validation.json).
+
+  python tools/hybrid_validation.py --frames 2048 --oracle-frames 256
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def run_weight_seed(weight_seed: int, frames: np.ndarray, size: int, batch: int, margin: float, conf: float, oracle_frames: int = 0, k: int | None = None) -> dict:
+    from wtracker_amd import hip
+    from wtracker_amd import yolo_spec as ys
+    from wtracker_amd.hybrid import HybridDetector
+
+    w = ys.synthetic_weights("s", 1, seed=weight_seed)
+    depth, width, maxch = ys.SCALES["s"]
+    mk = lambda dt, mb: hip.HipYolo(w, (size, size), mb, dtype=dt, nc=1, width=width, depth=depth, max_channels=maxch)
+    n = len(frames) // batch * batch
+    k = batch if k is None else k
+    plain, exact = mk("fp16", batch), mk("f16x3", batch)
+    hyb = HybridDetector(mk("fp16", batch), mk("f16x3", k), margin=margin, k=k)
+    dev = torch.device("cuda", 0)
+    out = {name: (torch.empty((n, 4), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+                  torch.empty((n,), dtype=torch.int32, device=dev)) for name in ("fp16", "f16x3", "hybrid")}
+    margins = np.empty((n,), dtype=np.float32)
+    weak_per_batch = []
+    buf = torch.empty((batch, size, size), dtype=torch.uint8, device=dev)
+    for i in range(0, n, batch):
+        buf.copy_(torch.from_numpy(frames[i : i + batch]))
+        sl = slice(i, i + batch)
+        for name, det in (("fp16", plain), ("f16x3", exact), ("hybrid", hyb)):
+            x, c, a = out[name]
+            det.predict(buf, batch, size, size, 1, x[sl], c[sl], a[sl], conf=conf)
+        torch.cuda.synchronize(dev)
+        margins[sl] = plain.last_margins(batch)
+        weak_per_batch.append(int((margins[sl] < margin).sum()))
+    res = {k_: tuple(t.cpu().numpy() for t in v) for k_, v in out.items()}
+    a16, ax3, ahy = res["fp16"][2], res["f16x3"][2], res["hybrid"][2]
+    bad = np.nonzero(a16 != ax3)[0]
+    rep = {"weight_seed": weight_seed, "frames": int(n), "detections_f16x3": int((ax3 >= 0).sum()),
+           "best_score_f16x3": {"p05": float(np.percentile(res["f16x3"][1], 5)), "p50": float(np.percentile(res["f16x3"][1], 50)), "p95": float(np.percentile(res["f16x3"][1], 95))},
+           "fp16_mismatches_vs_f16x3": int(len(bad)), "fp16_index_match_rate": float((a16 == ax3).mean()),
+           "fp16_mismatch_margin_max": float(margins[bad].max()) if len(bad) else 0.0,
+           "fp16_mismatch_margins_sorted_desc": [float(v) for v in np.sort(margins[bad])[::-1][:8]],
+           "margin_threshold": margin, "frames_below_threshold": int((margins < margin).sum()), "share_below_threshold": float((margins < margin).mean()),
+           "weak_per_batch_max": int(max(weak_per_batch)), "ceiling_per_batch": k,
+           "hybrid_equals_f16x3_index": bool((ahy == ax3).all()), "hybrid_index_mismatches_vs_f16x3": int((ahy != ax3).sum()),
+           "hybrid_rows_replaced": int(hyb.replaced.item()), "hybrid_overflow_rows": hyb.overflow_count()}
+    strong = margins >= margin
+    rep["hybrid_strong_rows_are_fp16_rows"] = bool(np.array_equal(res["hybrid"][0][strong], res["fp16"][0][strong], equal_nan=True))
+    weak = ~strong
+    rep["hybrid_weak_rows_are_f16x3_rows"] = bool(np.array_equal(res["hybrid"][0][weak], res["f16x3"][0][weak], equal_nan=True)) if rep["hybrid_overflow_rows"] == 0 else None
+    if oracle_frames > 0:
+        from oracle import yolo_oracle as yo
+        from wtracker_amd import metrics
+
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        m = min(oracle_frames, n)
+        oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
+        xs, cs, an, gaps = [], [], [], []
+        with torch.no_grad():
+            for i in range(0, m, 16):
+                x, hw = yo.preprocess(list(frames[i : i + 16]), size)
+                box, cls = oracle.forward(x)
+                a, b, c = yo.postprocess(box, cls, tuple(x.shape[2:]), hw, conf=conf)
+                xs.append(np.asarray(a, dtype=np.float64)), cs.append(b), an.append(c)
+                top2 = torch.topk(cls.max(2).values, 2, dim=1).values
+                gaps.append((top2[:, 0] - top2[:, 1]).numpy())
+        xo, co, ao, gap = np.concatenate(xs), np.concatenate(cs), np.concatenate(an), np.concatenate(gaps)
+        for name in ("fp16", "f16x3", "hybrid"):
+            x, c, a = (v[:m] for v in res[name])
+            r = metrics.accuracy_report(x, a, xo, ao, c, co)
+            wrong = np.nonzero(a != ao)[0]
+            r["mismatch_oracle_logit_gap_max"] = float(gap[wrong].max()) if len(wrong) else 0.0
+            rep[f"vs_cpu_restatement_{name}"] = r
+    for d in (plain, exact):
+        d.close()
+    hyb.close()
+    return rep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=2048)
+    ap.add_argument("--frame-seed", type=int, default=20000)
+    ap.add_argument("--weight-seeds", type=int, nargs="+", default=[1, 2, 3])
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--margin", type=float, default=0.04)
+    ap.add_argument("--conf", type=float, default=0.1)
+    ap.add_argument("--oracle-frames", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_hybrid_validation.json"))
+    args = ap.parse_args()
+    from wtracker_amd import _build
+    from wtracker_amd import frames as fr
+
+    t0 = time.time()
+    frames = fr.diverse_frames(args.frames, args.size, seed=args.frame_seed)
+    print(f"{len(frames)} frames drawn in {time.time() - t0:.1f} s", flush=True)
+    out = {"src_sha": _build.source_sha(), "frames_per_weight_seed": int(len(frames)), "frame_seed": args.frame_seed, "size": args.size, "batch": args.batch,
+           "margin": args.margin, "conf": args.conf, "per_weight_seed": []}
+    for ws in args.weight_seeds:
+        t0 = time.time()
+        rep = run_weight_seed(ws, frames, args.size, args.batch, args.margin, args.conf, args.oracle_frames)
+        rep["seconds"] = time.time() - t0
+        out["per_weight_seed"].append(rep)
+        print(json.dumps(rep), flush=True)
+    tot = out["per_weight_seed"]
+    out["summary"] = {"frames": sum(r["frames"] for r in tot), "fp16_mismatches": sum(r["fp16_mismatches_vs_f16x3"] for r in tot),
+                      "fp16_mismatch_margin_max": max(r["fp16_mismatch_margin_max"] for r in tot),
+                      "hybrid_index_mismatches": sum(r["hybrid_index_mismatches_vs_f16x3"] for r in tot),
+                      "hybrid_overflow_rows": sum(r["hybrid_overflow_rows"] for r in tot), "margin_threshold": args.margin}
+    print("summary " + json.dumps(out["summary"]), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
