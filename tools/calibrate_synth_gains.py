@@ -24,9 +24,9 @@ from wtracker_amd import frames as fr  # noqa: E402
 from wtracker_amd import yolo_spec as ys  # noqa: E402
 
 
-def calibrate(scale: str, size: int = 320, n_frames: int = 4) -> dict:
+def calibrate(scale: str, size: int = 320, n_frames: int = 4, seed: int = 0) -> dict:
     depth, width, maxch = ys.SCALES[scale]
-    w = ys.synthetic_weights(scale, 1, seed=0, gains={})
+    w = ys.synthetic_weights(scale, 1, seed=seed, gains={})
     m = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
     f, _ = fr.synthetic_frames(n_frames, size, seed=3)
     gains = {}
@@ -50,7 +50,16 @@ def calibrate(scale: str, size: int = 320, n_frames: int = 4) -> dict:
 
 
 if __name__ == "__main__":
+    # default: the seed-0 tables of scales n and s;  `--seeds 1 2 3`: per-seed tables for scale s (synth_gain_s_seed<k>.json) — the factors are
+    # a property of the weight DRAW (measured round 3: with the seed-0 table a seed-1 net saturates every class score at 1.0)
     os.makedirs(os.path.join(ROOT, "wtracker_amd", "data"), exist_ok=True)
+    if "--seeds" in sys.argv:
+        for seed in (int(v) for v in sys.argv[sys.argv.index("--seeds") + 1 :]):
+            g = calibrate("s", seed=seed)
+            path = os.path.join(ROOT, "wtracker_amd", "data", f"synth_gain_s_seed{seed}.json")
+            json.dump(g, open(path, "w"), indent=0)
+            print("s seed", seed, "gains min %.3f max %.3f" % (min(g.values()), max(g.values())), "->", path)
+        sys.exit(0)
     for scale in ("n", "s"):
         g = calibrate(scale)
         path = os.path.join(ROOT, "wtracker_amd", "data", f"synth_gain_{scale}.json")

@@ -145,12 +145,15 @@ _SILU_SECOND_MOMENT = 0.3557  # E[silu(z)^2], z ~ N(0,1)
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
-def _stored_gains(scale) -> dict:
-    """Per-conv scale factors measured once by tools/calibrate_synth_gains.py (63 floats per scale)."""
+def _stored_gains(scale, seed: int = 0) -> dict:
+    """Per-conv scale factors measured once by tools/calibrate_synth_gains.py (63 floats per scale).  They belong to a weight DRAW:
+    seed 0 uses synth_gain_<scale>.json, another seed its own synth_gain_<scale>_seed<k>.json where one was calibrated (scale s, seeds
+    1-3) and the seed-0 table otherwise (with it a different draw may drift: seed 1 at scale s saturates every class score)."""
     if isinstance(scale, str):
-        path = os.path.join(_DATA_DIR, f"synth_gain_{scale}.json")
-        if os.path.exists(path):
-            return json.load(open(path))
+        for name in ((f"synth_gain_{scale}_seed{seed}.json",) if seed else ()) + (f"synth_gain_{scale}.json",):
+            path = os.path.join(_DATA_DIR, name)
+            if os.path.exists(path):
+                return json.load(open(path))
     return {}
 
 
@@ -165,7 +168,7 @@ def synthetic_weights(scale: str | tuple = "s", nc: int = 1, seed: int = 0, gain
     occur."""
     rng = np.random.RandomState(seed)
     if gains is None:
-        gains = _stored_gains(scale)
+        gains = _stored_gains(scale, seed)
     out = {}
     for t in conv_table(scale, nc):
         fan_in = t["cin"] * t["k"] * t["k"]
