@@ -68,7 +68,14 @@ HBM_PEAK_GBPS = 8000.0
 # The second look's cost follows the NUMBER of weak frames (device-side dynamic batch, wtk_yolo_set_dynamic_batch), so K is only a ceiling.
 # Ceiling = the whole batch (K = B): NO weak row can be cut off, by construction (ADVICE r02 / VERDICT r02 item 4); the overflow counter of
 # wtk_recheck_select_counted is reported anyway and must read 0.
-HYBRID_MARGIN = 0.04
+# The margin is CALIBRATED on this model inside the run (HybridDetector.calibrate: 2 x the largest decision margin of any fp16 / f16x3 disagreement on
+# HYBRID_CAL_FRAMES frames the timed region and the parity leg never see; floor 0.02): the fp16 logit noise is a property of the weights — 0.019 at
+# most for the seed-0 draw used here, 0.10-0.15 for other draws (tests/test_gpu_hybrid_validation.py) — so a fixed number would be a guess.
+HYBRID_MARGIN_FALLBACK = 0.04
+HYBRID_CAL_FRAMES, HYBRID_CAL_SEED = 512, 40000
+# Deferred second look: the weak rows of HYBRID_DEFER consecutive batches of a lane share one f16x3 pass (its fixed cost of ~1.2 ms is paid once per
+# HYBRID_DEFER batches); queue of HYBRID_QUEUE rows per lane = 40 % of the frames it can receive — a fuller queue is COUNTED (overflow) and demotes the mode.
+HYBRID_DEFER, HYBRID_QUEUE_PER_64 = 5, 128
 PROFILE_ROUND = "r03"
 
 
@@ -125,7 +132,8 @@ class Workload:
         if dtype == "hybrid":  # fp16 on every frame + the K weakest decisions of each batch again in f16x3, merged on the device
             from wtracker_amd.hybrid import HybridDetector
 
-            self.dets = [HybridDetector(handle("fp16", args.batch), handle("f16x3", args.batch), margin=HYBRID_MARGIN, k=args.batch) for _ in range(lanes)]
+            q = max(args.batch * HYBRID_QUEUE_PER_64 // 64, 1) if args.defer > 1 else args.batch
+            self.dets = [HybridDetector(handle("fp16", args.batch), handle("f16x3", q), margin=args.hybrid_margin, k=q, defer=args.defer) for _ in range(lanes)]
         else:
             self.dets = [handle(dtype, args.batch) for _ in range(lanes)]
         self.mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=local_rank)
@@ -155,6 +163,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing (no roofline object)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision sub-object")
     ap.add_argument("--conf", type=float, default=0.1)
+    ap.add_argument("--defer", type=int, default=HYBRID_DEFER, help="hybrid: batches of a lane whose weak rows share one full-precision pass (1 = second look inside every step)")
+    ap.add_argument("--hybrid-margin", type=float, default=0.0, help="hybrid: decision-margin threshold; 0 = calibrate it on this model inside the run")
     ap.add_argument("--lanes", type=int, default=2, help="forward passes in flight per GPU (each lane = own workspace + HIP stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box, where every rank then shares cuda:0)")
@@ -334,6 +344,25 @@ def main():
 
     profile = not args.no_profile
     modes: dict = {}
+    calibration = None
+    if args.hybrid_margin <= 0.0:
+        if args.dtype in ("auto", "hybrid"):
+            from wtracker_amd.hybrid import HybridDetector
+
+            mkc = lambda dt: hip.HipYolo(weights, (args.size, args.size), 64, dtype=dt, nc=nc, width=width, depth=depth, max_channels=maxch, device=local_rank)
+            cal = HybridDetector(mkc("fp16"), mkc("f16x3"), margin=HYBRID_MARGIN_FALLBACK, k=64)
+            cal_frames = torch.from_numpy(fr.diverse_frames(HYBRID_CAL_FRAMES, args.size, seed=HYBRID_CAL_SEED + 1000 * rank)).to(dev)
+            calibration = cal.calibrate((cal_frames[i : i + 64] for i in range(0, len(cal_frames), 64)), args.size, args.size, 1, conf=args.conf)
+            calibration["frames_seed"] = HYBRID_CAL_SEED + 1000 * rank
+            args.hybrid_margin = calibration["margin"]
+            cal.close()
+            del cal_frames
+            if world > 1:  # every rank uses the widest margin any rank measured
+                t = torch.tensor([args.hybrid_margin], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                args.hybrid_margin = float(t.item())
+        else:
+            args.hybrid_margin = HYBRID_MARGIN_FALLBACK
     if world > 1 or args.dtype != "auto":
         head_dtype = "hybrid" if args.dtype == "auto" else args.dtype  # N > 1 has no CPU leg: hybrid's exactness is asserted at N = 1 and in tests/
         modes[head_dtype] = measure(head_dtype, args.lanes, args.repeats, profile)
@@ -365,7 +394,7 @@ def main():
             par[dtype] = metrics.accuracy_report(xg, ag, xo, ao, cg, co)
         from wtracker_amd.hybrid import HybridDetector
 
-        hyb = HybridDetector(mk("fp16", 64), mk("f16x3", 64), margin=HYBRID_MARGIN, k=64)
+        hyb = HybridDetector(mk("fp16", 64), mk("f16x3", 64), margin=args.hybrid_margin, k=64)
         sdev = torch.from_numpy(sample).to(dev)
         ox, oc, oa = (torch.empty((n, 4), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
                       torch.empty((n,), dtype=torch.int32, device=dev))
@@ -433,11 +462,15 @@ def main():
     if "hybrid" in modes:
         out["hybrid_overflow"] = modes["hybrid"]["second_look"]["overflow_rows"] + (par["hybrid"]["overflow_rows"] if par and "hybrid" in par else 0)
         out["hybrid_second_look_share"] = modes["hybrid"]["second_look"]["share"]
-        out["hybrid_margin"] = HYBRID_MARGIN
+        out["hybrid_margin"] = args.hybrid_margin
+        out["hybrid_defer"] = args.defer
+        if calibration is not None:
+            out["hybrid_calibration"] = calibration
     notes = {
         "fp16": "plain fp16 mode (throughput only): its survivor differs from the fp32 restatement's on ~2 % of the frames, so it is not the headline",
-        "hybrid": (f"wtracker_amd.hybrid.HybridDetector: fp16 on every frame, then EVERY frame whose decision margin is below {HYBRID_MARGIN} again through an f16x3 handle "
-                   "(ceiling = the whole batch, device-side dynamic batch: the cost follows the number of weak frames) and merged on the device; fixed launch sequence, no host round trip"),
+        "hybrid": (f"wtracker_amd.hybrid.HybridDetector: fp16 on every frame, then EVERY frame whose decision margin is below {args.hybrid_margin:.4f} (calibrated on this model in this "
+                   f"run) again through an f16x3 handle — the weak rows of {args.defer} batches of a lane share one pass (device-side queue, dynamic batch: the cost follows the "
+                   "number of weak frames), rows written back on the device; fixed launch sequence, no host round trip; overflow of the queue is counted and must be 0"),
         "f16x3": ("split-fp16 storage and three v_mfma_f32_16x16x32_f16 per product: every conv tensor within 4e-6 of the exact-fp32 "
                   "mode's (tests/test_gpu_f16x3.py), survivor indices equal the fp32 restatement's; roofline peak = fp16 peak / 3"),
         "fp32": "reference precision (ultralytics half: False): exact-fp32 v_mfma_f32_16x16x4_f32 through the same kernels",

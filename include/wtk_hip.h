@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WTK_ABI_VERSION 4 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted (additive: every earlier entry point is unchanged) */
+#define WTK_ABI_VERSION 5 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted; 5: + wtk_recheck_enqueue / _scatter (additive: every earlier entry point is unchanged) */
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
@@ -278,6 +278,24 @@ int wtk_release_cached_memory(void);
 int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin,
                       const float *src_xywh, const float *src_conf, const int32_t *src_anchor, float *dst_xywh,
                       float *dst_conf, int32_t *dst_anchor, int32_t *n_replaced_dev, void *stream);
+/* Deferred form of the same second look: the weak rows of SEVERAL fast passes share ONE full-precision pass, whose fixed cost
+ * (a forward pass of ~60 launches costs ~1.2 ms however few frames are live) is then paid once per D batches.
+ *   wtk_recheck_enqueue  every row of the batch with margin < `margin` is appended to a device-side queue: a copy of its frame
+ *                        (frames_dev [B][frame_bytes] -> q_frames_dev [q_cap][frame_bytes]) and the addresses of its three
+ *                        outputs (dst_xywh + 4 b, dst_conf + b, dst_anchor + b; the last two nullable).  *q_len += rows queued;
+ *                        rows that find the queue full keep their fast result and are COUNTED in *n_overflow (nullable) — a
+ *                        caller that flushes every D batches with q_cap >= D * B can never overflow.
+ *   (the caller then runs a full-precision handle over q_frames_dev with wtk_yolo_set_dynamic_batch(h, q_len_dev))
+ *   wtk_recheck_scatter  rows 0 .. *q_len - 1 of src_* go to the queued addresses; *n_replaced += count; *q_len = 0.
+ * The output rows named at enqueue time must stay valid until the scatter.  pos_scratch_dev: int32 [B].
+ * Replaces nothing in the reference (yolo_controller.py:62-90 computes every frame in fp32). */
+int wtk_recheck_enqueue(const float *margins_dev, int32_t B, float margin, const uint8_t *frames_dev, int64_t frame_bytes,
+                        uint8_t *q_frames_dev, int32_t q_cap, int32_t *q_len_dev, void **q_xywh_ptrs_dev,
+                        void **q_conf_ptrs_dev, void **q_anchor_ptrs_dev, float *dst_xywh, float *dst_conf,
+                        int32_t *dst_anchor, int32_t *pos_scratch_dev, int32_t *n_overflow_dev, void *stream);
+int wtk_recheck_scatter(int32_t *q_len_dev, int32_t q_cap, const float *src_xywh, const float *src_conf,
+                        const int32_t *src_anchor, void **q_xywh_ptrs_dev, void **q_conf_ptrs_dev,
+                        void **q_anchor_ptrs_dev, int32_t *n_replaced_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Detector on camera views of device-resident full frames: view cropping fused with the letterbox in front of

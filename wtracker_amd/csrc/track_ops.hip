@@ -236,7 +236,76 @@ __global__ __launch_bounds__(64) void recheck_merge_kernel(const RecheckArgs a) 
     if (a.n_replaced) atomicAdd(a.n_replaced, 1);
 }
 
+// ---- deferred second look: queue of weak rows over several fast passes
+// one block: queue position of every weak row of the batch (row order), the addresses its re-detected row will be written to, the new length
+__global__ __launch_bounds__(256) void recheck_enqueue_plan_kernel(const RecheckQueueArgs a) {
+    __shared__ int weak[1024];
+    __shared__ int total;
+    const int len0 = *a.q_len;
+    for (int i = threadIdx.x; i < a.B; i += 256) {
+        const float v = a.margins[i];
+        weak[i] = (v == v && v < a.thr) ? 1 : 0; // NaN margin = no decision to revisit
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.B; i += 256) {
+        int before = 0;
+        for (int j = 0; j < i; ++j) before += weak[j];
+        int p = -1;
+        if (weak[i] && len0 + before < a.q_cap) {
+            p = len0 + before;
+            a.q_xywh[p] = a.dst_xywh + 4 * (long long)i;
+            a.q_conf[p] = a.dst_conf ? a.dst_conf + i : nullptr;
+            a.q_anchor[p] = a.dst_anchor ? a.dst_anchor + i : nullptr;
+        }
+        a.pos[i] = p;
+        if (i == a.B - 1) total = before + weak[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int fit = min(total, a.q_cap - len0);
+        *a.q_len = len0 + fit;
+        if (a.n_overflow && total > fit) *a.n_overflow += total - fit;
+    }
+}
+
+// blockIdx.y = batch row; its frame goes to its queue slot, 16 bytes per thread and step (rows that are not queued exit at once)
+__global__ __launch_bounds__(256) void recheck_enqueue_copy_kernel(const RecheckQueueArgs a) {
+    const int b = blockIdx.y;
+    const int p = a.pos[b];
+    if (p < 0) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.frames + (long long)b * a.frame_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(a.q_frames + (long long)p * a.frame_bytes);
+    const long long n16 = a.frame_bytes / 16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(64) void recheck_scatter_kernel(const RecheckQueueArgs a) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= *a.q_len || k >= a.q_cap) return;
+    *reinterpret_cast<float4 *>(a.q_xywh[k]) = reinterpret_cast<const float4 *>(a.src_xywh)[k];
+    if (a.q_conf[k] && a.src_conf) *a.q_conf[k] = a.src_conf[k];
+    if (a.q_anchor[k] && a.src_anchor) *a.q_anchor[k] = a.src_anchor[k];
+    if (a.n_replaced) atomicAdd(a.n_replaced, 1);
+}
+
 } // namespace
+
+hipError_t launch_recheck_enqueue(const RecheckQueueArgs &a, hipStream_t stream) {
+    if (a.B <= 0 || a.B > 1024 || a.q_cap <= 0 || a.frame_bytes <= 0 || a.frame_bytes % 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recheck_enqueue_plan_kernel, dim3(1), dim3(256), 0, stream, a);
+    const long long n16 = a.frame_bytes / 16;
+    const unsigned bx = (unsigned)((n16 + 256 * 8 - 1) / (256 * 8) > 64 ? 64 : (n16 + 256 * 8 - 1) / (256 * 8)); // <= 64 blocks per frame, >= 8 steps each
+    hipLaunchKernelGGL(recheck_enqueue_copy_kernel, dim3(bx ? bx : 1, (unsigned)a.B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_recheck_scatter(const RecheckQueueArgs &a, hipStream_t stream) {
+    if (a.q_cap <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recheck_scatter_kernel, dim3((unsigned)((a.q_cap + 63) / 64)), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(a.q_len, 0, sizeof(int), stream); // the queue is empty again (stream order: after the scatter)
+}
 
 hipError_t launch_recheck_select(const RecheckArgs &a, hipStream_t stream) {
     if (a.B <= 0 || a.B > 1024 || a.K <= 0 || a.K > a.B) return hipErrorInvalidValue;

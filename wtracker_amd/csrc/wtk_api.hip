@@ -331,6 +331,38 @@ extern "C" int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_
     return 0;
 }
 
+extern "C" int wtk_recheck_enqueue(const float *margins_dev, int32_t B, float margin, const uint8_t *frames_dev, int64_t frame_bytes, uint8_t *q_frames_dev,
+                                   int32_t q_cap, int32_t *q_len_dev, void **q_xywh_ptrs_dev, void **q_conf_ptrs_dev, void **q_anchor_ptrs_dev, float *dst_xywh,
+                                   float *dst_conf, int32_t *dst_anchor, int32_t *pos_scratch_dev, int32_t *n_overflow_dev, void *stream) {
+    if (!margins_dev || !frames_dev || !q_frames_dev || !q_len_dev || !q_xywh_ptrs_dev || !q_conf_ptrs_dev || !q_anchor_ptrs_dev || !dst_xywh || !pos_scratch_dev)
+        return fail("wtk_recheck_enqueue: null argument");
+    if (B <= 0 || B > 1024 || q_cap <= 0) return fail("wtk_recheck_enqueue: need 1 <= B <= 1024 and a queue of at least one row");
+    if (frame_bytes <= 0 || frame_bytes % 16 || reinterpret_cast<uintptr_t>(frames_dev) % 16 || reinterpret_cast<uintptr_t>(q_frames_dev) % 16)
+        return fail("wtk_recheck_enqueue: frames must be 16-byte aligned and a multiple of 16 bytes each");
+    if (reinterpret_cast<uintptr_t>(dst_xywh) % 16) return fail("wtk_recheck_enqueue: xywh rows must be 16-byte aligned");
+    RecheckQueueArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.margins = margins_dev, a.B = B, a.thr = margin, a.frames = frames_dev, a.frame_bytes = frame_bytes, a.q_frames = q_frames_dev, a.q_cap = q_cap, a.q_len = q_len_dev;
+    a.q_xywh = reinterpret_cast<float **>(q_xywh_ptrs_dev), a.q_conf = reinterpret_cast<float **>(q_conf_ptrs_dev), a.q_anchor = reinterpret_cast<int **>(q_anchor_ptrs_dev);
+    a.dst_xywh = dst_xywh, a.dst_conf = dst_conf, a.dst_anchor = dst_anchor, a.pos = pos_scratch_dev, a.n_overflow = n_overflow_dev;
+    HIP_TRY(launch_recheck_enqueue(a, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int wtk_recheck_scatter(int32_t *q_len_dev, int32_t q_cap, const float *src_xywh, const float *src_conf, const int32_t *src_anchor, void **q_xywh_ptrs_dev,
+                                   void **q_conf_ptrs_dev, void **q_anchor_ptrs_dev, int32_t *n_replaced_dev, void *stream) {
+    if (!q_len_dev || !src_xywh || !q_xywh_ptrs_dev || !q_conf_ptrs_dev || !q_anchor_ptrs_dev) return fail("wtk_recheck_scatter: null argument");
+    if (q_cap <= 0) return fail("wtk_recheck_scatter: empty queue capacity");
+    if (reinterpret_cast<uintptr_t>(src_xywh) % 16) return fail("wtk_recheck_scatter: xywh rows must be 16-byte aligned");
+    RecheckQueueArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.q_len = q_len_dev, a.q_cap = q_cap, a.src_xywh = src_xywh, a.src_conf = src_conf, a.src_anchor = src_anchor;
+    a.q_xywh = reinterpret_cast<float **>(q_xywh_ptrs_dev), a.q_conf = reinterpret_cast<float **>(q_conf_ptrs_dev), a.q_anchor = reinterpret_cast<int **>(q_anchor_ptrs_dev);
+    a.n_replaced = n_replaced_dev;
+    HIP_TRY(launch_recheck_scatter(a, (hipStream_t)stream));
+    return 0;
+}
+
 // =============================================================================================
 // View extraction
 // =============================================================================================

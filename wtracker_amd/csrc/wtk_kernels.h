@@ -509,4 +509,30 @@ struct RecheckArgs {
 hipError_t launch_recheck_select(const RecheckArgs &a, hipStream_t stream);
 hipError_t launch_recheck_merge(const RecheckArgs &a, hipStream_t stream);
 
+// Deferred second look (wtk_recheck_enqueue / wtk_recheck_scatter): the weak rows of SEVERAL fast passes are collected in a device-side
+// queue — a copy of the frame plus the addresses of the row's three outputs — and looked at again in ONE full-precision pass, so the fixed
+// cost of that pass (62 launches of a few tiles each: ~1.2 ms however few frames are live) is paid once per D batches instead of once per batch.
+struct RecheckQueueArgs {
+    const float *margins;       // [B] decision margins of the fast pass
+    int B;
+    float thr;                  // rows with margin < thr are queued
+    const unsigned char *frames; // [B][frame_bytes] the fast pass's input batch
+    long long frame_bytes;      // multiple of 16
+    unsigned char *q_frames;    // [q_cap][frame_bytes]
+    int q_cap;
+    int *q_len;                 // rows queued so far (device counter)
+    float **q_xywh, **q_conf;   // [q_cap] where the re-detected row goes (q_conf / q_anchor entries may be null)
+    int **q_anchor;
+    float *dst_xywh, *dst_conf; // this batch's output rows: row b at dst_xywh + 4 b, dst_conf + b, dst_anchor + b
+    int *dst_anchor;
+    int *pos;                   // [B] scratch: queue position of batch row b, or -1
+    int *n_overflow;            // nullable: += weak rows that found the queue full (they keep their fast result)
+    // scatter
+    const float *src_xywh, *src_conf; // [q_cap] rows of the full-precision pass over q_frames
+    const int *src_anchor;
+    int *n_replaced;            // nullable: += rows written back
+};
+hipError_t launch_recheck_enqueue(const RecheckQueueArgs &a, hipStream_t stream);
+hipError_t launch_recheck_scatter(const RecheckQueueArgs &a, hipStream_t stream);
+
 } // namespace wtk

@@ -58,7 +58,7 @@ SYMBOLS = [
     "wtk_comm_unique_id", "wtk_comm_create", "wtk_comm_destroy", "wtk_allgather_tracks",
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
     "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch", "wtk_yolo_set_side_streams",
-    "wtk_release_cached_memory", "wtk_recheck_select_counted",
+    "wtk_release_cached_memory", "wtk_recheck_select_counted", "wtk_recheck_enqueue", "wtk_recheck_scatter",
 ]
 
 
@@ -145,6 +145,8 @@ def load() -> C.CDLL:
     lib.wtk_yolo_last_margins_host.argtypes = [vp, i32, vp]
     lib.wtk_recheck_select.argtypes = [vp, i32, i32, f32, vp, vp, vp]
     lib.wtk_recheck_select_counted.argtypes = [vp, i32, i32, f32, vp, vp, vp, vp]
+    lib.wtk_recheck_enqueue.argtypes = [vp, i32, f32, vp, C.c_int64, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.wtk_recheck_scatter.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.wtk_yolo_set_dynamic_batch.argtypes = [vp, vp]
     lib.wtk_yolo_set_side_streams.argtypes = [vp, i32]
     lib.wtk_recheck_merge.argtypes = [vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -201,6 +203,20 @@ def recheck_select(margins_dev, B: int, K: int, margin: float, slots_dev, n_weak
     n_overflow += the weak rows beyond the ceiling K (they get no second look); asynchronous on `stream`."""
     _check(load().wtk_recheck_select_counted(_ptr(margins_dev), B, K, margin, _ptr(slots_dev), _ptr(n_weak_dev), _ptr(n_overflow_dev), C.c_void_p(stream)),
            "wtk_recheck_select_counted")
+
+
+def recheck_enqueue(margins_dev, B: int, margin: float, frames_dev, frame_bytes: int, q_frames_dev, q_cap: int, q_len_dev, q_xywh_ptrs, q_conf_ptrs, q_anchor_ptrs,
+                    dst_xywh, dst_conf, dst_anchor, pos_scratch_dev, n_overflow_dev=None, stream: int = 0):
+    """Append the batch rows with margin < `margin` (frame copy + output addresses) to the device-side queue of the deferred second look."""
+    _check(load().wtk_recheck_enqueue(_ptr(margins_dev), B, margin, _ptr(frames_dev), frame_bytes, _ptr(q_frames_dev), q_cap, _ptr(q_len_dev), _ptr(q_xywh_ptrs),
+                                      _ptr(q_conf_ptrs), _ptr(q_anchor_ptrs), _ptr(dst_xywh), _ptr(dst_conf), _ptr(dst_anchor), _ptr(pos_scratch_dev),
+                                      _ptr(n_overflow_dev), C.c_void_p(stream)), "wtk_recheck_enqueue")
+
+
+def recheck_scatter(q_len_dev, q_cap: int, src_xywh, src_conf, src_anchor, q_xywh_ptrs, q_conf_ptrs, q_anchor_ptrs, n_replaced_dev=None, stream: int = 0):
+    """Rows 0 .. *q_len - 1 of the full-precision pass go to the addresses queued by recheck_enqueue; the queue is empty afterwards."""
+    _check(load().wtk_recheck_scatter(_ptr(q_len_dev), q_cap, _ptr(src_xywh), _ptr(src_conf), _ptr(src_anchor), _ptr(q_xywh_ptrs), _ptr(q_conf_ptrs),
+                                      _ptr(q_anchor_ptrs), _ptr(n_replaced_dev), C.c_void_p(stream)), "wtk_recheck_scatter")
 
 
 def recheck_merge(margins_dev, slots_dev, B: int, K: int, margin: float, src_xywh, src_conf, src_anchor, dst_xywh, dst_conf=None, dst_anchor=None,

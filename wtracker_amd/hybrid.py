@@ -16,6 +16,14 @@ still follows the number of weak rows.  A caller that passes a smaller K trades 
 fp16 result, and `overflow` (device counter, `overflow_count()` on the host) says how many did — it must read 0 for the
 "full-precision decisions" claim to hold on that run.
 
+How wide must `margin` be?  At least twice the fp16 logit noise of the MODEL AT HAND — and that noise is a property of the weights: with
+the synthetic weight draw bench.py uses (seed 0) no fp16 survivor mismatch in thousands of frames has a margin above 0.019, with other
+draws (seeds 2 and 3) mismatches reach margins of 0.10-0.15 (tests/test_gpu_hybrid_validation.py, profiles/r03_hybrid_validation.json).
+A fixed number is therefore NOT a guarantee.  `calibrate()` measures the largest margin of any fp16 / full-precision disagreement on
+frames of the caller's choosing and sets margin = safety x that (default 2 x, floor 0.02); the procedure is validated out of sample
+(calibration frames and validation frames disjoint) on four weight draws in the tests.  Where the calibrated margin makes most frames
+weak, the hybrid is slower than the full-precision mode alone and "f16x3" is the mode to use — bench.py reports both.
+
 It has the detector interface TrackPipeline uses (predict / predict_views / device / max_batch), so `dets=[HybridDetector(...)]`
 turns the open-loop pipeline into the hybrid mode.  torch: device memory only.
 """
@@ -27,11 +35,14 @@ from . import hip
 
 
 class HybridDetector:
-    def __init__(self, fast: hip.HipYolo, exact: hip.HipYolo, margin: float = 0.04, k: int | None = None):
+    def __init__(self, fast: hip.HipYolo, exact: hip.HipYolo, margin: float = 0.04, k: int | None = None, defer: int = 1):
         if fast.device != exact.device:
             raise hip.WtkError("HybridDetector: both handles must live on the same device")
+        if defer < 1:
+            raise hip.WtkError("HybridDetector: defer >= 1")
+        self.defer = int(defer)
         if k is None:
-            k = min(fast.max_batch, exact.max_batch)
+            k = exact.max_batch if defer > 1 else min(fast.max_batch, exact.max_batch)
         if k < 1 or k > exact.max_batch:
             raise hip.WtkError("HybridDetector: 1 <= k <= max_batch of the full-precision handle")
         self.fast, self.exact, self.margin, self.k = fast, exact, float(margin), int(k)
@@ -43,13 +54,27 @@ class HybridDetector:
         self._xywh = torch.empty((self.k, 4), dtype=torch.float32, device=dev)
         self._conf = torch.empty((self.k,), dtype=torch.float32, device=dev)
         self._anchor = torch.empty((self.k,), dtype=torch.int32, device=dev)
-        self._pos = None  # view centre that makes a "view" the whole frame, per frame shape
+        self._pos = None  # view centre that makes a "view" the whole frame, per frame shape (defer = 1) / enqueue scratch (defer > 1)
         self._idx_tmp = torch.empty((self.k,), dtype=torch.int32, device=dev)
         self._pos_tmp = torch.empty((self.k, 2), dtype=torch.int32, device=dev)
         self.replaced = torch.zeros((1,), dtype=torch.int32, device=dev)  # rows replaced so far (device counter)
         self._n_weak = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows of the current batch: the second look's dynamic batch size
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows so far that the ceiling k cut off (0 by construction when k >= B)
         exact.set_dynamic_batch(self._n_weak)
+        # ---- deferred mode (defer = D > 1): the weak rows of D consecutive calls share ONE full-precision pass (wtk_recheck_enqueue /
+        # wtk_recheck_scatter): `_n_weak` is then the length of a device-side queue of frame copies + output-row addresses.  The pass has a
+        # fixed cost of ~1.2 ms however few frames are live (62 launches of a few tiles each); per call that is 1.2 ms / D instead of 1.2 ms.
+        # With k >= D x (fast batch) no weak row can find the queue full.  A smaller queue (the full-precision pass launches its grids for k frames
+        # and the blocks of slots beyond the queue's length exit at once, ~5 us per unused slot: k should not be much larger than what is
+        # expected) COUNTS what it has to drop (`overflow`): such rows keep their fp16 result, and a caller that promises full-precision
+        # decisions must check the counter (bench.py does, and demotes the mode if it is not 0).
+        # Rows named in a call are FINAL only after the flush that follows (every D-th call, or flush()): `pending` says how many calls wait.
+        self._calls = 0
+        self._q_frames = None
+        self._q_shape = None
+        if self.defer > 1:
+            self._q_ptrs = [torch.zeros((self.k,), dtype=torch.int64, device=dev) for _ in range(3)]
+            self._pos = torch.empty((max(fast.max_batch, 1),), dtype=torch.int32, device=dev)
         # (the second look keeps the default concurrency: with ONE pair of side streams per process, shared by every handle, its towers cost no
         # extra streams — 17.7 k frames/s against 17.1 k with wtk_yolo_set_side_streams(0); with a pair per handle it was the other way round)
 
@@ -59,6 +84,21 @@ class HybridDetector:
         if max_det != 1:
             raise hip.WtkError("HybridDetector: max_det must be 1")
         self.fast.predict(frames_dev, B, H, W, Cc, out_xywh, out_conf, out_anchor, conf=conf, iou=iou, max_det=1, stream=stream)
+        if self.defer > 1:
+            if self._q_frames is None:
+                self._q_shape = (H, W, Cc)
+                self._q_frames = torch.empty((self.k, H, W, Cc), dtype=torch.uint8, device=self._slots.device)
+            elif self._q_shape != (H, W, Cc):
+                raise hip.WtkError("HybridDetector(defer > 1): every call must bring frames of the same shape")
+            if (H * W * Cc) % 16:
+                raise hip.WtkError("HybridDetector(defer > 1): frames must be a multiple of 16 bytes")
+            hip.recheck_enqueue(self.fast.margin_buffer(), B, self.margin, frames_dev, H * W * Cc, self._q_frames, self.k, self._n_weak, *self._q_ptrs,
+                                out_xywh, out_conf, out_anchor, self._pos, self.overflow, stream=stream)
+            self._calls += 1
+            self._conf_thr = conf
+            if self._calls % self.defer == 0:
+                self.flush(stream)
+            return
         k = min(self.k, B)
         m = self.fast.margin_buffer()
         hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream, n_overflow_dev=self.overflow)
@@ -71,10 +111,26 @@ class HybridDetector:
                                  max_det=1, stream=stream)
         hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
 
+    @property
+    def pending(self) -> int:
+        """Calls whose weak rows still wait for their full-precision pass (deferred mode; 0 = every row handed out so far is final)."""
+        return self._calls if self.defer > 1 else 0
+
+    def flush(self, stream: int = 0):
+        """Deferred mode: look again at everything queued so far and write the rows back (enqueued on `stream`, no host synchronisation)."""
+        if self.defer <= 1 or self._q_frames is None or self._calls == 0:
+            return
+        H, W, Cc = self._q_shape
+        self.exact.predict(self._q_frames, self.k, H, W, Cc, self._xywh, self._conf, self._anchor, conf=getattr(self, "_conf_thr", 0.1), max_det=1, stream=stream)
+        hip.recheck_scatter(self._n_weak, self.k, self._xywh, self._conf, self._anchor, *self._q_ptrs, self.replaced, stream=stream)
+        self._calls = 0
+
     def predict_views(self, frames_dev, n_frames: int, H: int, W: int, Cc: int, frame_index_dev, pos_xy_dev, B: int, view_w: int, view_h: int,
                       out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1, iou: float = 0.7, max_det: int = 1, stream: int = 0):
         if max_det != 1:
             raise hip.WtkError("HybridDetector: max_det must be 1")
+        if self.defer > 1:
+            raise hip.WtkError("HybridDetector(defer > 1): the views entry point has no deferred form (use defer = 1)")
         self.fast.predict_views(frames_dev, n_frames, H, W, Cc, frame_index_dev, pos_xy_dev, B, view_w, view_h, out_xywh, out_conf, out_anchor, conf=conf,
                                 iou=iou, max_det=1, stream=stream)
         k = min(self.k, B)
@@ -90,6 +146,38 @@ class HybridDetector:
         self.exact.predict_views(frames_dev, n_frames, H, W, Cc, self._idx_tmp, self._pos_tmp, k, view_w, view_h, self._xywh, self._conf, self._anchor,
                                  conf=conf, iou=iou, max_det=1, stream=stream)
         hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
+
+    def calibrate(self, batches, H: int, W: int, Cc: int = 1, conf: float = 0.1, safety: float = 2.0, floor: float = 0.02) -> dict:
+        """Set `margin` from measurements on THIS model: every batch of `batches` (device uint8 tensors [B, H, W(, C)], B <= max_batch of both
+        handles) goes through the fast and through the full-precision handle; margin = max(floor, safety x the largest fast-pass decision
+        margin of any frame on which the two disagree about the survivor).  Returns what was measured.  Synchronises; not for timed regions."""
+        if self.exact.max_batch < self.fast.max_batch:
+            raise hip.WtkError("calibrate: the full-precision handle must take whole batches (max_batch >= the fast handle's)")
+        import numpy as np
+
+        self.exact.set_dynamic_batch(None)
+        dev = torch.device("cuda", self.device)
+        worst, n_frames, n_bad, margins_bad = 0.0, 0, 0, []
+        try:
+            for fb in batches:
+                B = int(fb.shape[0])
+                o = [(torch.empty((B, 4), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.float32, device=dev),
+                      torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(2)]
+                self.fast.predict(fb, B, H, W, Cc, *o[0], conf=conf)
+                self.exact.predict(fb, B, H, W, Cc, *o[1], conf=conf)
+                torch.cuda.synchronize(dev)
+                m = self.fast.last_margins(B)
+                bad = (o[0][2] != o[1][2]).cpu().numpy()
+                n_frames += B
+                n_bad += int(bad.sum())
+                if bad.any():
+                    margins_bad.extend(float(v) for v in m[bad])
+                    worst = max(worst, float(np.nanmax(m[bad])))
+        finally:
+            self.exact.set_dynamic_batch(self._n_weak)
+        self.margin = max(float(floor), float(safety) * worst)
+        return {"frames": n_frames, "fast_mismatches": n_bad, "largest_mismatch_margin": worst, "safety": safety, "floor": floor, "margin": self.margin,
+                "mismatch_margins_sorted_desc": sorted(margins_bad, reverse=True)[:8]}
 
     def overflow_count(self) -> int:
         """Weak rows (margin below the threshold) that kept their fp16 result because more than k rows of a batch were weak.  Synchronises."""

@@ -93,17 +93,62 @@ class TrackPipeline:
         if streams is not None and len(streams) != n_lanes:
             raise ValueError("one stream per lane")
         self.streams = list(streams) if streams is not None else ([torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 else [None])
-        self.det_done = [torch.cuda.Event() for _ in range(n_lanes)]
+        # A lane whose detector holds rows back (HybridDetector(defer = D): the weak rows of D calls share one full-precision pass) hands out
+        # rows that are FINAL only after its next flush.  Everything downstream of the rows — the exchange between ranks and the ResMLP —
+        # runs when a lane's rows become final, for every step that is final on ALL lanes by then; a detector without `defer` is final at
+        # once and the schedule is the plain one (detect, exchange, predict, per step).
+        self._ring = [max(int(getattr(d, "defer", 1)), 1) for d in self.dets]
+        self.final_ev = [torch.cuda.Event() for _ in range(n_lanes)]
+        self.det_done = self.final_ev  # (older name)
         # device-resident track of the whole run: xywh per frame (NaN = no detection yet / none found)
         self.track = torch.full((total_frames, 4), float("nan"), dtype=torch.float32, device=self.device)
-        self.local_xywh = [torch.empty((batch, 4), dtype=torch.float32, device=self.device) for _ in range(n_lanes)]
-        self.local_conf = [torch.empty((batch,), dtype=torch.float32, device=self.device) for _ in range(n_lanes)]
-        self.local_anchor = [torch.empty((batch,), dtype=torch.int32, device=self.device) for _ in range(n_lanes)]
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)
+        self.local_xywh = [[mk((batch, 4), torch.float32) for _ in range(r)] for r in self._ring]  # one set per step a lane may hold back
+        self.local_conf = [[mk((batch,), torch.float32) for _ in range(r)] for r in self._ring]
+        self.local_anchor = [[mk((batch,), torch.int32) for _ in range(r)] for r in self._ring]
         n = max(len(self.plan.anchors), 1)
         self.anchors = torch.from_numpy(self.plan.anchors).to(self.device)
         self.moves = torch.zeros((n, 2), dtype=torch.float32, device=self.device)  # raw ResMLP (dx, dy) per cycle
         self.valid = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self._steps_done = 0
+        self._calls = [0] * n_lanes            # detector calls per lane (ring position)
+        self._held = [[] for _ in range(n_lanes)]  # (step, ring slot) of a lane's steps whose rows are not final yet
+        self._ready = {}                       # step -> lane: rows final, ResMLP of its cycles not enqueued yet
+
+    def _finalize_lane(self, lane: int) -> int:
+        """The rows of every step this lane holds are final in the order of the current stream (= the lane's): exchange them between the
+        ranks, then run the ResMLP for the cycles of every step that is now final on all lanes.  Returns the cycles launched."""
+        cur = torch.cuda.current_stream(self.device)
+        st = cur.cuda_stream
+        for t, k in self._held[lane]:
+            if self.world > 1:
+                exchange_tracks(self.track, self.local_xywh[lane][k], self.plan, t, self.group, self.comm, st)
+            self._ready[t] = lane
+        self._held[lane] = []
+        self.final_ev[lane].record(cur)
+        # A final step can be processed once no lane still holds an earlier step back (the ResMLP of step t looks back into step t - 1);
+        # steps that were never enqueued are gaps, not obstacles (their rows stay NaN and the cycles that need them come out invalid).
+        first_held = min((t for h in self._held for t, _ in h), default=None)
+        todo = sorted(t for t in self._ready if first_held is None or t < first_held)
+        if not todo:
+            return 0
+        for other in range(len(self.dets)):  # the look-back of these steps reaches into rows that other lanes finalised on their own streams
+            if other != lane and self._calls[other] > 0:
+                cur.wait_event(self.final_ev[other])
+        n, i = 0, 0
+        while i < len(todo):  # one launch per run of consecutive steps (their cycles are contiguous)
+            j = i
+            while j + 1 < len(todo) and todo[j + 1] == todo[j] + 1:
+                j += 1
+            lo, hi = self.plan.cycles(todo[i])[0], self.plan.cycles(todo[j])[1]
+            if hi > lo:
+                self.mlp.predict_track(self.track, self.plan.total_frames, self.anchors[lo:hi], hi - lo, self.folded.input_frames,
+                                       self.moves[lo:hi], self.valid[lo:hi], stream=st)
+                n += hi - lo
+            i = j + 1
+        for t in todo:
+            del self._ready[t]
+        return n
 
     def _step_on_current_stream(self, s: int, lane: int, frames_dev: torch.Tensor, views=None) -> int:
         H, W = frames_dev.shape[1], frames_dev.shape[2]
@@ -111,27 +156,24 @@ class TrackPipeline:
         det = self.dets[lane]
         st = torch.cuda.current_stream(self.device).cuda_stream
         f0, f1 = self.plan.local_range(s, 0)
-        out = self.track[f0:f1] if self.world == 1 else self.local_xywh[lane]  # one rank: straight into the track
+        k = self._calls[lane] % self._ring[lane]
+        self._calls[lane] += 1
+        out = self.track[f0:f1] if self.world == 1 else self.local_xywh[lane][k]  # one rank: straight into the track
         if views is None:
-            det.predict(frames_dev, frames_dev.shape[0], H, W, C, out, self.local_conf[lane], self.local_anchor[lane], conf=self.conf, stream=st)
+            det.predict(frames_dev, frames_dev.shape[0], H, W, C, out, self.local_conf[lane][k], self.local_anchor[lane][k], conf=self.conf, stream=st)
         else:  # camera views of full frames: crop + letterbox on the device in front of the detector
             frame_index, pos_xy, (vw, vh) = views
-            det.predict_views(frames_dev, frames_dev.shape[0], H, W, C, frame_index, pos_xy, self.plan.B, vw, vh, out, self.local_conf[lane],
-                              self.local_anchor[lane], conf=self.conf, stream=st)
-        if self.world > 1:
-            exchange_tracks(self.track, self.local_xywh[lane], self.plan, s, self.group, self.comm, st)
-        self.det_done[lane].record(torch.cuda.current_stream(self.device))
-        lo, hi = self.plan.cycles(s)
-        if hi > lo:
-            if len(self.dets) > 1 and self._steps_done > 0:  # rows of the previous super-batch come from the other lane
-                torch.cuda.current_stream(self.device).wait_event(self.det_done[(lane + len(self.dets) - 1) % len(self.dets)])
-            self.mlp.predict_track(self.track, self.plan.total_frames, self.anchors[lo:hi], hi - lo, self.folded.input_frames,
-                                   self.moves[lo:hi], self.valid[lo:hi], stream=st)
+            det.predict_views(frames_dev, frames_dev.shape[0], H, W, C, frame_index, pos_xy, self.plan.B, vw, vh, out, self.local_conf[lane][k],
+                              self.local_anchor[lane][k], conf=self.conf, stream=st)
+        self._held[lane].append((s, k))
         self._steps_done += 1
-        return hi - lo
+        if getattr(det, "pending", 0) == 0:
+            return self._finalize_lane(lane)
+        return 0
 
     def step(self, s: int, frames_dev: torch.Tensor, views=None) -> int:
-        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles.
+        """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles (at once, or — with a detector that holds
+        rows back — when the rows become final: flush() / synchronize() make everything final).
         `views` = (frame_index [B] int32 or None, pos_xy [B,2] int32, (view_w, view_h)): `frames_dev` then holds FULL frames
         and the batch rows are their camera views (device crop + letterbox)."""
         lane = s % len(self.dets)
@@ -141,6 +183,25 @@ class TrackPipeline:
         stream.wait_stream(torch.cuda.current_stream(self.device))  # inputs produced on the caller's stream
         with torch.cuda.stream(stream):
             return self._step_on_current_stream(s, lane, frames_dev, views)
+
+    def flush(self) -> int:
+        """Make every row handed out so far final (detectors that hold rows back look again at what they queued) and run what waited for
+        them.  Enqueues work on the lanes' streams; no host synchronisation."""
+        n = 0
+        for lane, det in enumerate(self.dets):
+            if not self._held[lane]:
+                continue
+            stream = self.streams[lane]
+            if stream is None:
+                if getattr(det, "pending", 0):
+                    det.flush(torch.cuda.current_stream(self.device).cuda_stream)
+                n += self._finalize_lane(lane)
+            else:
+                with torch.cuda.stream(stream):
+                    if getattr(det, "pending", 0):
+                        det.flush(stream.cuda_stream)
+                    n += self._finalize_lane(lane)
+        return n
 
     def baseline_targets(self, sample_times=None, weights=None, degree: int = 2):
         """The other two predictors of the reference over the finished device track, every cycle in one launch each and no
@@ -168,6 +229,7 @@ class TrackPipeline:
         return out
 
     def synchronize(self):
+        self.flush()
         for st in self.streams:
             if st is not None:
                 st.synchronize()
