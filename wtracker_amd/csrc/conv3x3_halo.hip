@@ -1013,7 +1013,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 constexpr int kWsRows = 344;                 // window rows per group buffer (43 pieces of 8 rows)
 constexpr int kWsPiecesPerWave = 11;         // 43 pieces over the 4 waves of a group
 
+// NWV (round 3): pixel tiles (of the four of a wave's 64 x 64 tile) whose epilogue is DEFERRED — their sums move to a second accumulator set
+// when the group leaves its multiply phase and the SiLU / residual / store of those values is woven, one floatx4 at a time, between the
+// MFMAs of the group's NEXT multiply phase (sched_group_barrier pins the interleave; stores go out as raw buffer stores whose junk lanes
+// carry an out-of-range offset, so the phase has no branch in it).  Stamps of the round-2 kernel had Q (stage + epilogue, ~8 400 cycles)
+// as the long pole of every interval against ~5 100 for the multiply: the partner's matrix time was wasted for a third of each interval,
+// and with two waves per SIMD no amount of overlap BETWEEN waves gets under (P + Q) / 2 — only work moved INTO the multiplying wave's
+// own instruction stream does.  NWV = 0 is the round-2 kernel (WTK_WS64_WEAVE=0), results are bit-identical for every NWV.
+template <int NWV>
 __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
+    static_assert(NWV >= 0 && NWV <= 4, "woven pixel tiles");
     asm volatile("" ::"s"(a.in), "s"(a.w), "s"(a.bias), "s"(a.in_ld), "s"(a.in_coff), "s"(a.N), "s"(a.H), "s"(a.W), "s"(a.Kpad), "s"(a.S), "s"(a.pitch),
                  "s"(a.strips), "s"(a.d_strips.mul), "s"(a.d_strips.sh1), "s"(a.d_strips.sh2), "s"(a.d_pitch.mul), "s"(a.d_pitch.sh1), "s"(a.d_pitch.sh2),
                  "s"(a.d_h1.mul), "s"(a.d_h1.sh1), "s"(a.d_h1.sh2), "s"(a.grid), "s"(a.blocks_per_strip));
@@ -1106,14 +1115,13 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
     }
     // accumulators start at the bias
     floatx4 acc[TC][TP];
-    float biasv[NV];
+    auto arm_acc = [&]() __attribute__((always_inline)) { // the bias is re-read per tile (64 B per lane, cache resident): 16 registers that need not live through the multiply phase
 #pragma unroll
-    for (int i = 0; i < NV; ++i) biasv[i] = a.bias[lg * NV + i];
-    auto arm_acc = [&]() __attribute__((always_inline)) {
+        for (int i = 0; i < TC; ++i) {
+            const float4 b = *reinterpret_cast<const float4 *>(a.bias + lg * NV + i * 4);
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){biasv[i * 4 + 0], biasv[i * 4 + 1], biasv[i * 4 + 2], biasv[i * 4 + 3]};
+            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){b.x, b.y, b.z, b.w};
+        }
     };
     arm_acc();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1140,12 +1148,33 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wts + wa + i * 512);
     };
+    // ---- deferred (woven) part of the previous tile's epilogue: sums, residual values and store offsets of its last NWV pixel tiles
+    constexpr int NB = NWV > 0 ? NWV : 1;
+    constexpr int kPieces = 4 * NWV; // one floatx4 (4 couts of one pixel) per piece
+    floatx4 accB[TC][NB];
+    half8 rresB[NB][2];
+    unsigned ooffB[NB]; // byte offset of the lane's 16 couts of that pixel in `out`; kJunkOff for junk pixels: beyond the descriptor's range, also after the
+                        // + 16 of a pixel's second store (0xffffffff would wrap to 15 and land inside the tensor), so the hardware drops the store
+    constexpr unsigned kJunkOff = 0xf0000000u, kOutRange = 0xe0000000u;
+#pragma unroll
+    for (int jw = 0; jw < NB; ++jw) {
+        ooffB[jw] = kJunkOff;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) accB[i][jw] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        rresB[jw][0] = rresB[jw][1] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.out) + (long long)a.out_coff * (long long)sizeof(T), 0,
+                                                                            (int)kOutRange, 0x00020000);
+    // step of the multiply phase that hosts piece p: the pieces are spread evenly over steps 0 .. 15
     auto compute_tile = [&]() __attribute__((always_inline)) {
+        constexpr bool WV = NWV > 0; // the woven pieces run in EVERY multiply phase: a group's first tile has nothing pending and weaves zeros whose stores are
+                                     // dropped (out-of-range offsets) — one instruction stream, no branch, no second copy of the 288-MFMA body
         // Two fragment register sets: the eight ds_read_b128 of step s+1 are issued BETWEEN the MFMAs of step s (one read per two
         // MFMAs), so a wave that has the SIMD's matrix pipe to itself never waits for LDS.  hipcc's scheduler otherwise sinks every
         // read to just before its first use (one register set, the LDS latency exposed 18 times per tile): the sched_barrier /
         // sched_group_barrier calls pin the order.
         uint4 pf[2][TP], wf[2][TC];
+        uint2 packed[2]; // a pixel's 8 finished couts (two pieces) on their way to one 16-byte store
         if (a.slabs & 8) __builtin_amdgcn_s_setprio(3); // the multiplying wave wins the SIMD's issue arbitration; its partner (stage + epilogue) takes the gaps
         load_frags(0, pf[0], wf[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -1156,18 +1185,45 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
             for (int i = 0; i < TC; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j) mma_h(wf[s & 1][i], pf[s & 1][j], acc[i][j], (T *)nullptr);
+            // piece p = (pixel tile jw, cout quad i) of the deferred tile rides on this step when p * 16 / kPieces == s
+            bool hosts = false;
+            if constexpr (WV) {
+#pragma unroll
+                for (int p = 0; p < kPieces; ++p) {
+                    if (p * 16 / kPieces != s) continue;
+                    hosts = true;
+                    const int jw = p >> 2, i = p & 3;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = accB[i][jw][r];
+                    wtk_silu_scaled_run<4, true>(v); // scalar add / multiply: a packed fp32 instruction costs 27-32 issue cycles beside MFMAs
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = wtk_pin_f32(v[r] + (float)rresB[jw][i >> 1][(i & 1) * 4 + r]); // zeros when the layer has no residual
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                    const half4 h4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    packed[i & 1] = __builtin_bit_cast(uint2, h4);
+                    if (i & 1) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 d = {packed[0].x, packed[0].y, packed[1].x, packed[1].y};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, out_rs, (int)(ooffB[jw] + (unsigned)((i >> 1) * 16)), 0, 0);
+                    }
+                }
+            }
             if (s + 1 < 18) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); // 2 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read
+                    if (WV && hosts) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); // 4 VALU of the woven piece
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (a.slabs & 8) __builtin_amdgcn_s_setprio(0);
     };
-    auto epilogue = [&](const Tile &tc) __attribute__((always_inline)) {
+    // `defer_tail`: the last NWV pixel tiles are not finished here — their sums, residual values and store offsets go to the deferred set and
+    // ride on the group's next multiply phase (only when the group HAS a next tile; the last tile of a group is finished whole)
+    auto epilogue = [&](const Tile &tc, bool defer_tail) __attribute__((always_inline)) {
         int pix_e, col_e;
         halo_out_pixel(a, tc.o0 + gw * WP, tc.xs, lane, pix_e, col_e);
         long long pixj[TP];
@@ -1186,6 +1242,14 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
+            if (NWV > 0 && j >= TP - NWV && defer_tail) { // wave-uniform
+                const int jw = j - (TP - NWV);
+#pragma unroll
+                for (int i = 0; i < TC; ++i) accB[i][jw] = acc[i][j];
+                if (res) rresB[jw][0] = rraw[j][0], rresB[jw][1] = rraw[j][1]; // (no residual: they stay the zeros they were initialised to)
+                ooffB[jw] = pixj[j] >= 0 ? (unsigned)((pixj[j] * a.out_ld + cb) * (long long)sizeof(T)) : kJunkOff;
+                continue;
+            }
             float v[NV];
 #pragma unroll
             for (int i = 0; i < TC; ++i)
@@ -1229,13 +1293,6 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
         } else {
             const int kprev = (i - 1 - grp) >> 1, knext = (i + 1 - grp) >> 1;
             const bool has_prev = i - 1 - grp >= 0 && kprev < n_mine, has_next = knext < n_mine;
-            if (has_prev && (a.slabs & 16)) {
-#ifdef WTK_WS64_ABLATE
-                if (!(a.bm & 4))
-#endif
-                    epilogue(done);
-                arm_acc();
-            }
             if (has_next) {
                 setup_tile(knext, cur);
 #ifdef WTK_WS64_ABLATE
@@ -1243,11 +1300,11 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
 #endif
                     stage_window(cur); // the group finished reading its window before the last barrier
             }
-            if (has_prev && !(a.slabs & 16)) {
+            if (has_prev) {
 #ifdef WTK_WS64_ABLATE
                 if (!(a.bm & 4))
 #endif
-                    epilogue(done);
+                    epilogue(done, has_next);
                 arm_acc();
             }
 #ifdef WTK_WS64_ABLATE
@@ -1280,7 +1337,18 @@ hipError_t launch_ws64(HaloArgs a, int num_cus, hipStream_t stream) {
     const long long want = (tiles + 1) / 2;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     a.grid = (int)grid;
-    hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(grid), dim3(512), 0, stream, a);
+    // woven epilogue: needs SiLU (the woven pieces have no activation switch) and 32-bit store offsets; a.bm carries the number of woven pixel tiles
+    // (0: the round-2 schedule) outside the ablation builds
+    const bool can_weave = a.act && (long long)a.N * a.H * a.W * a.out_ld * 2 < 0xe0000000LL; // (kOutRange of the kernel)
+#ifdef WTK_WS64_ABLATE
+    const int nwv = 0;
+#else
+    const int nwv = can_weave ? a.bm : 0;
+#endif
+    if (nwv == 1) hipLaunchKernelGGL(conv3x3_ws64_kernel<1>, dim3(grid), dim3(512), 0, stream, a);
+    else if (nwv == 2) hipLaunchKernelGGL(conv3x3_ws64_kernel<2>, dim3(grid), dim3(512), 0, stream, a);
+    else if (nwv == 3) hipLaunchKernelGGL(conv3x3_ws64_kernel<3>, dim3(grid), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(conv3x3_ws64_kernel<0>, dim3(grid), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 

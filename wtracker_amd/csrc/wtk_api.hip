@@ -540,6 +540,7 @@ struct wtk_yolo {
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
     int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
+    int ws64_weave = 2; // pixel tiles (of 4) of a 64-channel 3x3 tile whose epilogue rides on the next multiply phase (WTK_WS64_WEAVE=0..3; 0: the round-2 schedule)
     int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
     int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
@@ -929,6 +930,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
+    if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
     if (const char *e = std::getenv("WTK_NO_S2WIN")) h->use_s2win = e[0] != '1';
     {
         hipDeviceProp_t prop;
@@ -1552,6 +1554,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 }
                 if (ws64) {
                     g.zeros = h->zero_page;
+                    g.bm = h->ws64_weave;
                     if (const char *e = std::getenv("WTK_WS64_ABLATE")) g.bm = std::atoi(e); // timing-only switches of -DWTK_WS64_ABLATE builds
                     if (const char *e = std::getenv("WTK_WS64_FLAGS")) g.slabs = std::atoi(e);  // 8: s_setprio around the multiply phase
 #ifdef WTK_WS64_ABLATE

@@ -19,9 +19,9 @@ fp16 result, and `overflow` (device counter, `overflow_count()` on the host) say
 How wide must `margin` be?  At least twice the fp16 logit noise of the MODEL AT HAND — and that noise is a property of the weights: with
 the synthetic weight draw bench.py uses (seed 0) no fp16 survivor mismatch in thousands of frames has a margin above 0.019, with other
 draws (seeds 2 and 3) mismatches reach margins of 0.10-0.15 (tests/test_gpu_hybrid_validation.py, profiles/r03_hybrid_validation.json).
-A fixed number is therefore NOT a guarantee.  `calibrate()` measures the largest margin of any fp16 / full-precision disagreement on
-frames of the caller's choosing and sets margin = safety x that (default 2 x, floor 0.02); the procedure is validated out of sample
-(calibration frames and validation frames disjoint) on four weight draws in the tests.  Where the calibrated margin makes most frames
+A fixed number is therefore NOT a guarantee.  `calibrate()` measures, on frames of the caller's choosing, the noise of the fp16 decision margin against the full-precision one
+(every frame a sample) and the largest margin of any outright disagreement, and sets margin = max(6 sigma, 2 x that largest margin,
+0.02); the procedure is validated out of sample (calibration frames and validation frames disjoint) on four weight draws in the tests.  Where the calibrated margin makes most frames
 weak, the hybrid is slower than the full-precision mode alone and "f16x3" is the mode to use — bench.py reports both.
 
 It has the detector interface TrackPipeline uses (predict / predict_views / device / max_batch), so `dets=[HybridDetector(...)]`
@@ -147,17 +147,21 @@ class HybridDetector:
                                  conf=conf, iou=iou, max_det=1, stream=stream)
         hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
 
-    def calibrate(self, batches, H: int, W: int, Cc: int = 1, conf: float = 0.1, safety: float = 2.0, floor: float = 0.02) -> dict:
+    def calibrate(self, batches, H: int, W: int, Cc: int = 1, conf: float = 0.1, safety: float = 2.0, z: float = 6.0, floor: float = 0.02) -> dict:
         """Set `margin` from measurements on THIS model: every batch of `batches` (device uint8 tensors [B, H, W(, C)], B <= max_batch of both
-        handles) goes through the fast and through the full-precision handle; margin = max(floor, safety x the largest fast-pass decision
-        margin of any frame on which the two disagree about the survivor).  Returns what was measured.  Synchronises; not for timed regions."""
+        handles) goes through the fast and through the full-precision handle.  Two statistics bound how far fp16 can move a decision:
+          * the NOISE of the decision margin itself, d = margin(fast) - margin(full precision) on the frames where both name the same survivor
+            (every frame is a sample): sigma = max(std, 1.4826 MAD, p99 / 2.576) of d.  A survivor can only flip where the full-precision gap
+            between two anchors is smaller than fp16's perturbation of that gap, and the flipped frame's fp16 margin is at most that perturbation;
+          * the largest fast-pass margin of any frame on which the two DO disagree (few samples: only the tail).
+        margin = max(floor, z x sigma, safety x largest mismatch margin).  Returns what was measured.  Synchronises; not for timed regions."""
         if self.exact.max_batch < self.fast.max_batch:
             raise hip.WtkError("calibrate: the full-precision handle must take whole batches (max_batch >= the fast handle's)")
         import numpy as np
 
         self.exact.set_dynamic_batch(None)
         dev = torch.device("cuda", self.device)
-        worst, n_frames, n_bad, margins_bad = 0.0, 0, 0, []
+        worst, n_frames, n_bad, margins_bad, noise = 0.0, 0, 0, [], []
         try:
             for fb in batches:
                 B = int(fb.shape[0])
@@ -166,18 +170,26 @@ class HybridDetector:
                 self.fast.predict(fb, B, H, W, Cc, *o[0], conf=conf)
                 self.exact.predict(fb, B, H, W, Cc, *o[1], conf=conf)
                 torch.cuda.synchronize(dev)
-                m = self.fast.last_margins(B)
+                m, mx = self.fast.last_margins(B), self.exact.last_margins(B)
                 bad = (o[0][2] != o[1][2]).cpu().numpy()
                 n_frames += B
                 n_bad += int(bad.sum())
+                d = (m - mx)[~bad]
+                noise.extend(float(v) for v in d[np.isfinite(d)])
                 if bad.any():
                     margins_bad.extend(float(v) for v in m[bad])
                     worst = max(worst, float(np.nanmax(m[bad])))
         finally:
             self.exact.set_dynamic_batch(self._n_weak)
-        self.margin = max(float(floor), float(safety) * worst)
-        return {"frames": n_frames, "fast_mismatches": n_bad, "largest_mismatch_margin": worst, "safety": safety, "floor": floor, "margin": self.margin,
-                "mismatch_margins_sorted_desc": sorted(margins_bad, reverse=True)[:8]}
+        noise = np.asarray(noise, dtype=np.float64)
+        if len(noise) >= 8:
+            mad = float(np.median(np.abs(noise - np.median(noise))))
+            sigma = max(float(noise.std()), 1.4826 * mad, float(np.percentile(np.abs(noise), 99)) / 2.576)
+        else:
+            sigma = 0.0
+        self.margin = max(float(floor), float(z) * sigma, float(safety) * worst)
+        return {"frames": n_frames, "fast_mismatches": n_bad, "largest_mismatch_margin": worst, "margin_noise_sigma": sigma, "margin_noise_max_abs": float(np.abs(noise).max()) if len(noise) else 0.0,
+                "safety": safety, "z": z, "floor": floor, "margin": self.margin, "mismatch_margins_sorted_desc": sorted(margins_bad, reverse=True)[:8]}
 
     def overflow_count(self) -> int:
         """Weak rows (margin below the threshold) that kept their fp16 result because more than k rows of a batch were weak.  Synchronises."""
