@@ -133,7 +133,7 @@ class Workload:
         if dtype == "hybrid":  # fp16 on every frame + the K weakest decisions of each batch again in f16x3, merged on the device
             from wtracker_amd.hybrid import HybridDetector
 
-            q = max(args.batch * HYBRID_QUEUE_PER_64 // 64, 1) if args.defer > 1 else args.batch
+            q = args.hybrid_queue if args.defer > 1 else args.batch
             self.dets = [HybridDetector(handle("fp16", args.batch), handle("f16x3", q), margin=args.hybrid_margin, k=q, defer=args.defer) for _ in range(lanes)]
         else:
             self.dets = [handle(dtype, args.batch) for _ in range(lanes)]
@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision sub-object")
     ap.add_argument("--conf", type=float, default=0.1)
     ap.add_argument("--defer", type=int, default=HYBRID_DEFER, help="hybrid: batches of a lane whose weak rows share one full-precision pass (1 = second look inside every step)")
+    ap.add_argument("--hybrid-queue", type=int, default=0, help="hybrid, deferred: rows of a lane's queue (0 = from the calibration: twice the measured weak share, at most defer x batch)")
     ap.add_argument("--hybrid-margin", type=float, default=0.0, help="hybrid: decision-margin threshold; 0 = calibrate it on this model inside the run")
     ap.add_argument("--lanes", type=int, default=2, help="forward passes in flight per GPU (each lane = own workspace + HIP stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
@@ -364,6 +365,10 @@ def main():
                 args.hybrid_margin = float(t.item())
         else:
             args.hybrid_margin = HYBRID_MARGIN_FALLBACK
+    if args.hybrid_queue <= 0:
+        # a lane's queue receives the weak rows of `defer` batches: twice the share measured on the calibration frames (+ 10 %), never more than all of them
+        share = calibration["share_below_margin"] if calibration is not None else HYBRID_QUEUE_PER_64 / (64.0 * HYBRID_DEFER)
+        args.hybrid_queue = int(min(args.defer * args.batch, max(args.batch // 2, np.ceil(args.defer * args.batch * min(1.0, 2.0 * share + 0.1)))))
     if world > 1 or args.dtype != "auto":
         head_dtype = "hybrid" if args.dtype == "auto" else args.dtype  # N > 1 has no CPU leg: hybrid's exactness is asserted at N = 1 and in tests/
         modes[head_dtype] = measure(head_dtype, args.lanes, args.repeats, profile)
@@ -465,6 +470,7 @@ def main():
         out["hybrid_second_look_share"] = modes["hybrid"]["second_look"]["share"]
         out["hybrid_margin"] = args.hybrid_margin
         out["hybrid_defer"] = args.defer
+        out["hybrid_queue"] = args.hybrid_queue
         if calibration is not None:
             out["hybrid_calibration"] = calibration
     notes = {

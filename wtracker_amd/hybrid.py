@@ -161,7 +161,7 @@ class HybridDetector:
 
         self.exact.set_dynamic_batch(None)
         dev = torch.device("cuda", self.device)
-        worst, n_frames, n_bad, margins_bad, noise = 0.0, 0, 0, [], []
+        worst, n_frames, n_bad, margins_bad, noise, all_margins = 0.0, 0, 0, [], [], []
         try:
             for fb in batches:
                 B = int(fb.shape[0])
@@ -172,6 +172,7 @@ class HybridDetector:
                 torch.cuda.synchronize(dev)
                 m, mx = self.fast.last_margins(B), self.exact.last_margins(B)
                 bad = (o[0][2] != o[1][2]).cpu().numpy()
+                all_margins.extend(float(v) for v in m)
                 n_frames += B
                 n_bad += int(bad.sum())
                 d = (m - mx)[~bad]
@@ -188,7 +189,8 @@ class HybridDetector:
         else:
             sigma = 0.0
         self.margin = max(float(floor), float(z) * sigma, float(safety) * worst)
-        return {"frames": n_frames, "fast_mismatches": n_bad, "largest_mismatch_margin": worst, "margin_noise_sigma": sigma, "margin_noise_max_abs": float(np.abs(noise).max()) if len(noise) else 0.0,
+        share = float((np.asarray(all_margins) < self.margin).mean()) if all_margins else 0.0
+        return {"frames": n_frames, "share_below_margin": share, "fast_mismatches": n_bad, "largest_mismatch_margin": worst, "margin_noise_sigma": sigma, "margin_noise_max_abs": float(np.abs(noise).max()) if len(noise) else 0.0,
                 "safety": safety, "z": z, "floor": floor, "margin": self.margin, "mismatch_margins_sorted_desc": sorted(margins_bad, reverse=True)[:8]}
 
     def overflow_count(self) -> int:
