@@ -77,6 +77,7 @@ HYBRID_CAL_FRAMES, HYBRID_CAL_SEED = 512, 40000
 # Deferred second look: the weak rows of HYBRID_DEFER consecutive batches of a lane share one f16x3 pass (its fixed cost of ~1.2 ms is paid once per
 # HYBRID_DEFER batches); queue of HYBRID_QUEUE rows per lane = 40 % of the frames it can receive — a fuller queue is COUNTED (overflow) and demotes the mode.
 HYBRID_DEFER, HYBRID_QUEUE_PER_64 = 5, 128
+HYBRID_EXACT_MEM_GB = 48.0  # f16x3 workspace of one lane's second-look handle
 PROFILE_ROUND = "r03"
 
 
@@ -133,7 +134,7 @@ class Workload:
         if dtype == "hybrid":  # fp16 on every frame + the K weakest decisions of each batch again in f16x3, merged on the device
             from wtracker_amd.hybrid import HybridDetector
 
-            q = args.hybrid_queue if args.defer > 1 else args.batch
+            q = args.hybrid_queue
             self.dets = [HybridDetector(handle("fp16", args.batch), handle("f16x3", q), margin=args.hybrid_margin, k=q, defer=args.defer) for _ in range(lanes)]
         else:
             self.dets = [handle(dtype, args.batch) for _ in range(lanes)]
@@ -366,9 +367,19 @@ def main():
         else:
             args.hybrid_margin = HYBRID_MARGIN_FALLBACK
     if args.hybrid_queue <= 0:
-        # a lane's queue receives the weak rows of `defer` batches: twice the share measured on the calibration frames (+ 10 %), never more than all of them
+        # a lane's queue receives the weak rows of `defer` batches: twice the share measured on the calibration frames (+ 10 %), never more than all of them —
+        # and never more frames than HYBRID_EXACT_MEM_GB of f16x3 workspace hold (107 MB of activations per 640x640 frame, per lane): at 1280x1280 / B = 256 that
+        # is ~110 rows, so the number of batches that share a pass shrinks with it (down to the immediate form, ceiling = what fits; overflow is counted)
         share = calibration["share_below_margin"] if calibration is not None else HYBRID_QUEUE_PER_64 / (64.0 * HYBRID_DEFER)
-        args.hybrid_queue = int(min(args.defer * args.batch, max(args.batch // 2, np.ceil(args.defer * args.batch * min(1.0, 2.0 * share + 0.1)))))
+        per_batch = args.batch * min(1.0, 2.0 * share + 0.1)
+        fits = max(int(HYBRID_EXACT_MEM_GB * 1e9 / (107e6 * (args.size / 640.0) ** 2)), 1)
+        if args.defer > 1 and fits < 2 * per_batch:
+            args.defer = 1
+        if args.defer > 1:
+            args.defer = int(max(2, min(args.defer, fits // max(per_batch, 1))))
+            args.hybrid_queue = int(min(args.defer * args.batch, fits, max(args.batch // 2, np.ceil(args.defer * per_batch))))
+        else:
+            args.hybrid_queue = int(min(args.batch, fits))
     if world > 1 or args.dtype != "auto":
         head_dtype = "hybrid" if args.dtype == "auto" else args.dtype  # N > 1 has no CPU leg: hybrid's exactness is asserted at N = 1 and in tests/
         modes[head_dtype] = measure(head_dtype, args.lanes, args.repeats, profile)
@@ -400,7 +411,8 @@ def main():
             par[dtype] = metrics.accuracy_report(xg, ag, xo, ao, cg, co)
         from wtracker_amd.hybrid import HybridDetector
 
-        hyb = HybridDetector(mk("fp16", 64), mk("f16x3", 64), margin=args.hybrid_margin, k=64)
+        kq = min(64, args.hybrid_queue if args.defer <= 1 else 64)
+        hyb = HybridDetector(mk("fp16", 64), mk("f16x3", kq), margin=args.hybrid_margin, k=kq)
         sdev = torch.from_numpy(sample).to(dev)
         ox, oc, oa = (torch.empty((n, 4), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
                       torch.empty((n,), dtype=torch.int32, device=dev))
