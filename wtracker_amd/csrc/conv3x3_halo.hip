@@ -61,6 +61,27 @@ __device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, pf.w), acc, 0, 0, 0);
 }
 
+// -DWTK_TIMING_MFMA32: TIMING EXPERIMENT ONLY (results are garbage).  The fp16 128-cout window kernels issue, per k-half of a tap, EIGHT
+// v_mfma_f32_32x32x16_f16 on the fragments they have already read instead of SIXTEEN v_mfma_f32_16x16x32_f16: the same fragment reads, the same
+// FLOPs, the same 64 accumulator registers, half the MFMA issue slots (an MFMA holds the SIMD's issue port for 8 cycles whatever its shape).  It
+// answers one question before anybody rewrites the fragment layouts for the other shape: how much of a tap's ~1 300-1 500 cycles is MFMA issue?
+#ifdef WTK_TIMING_MFMA32
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+template <int TC, int TP> __device__ __forceinline__ void mma32_timing(const uint4 (&wf)[TC], const uint4 (&pf)[TP], floatx4 (&acc)[TC][TP]) {
+    static_assert(TC == 4 && TP == 4, "timing experiment: 64 x 64 wave tile");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        floatx16 c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = acc[q][e >> 2][e & 3];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[q]), __builtin_bit_cast(half8, pf[q]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[(q + 1) & 3]), __builtin_bit_cast(half8, pf[(q + 2) & 3]), c, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e >> 2][e & 3] = c[e];
+    }
+}
+#endif
+
 template <int NV> __device__ __forceinline__ void load_run_h(const _Float16 *p, float (&v)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; i += 8) {
@@ -383,6 +404,12 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
 #pragma unroll
             for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
+#ifdef WTK_TIMING_MFMA32
+            if constexpr (TC == 4 && TP == 4 && sizeof(T) == 2) {
+                mma32_timing<TC, TP>(wf, pf, acc);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -853,6 +880,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
             for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
 #pragma unroll
             for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
+#ifdef WTK_TIMING_MFMA32
+            if constexpr (TC == 4 && TP == 4 && sizeof(T) == 2) {
+                mma32_timing<TC, TP>(wf, pf, acc);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
