@@ -930,14 +930,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
         for (int tap = 0; tap < 9; ++tap) {
             const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
             char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
-            const int issued = WR + (tap < kMaxPiecesPerWave ? 1 : 0);
+#ifndef WTK_TIMING_SKIP // TIMING ablations of the persistent kernel's tap (garbage results): 1 no weight-slab requests, 2 no window-piece requests, 4 no tap barrier
+#define WTK_TIMING_SKIP 0
+#endif
+            const int issued = ((WTK_TIMING_SKIP & 1) ? 0 : WR) + ((tap < kMaxPiecesPerWave && !(WTK_TIMING_SKIP & 2)) ? 1 : 0);
             compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
             // requests after the tap's reads and MFMAs (see conv3x3_halo_kernel)
+            if constexpr (!(WTK_TIMING_SKIP & 1)) {
             if (tap < 7)
                 issue_weights(wnext2, cur.wtile, tap + 2, c);
             else
                 issue_weights(wnext2, to_next ? nxt.wtile : cur.wtile, tap - 7, cn);
-            if (tap < kMaxPiecesPerWave) {
+            }
+            if (tap < kMaxPiecesPerWave && !(WTK_TIMING_SKIP & 2)) {
                 // select the geometry by value (no branch around the request)
                 Tile sel;
                 sel.img = to_next ? nxt.img : cur.img;
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
             }
             wait_vmcnt(issued);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(WTK_TIMING_SKIP & 4)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
     };
