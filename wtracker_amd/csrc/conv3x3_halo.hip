@@ -868,11 +868,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
     const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
     const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
     const int prow0 = wave_p * WP + lr;
-    auto compute_tap = [&](const char *halo, const char *wb, int tapoff) __attribute__((always_inline)) {
+    auto compute_tap = [&](const char *halo, const char *wb, int tapoff, int which = -1) __attribute__((always_inline)) {
         const int base = prow0 + tapoff;
         const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4);
 #pragma unroll
         for (int kh2 = 0; kh2 < 2; ++kh2) {
+            if (which >= 0 && kh2 != which) continue; // (timing experiment WTK_TIMING_STAGGER: one k-half at a time)
             const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
             const unsigned wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
             uint4 pf[TP], wf[TC];
@@ -934,7 +935,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 #define WTK_TIMING_SKIP 0
 #endif
             const int issued = ((WTK_TIMING_SKIP & 1) ? 0 : WR) + ((tap < kMaxPiecesPerWave && !(WTK_TIMING_SKIP & 2)) ? 1 : 0);
+#ifdef WTK_TIMING_STAGGER // TIMING experiment (garbage results): waves 4-7 meet the tap barrier BETWEEN their two k-halves, i.e. run half a tap behind waves 0-3
+            const bool lag = wave >= 4;
+            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3), lag ? 0 : -1);
+#else
             compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
+#endif
             // requests after the tap's reads and MFMAs (see conv3x3_halo_kernel)
             if constexpr (!(WTK_TIMING_SKIP & 1)) {
             if (tap < 7)
@@ -955,6 +961,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (!(WTK_TIMING_SKIP & 4)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifdef WTK_TIMING_STAGGER
+            if (lag) compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3), 1);
+#endif
         }
     };
 
