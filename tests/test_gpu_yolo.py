@@ -762,29 +762,6 @@ def test_weight_stationary_64ch_kernel_equals_window_kernel(hip_lib, monkeypatch
             np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("B,H,W", [(64, 640, 640), (24, 1280, 736), (5, 352, 224)])
-def test_loader_consumer_window_kernel_equals_persistent_kernel(hip_lib, monkeypatch, B, H, W):
-    """WTK_HALO_LC=1: the 128-cout 3x3 layers through conv3x3_halo_lckernel (four consumer waves that only read fragments and multiply,
-    four loader waves that issue every LDS-DMA request; hand-over through counters in LDS, no block barrier inside the tile loop).  Same K
-    order, same MFMA, same epilogue arithmetic as the persistent kernel: head logits bit-identical, twice in a row (the hand-over protocol
-    must not depend on timing)."""
-    w = ys.synthetic_weights("s", 1, seed=0)
-    depth, width, maxch = ys.SCALES["s"]
-    rng = np.random.default_rng(21)
-    frames = rng.integers(0, 256, size=(B, H, W), dtype=np.uint8)
-    outs = []
-    for lc in ("0", "1", "1"):
-        monkeypatch.setenv("WTK_HALO_LC", lc)
-        det = hip.HipYolo(w, (H, W), B, dtype="fp16", nc=1, width=width, depth=depth, max_channels=maxch)
-        xywh, conf, anchor = det.predict_host(frames, conf=0.1)
-        box, cls = det.debug_head(B)
-        outs.append((xywh, conf, anchor, box, cls))
-        det.close()
-    for o in outs[1:]:
-        for x, y in zip(outs[0], o):
-            np.testing.assert_array_equal(x, y)
-
-
 @pytest.mark.parametrize("B,H,W", [(64, 640, 640), (3, 352, 224), (9, 1280, 736)])
 def test_stride2_window_kernel_matches_implicit_gemm(hip_lib, monkeypatch, B, H, W):
     """conv3x3_s2_kernel (strided 3x3 convs through an LDS-resident window of the four input parity planes) against the implicit-GEMM

@@ -1041,335 +1041,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Loader / consumer form of the persistent three-slab kernel (round 3; fp16, 128-cout tile, even number of 64-channel chunks).
-//
-// Timing ablations of conv3x3_halo_pkernel (profiles/r03_notes.md §3c) price a tap's operand requests at 16-19 % and its block-wide barrier
-// at 9-12 %: three LDS-DMA requests per wave and tap, each holding the wave 100-185 cycles while it also has 32 MFMAs to issue, and a barrier
-// that every tap waits for the slowest of eight waves.  Here the roles are split.  Waves 0-3 (one per SIMD) are CONSUMERS: each owns 64
-// pixels x all 128 couts of the block's tile (128 accumulator registers), issues nothing but ds_reads and MFMAs, and never meets a block
-// barrier inside the tile loop.  Waves 4-7 (their SIMD partners) are LOADERS: they issue every LDS-DMA request (weight slabs two taps ahead,
-// the next chunk's window piece by piece), wait for them with counted vmcnt, and publish what has landed.  Hand-over through LDS words:
-//   full_w[slot][loader]   = fills of that slab slot completed by that loader      (consumers wait for all four before reading the slot)
-//   free_w[slot][consumer] = taps of that slot whose fragments the consumer has read (loaders wait for all four before refilling it)
-//   full_h / free_h        the same for the two window buffers, counted in chunks
-// All counters are monotonic; a reader polls with one ds_read_b128 of the four words.  Polls are bounded (kSpinMax): a protocol error ends in
-// wrong results and a set error word, never in a hung GPU.
-// Geometry, LDS layouts, K order (tap-major, two 32-deep halves per tap), bias-initialised accumulators and the epilogue arithmetic are those of
-// conv3x3_halo_pkernel: results are bit-identical (WTK_HALO_LC=0 switches back; tests compare).  The cout <-> MFMA-row permutation is the
-// 128-couts-per-wave one (a lane owns 32 consecutive couts of a pixel).
-// ---------------------------------------------------------------------------------------------------------------
-template <int HROWS>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo_lckernel(const HaloArgs a) {
-    using T = _Float16;
-    constexpr int BN = 128, CE = 8, CCH = 64;
-    constexpr int TP = 4, TC = 8, NV = 32, WP = 64; // consumer tile: 64 px x 128 cout
-    constexpr int kPieces = HROWS / 8;              // window pieces of 8 rows
-    constexpr int kPL = (kPieces + 3) / 4;          // window pieces per loader wave
-    constexpr int kPLT = (kPL + 6) / 7;             // ... requested per tap (taps 0..6 of the previous chunk)
-    constexpr unsigned kSpinMax = 1u << 22;
-    static_assert(kPL <= 16 && kPLT * 7 >= kPL, "window pieces per loader");
-
-    __shared__ __attribute__((aligned(16))) char halo0[HROWS * 128];
-    __shared__ __attribute__((aligned(16))) char halo1[HROWS * 128];
-    __shared__ __attribute__((aligned(16))) char wbuf0[BN * 128];
-    __shared__ __attribute__((aligned(16))) char wbuf1[BN * 128];
-    __shared__ __attribute__((aligned(16))) char wbuf2[BN * 128];
-    __shared__ unsigned full_w[3], free_w[3], full_h[2], free_h[2]; // every counter is the SUM over the four loaders / consumers (LDS atomic adds)
-    __shared__ unsigned lc_error;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 4;
-    const int role_i = wave & 3; // consumer: pixel quarter of the tile; loader: loader index
-    const int lr = lane & 15, lg = lane >> 4;
-    const int pitch = a.pitch;
-    const int halo_rows = kBM + 2 * pitch + 2;
-    const int nct = a.CoutPad / BN;
-    const int nchunks = a.Cin / CCH; // even (launcher)
-    const int total = a.strips * a.blocks_per_strip * nct;
-    const int G = a.grid;
-
-    if (tid < 3) full_w[tid] = 0u, free_w[tid] = 0u;
-    if (tid < 2) full_h[tid] = 0u, free_h[tid] = 0u;
-    if (tid == 0) lc_error = 0u;
-    __syncthreads();
-    if ((int)blockIdx.x >= total) return;
-
-    // tile -> (cout tile, flat origin, strip) as conv3x3_halo_pkernel
-    auto tile_origin = [&](int v, int &n0, int &o0, int &xs, int &n_base) __attribute__((always_inline)) {
-        const int xcd = v & 7, q8 = total >> 3, r8 = total & 7;
-        const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
-        const unsigned t = fdiv((unsigned)L, a.d_nct);
-        n0 = (L - (int)t * nct) * BN;
-        const int rb = (int)fdiv(t, a.d_strips);
-        const int strip = (int)t - rb * a.strips;
-        o0 = rb * kBM;
-        xs = strip * a.S;
-        n_base = (int)fdiv(fdiv((unsigned)o0, a.d_pitch), a.d_h1);
-    };
-    // counter >= 4 x want: all four partners have got that far (bounded spin)
-    auto wait_all4 = [&](const unsigned *row, unsigned want) __attribute__((always_inline)) {
-        for (unsigned spin = 0;; ++spin) {
-            const unsigned v = *reinterpret_cast<const volatile unsigned *>(row);
-            if (v >= 4u * want) break;
-            if (spin > kSpinMax) {
-                lc_error = 1u;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-    };
-
-    if (loader) {
-        // =========================================================== LOADER ===========================================================
-        const int lw = role_i;
-        // weight slab pieces of this loader: pieces 4 lw .. 4 lw + 3 of 16 (8 couts x 128 B each)
-        unsigned wvoff[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (4 * lw + i) * 8 + (lane >> 3);
-            const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
-            wvoff[i] = (unsigned)(((long long)row * a.Kpad + ((lane & 7) ^ key) * CE) * (long long)sizeof(T));
-        }
-        auto issue_slab = [&](char *buf, const char *wtile, int tap, int c) __attribute__((always_inline)) {
-            const rsrc_t rs = make_rsrc(wtile);
-            const unsigned so = (unsigned)((tap * a.Cin + c * CCH) * (int)sizeof(T));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lds_dma16_buf(rs, wvoff[i], so, buf + (4 * lw + i) * 1024);
-        };
-        struct LTile {
-            const char *img, *wtile;
-            unsigned hoff[kPL];
-            unsigned hvalid;
-        };
-        auto setup_ltile = [&](int v, LTile &tc) __attribute__((always_inline)) {
-            int n0, o0, xs, n_base;
-            tile_origin(v, n0, o0, xs, n_base);
-            tc.img = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.in) + (long long)n_base * a.H * a.W * a.in_ld + a.in_coff);
-            tc.wtile = reinterpret_cast<const char *>(reinterpret_cast<const T *>(a.w) + (long long)n0 * a.Kpad);
-            // window rows of this loader's pieces lw, lw + 4, ...: lane L evaluates row L & 7 of piece slot L >> 3, two rounds (slots 0..7, 8..15)
-            unsigned row_e[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int q = rr * 8 + (lane >> 3);
-                const int hr = (lw + 4 * q) * 8 + (lane & 7);
-                int pn = 0, iy = 0, ix = 0;
-                const bool ok = q < kPL && hr < halo_rows && halo_in_coords(a, o0 + hr, xs, pn, iy, ix);
-                row_e[rr] = ok ? (unsigned)(((((long long)(pn - n_base) * a.H + iy) * a.W + ix) * a.in_ld) * (long long)sizeof(T)) : 0xffffffffu;
-            }
-            const unsigned lc_term = (unsigned)((((lane & 7) ^ ((lane >> 3) & 7)) * CE) * (int)sizeof(T));
-            tc.hvalid = 0;
-#pragma unroll
-            for (int q = 0; q < kPL; ++q) {
-                const unsigned v2 = (unsigned)__builtin_amdgcn_ds_bpermute(((q & 7) * 8 + (lane >> 3)) * 4, (int)row_e[q >> 3]);
-                const bool ok = v2 != 0xffffffffu;
-                tc.hoff[q] = ok ? v2 + lc_term : 0u;
-                tc.hvalid |= ok ? (1u << q) : 0u;
-            }
-        };
-        auto issue_piece = [&](char *buf, int q, const LTile &tc, int c) __attribute__((always_inline)) { // q static
-            const int piece = lw + 4 * q;
-            if (piece >= kPieces) return; // wave-uniform
-            lds_dma16_buf(make_rsrc(tc.img), ((tc.hvalid >> q) & 1u) ? tc.hoff[q] : 0xffffffffu, (unsigned)(c * (CCH * (int)sizeof(T))), buf + piece * 1024);
-        };
-
-        int v = blockIdx.x;
-        LTile cur, nxt;
-        setup_ltile(v, cur);
-        nxt = cur;
-        // prologue: window of chunk 0, slabs of taps 0 and 1
-#pragma unroll
-        for (int q = 0; q < kPL; ++q) issue_piece(halo0, q, cur, 0);
-        issue_slab(wbuf0, cur.wtile, 0, 0);
-        issue_slab(wbuf1, cur.wtile, 1, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        auto publish = [](unsigned *p) __attribute__((always_inline)) { atomicAdd(p, 1u); }; // this loader's share of one more fill
-        if (lane == 0) {
-            publish(&full_h[0]);
-            publish(&full_w[0]);
-            publish(&full_w[1]);
-        }
-        unsigned hchunk = 0; // chunks started so far by this block (window buffer = hchunk & 1)
-        while (true) {
-            const bool has_next = v + G < total;
-            if (has_next) setup_ltile(v + G, nxt);
-            for (int c = 0; c < nchunks; ++c, ++hchunk) {
-                const bool last = c + 1 == nchunks;
-                const bool to_next = last && has_next;
-                const bool any_next = !last || has_next;  // a chunk follows this one (in this tile or the next)
-                const int cn = last ? 0 : c + 1;
-                char *hnext = (hchunk & 1) ? halo0 : halo1;
-                const LTile &src = to_next ? nxt : cur;
-                // the other window buffer was last read in chunk hchunk - 1
-                if (any_next && hchunk >= 1) wait_all4(&free_h[(hchunk + 1) & 1], (hchunk - 1) / 2 + 1);
-                const unsigned gen0 = 3u * hchunk; // fills of each slab slot completed before this chunk's taps 0..2 are (gen0), ...
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    // slab of tap g + 2 goes to the slot that held tap g - 1: every consumer must have read that tap's fragments
-                    char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
-                    const bool slab_follows = tap < 7 || any_next;
-                    int issued = 0;
-                    if (slab_follows) {
-                        const unsigned prev_fill = gen0 + (unsigned)((tap + 2) / 3); // fills of slot (tap+2)%3 before the one requested now
-                        if (prev_fill >= 1) wait_all4(&free_w[(tap + 2) % 3], prev_fill);
-                        if (tap < 7)
-                            issue_slab(wnext2, cur.wtile, tap + 2, c);
-                        else
-                            issue_slab(wnext2, src.wtile, tap - 7, cn);
-                        issued += 4;
-                    }
-                    if (tap < 7 && any_next) {
-#pragma unroll
-                        for (int k = 0; k < kPLT; ++k)
-                            if (tap * kPLT + k < kPL) issue_piece(hnext, tap * kPLT + k, src, cn), issued += (lw + 4 * (tap * kPLT + k) < kPieces) ? 1 : 0;
-                    }
-                    // everything requested in EARLIER taps has landed: the slab of tap g + 1, and (at tap 7) the whole next window
-                    wait_vmcnt(issued > 8 ? 8 : issued);
-                    if (issued > 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) {
-                        if (tap < 8 || any_next) publish(&full_w[(tap + 1) % 3]);
-                        if (tap == 7 && any_next) publish(&full_h[(hchunk + 1) & 1]);
-                    }
-                }
-            }
-            if (!has_next) break;
-            cur = nxt;
-            v += G;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-
-    // ============================================================= CONSUMER =============================================================
-    const int cq = role_i; // pixel quarter
-    floatx4 acc[TC][TP];
-    const int wrow_l = (lr >> 2) * NV + (lr & 3); // + 4 i
-    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
-    const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4); // tiles i: + i * 512 (key unchanged: rows + 4 i stay in the same NV block and keep bit 1)
-    const int prow0 = cq * WP + lr;
-    T *out = reinterpret_cast<T *>(a.out);
-    const T *res = reinterpret_cast<const T *>(a.res);
-
-    int v = blockIdx.x;
-    int n0, o0, xs, n_base;
-    tile_origin(v, n0, o0, xs, n_base);
-    auto arm_acc = [&](int n0_) __attribute__((always_inline)) {
-        const int cb = n0_ + lg * NV;
-#pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const float4 b = *reinterpret_cast<const float4 *>(a.bias + cb + i * 4);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) acc[i][j] = (floatx4){b.x, b.y, b.z, b.w};
-        }
-    };
-    arm_acc(n0);
-    unsigned hchunk = 0;
-    // one tap = 4 sub-steps (k-half, cout half): 16 MFMAs each; fragments of the next sub-step are read while this one multiplies
-    auto read_p = [&](const char *halo, int tapoff, int kh, uint4 (&pf)[TP]) __attribute__((always_inline)) {
-        const int base = prow0 + tapoff;
-        unsigned pa = base * 128 + ((lg ^ (base & 7)) << 4);
-        if (kh) pa ^= 64u;
-#pragma unroll
-        for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
-    };
-    auto read_w = [&](const char *wb, int kh, int ch, uint4 (&wf)[4]) __attribute__((always_inline)) {
-        const unsigned wa = (kh ? (wfrag0 ^ 64u) : wfrag0) + ch * 2048;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
-    };
-    auto peek4 = [](const unsigned *row) __attribute__((always_inline)) -> unsigned { return *reinterpret_cast<const volatile unsigned *>(row); };
-    auto all_ge = [](unsigned f, unsigned want) __attribute__((always_inline)) -> bool { return f >= 4u * want; };
-    uint4 pf[2][TP], wf[2][4];
-    while (true) {
-        const bool has_next = v + G < total;
-        // cold start of a tile: the first tap's first fragments (every later tap finds its first fragments prefetched by the tap before it)
-        wait_all4(&full_h[hchunk & 1], hchunk / 2 + 1u);
-        wait_all4(&full_w[0], 3u * hchunk + 1u);
-        read_p((hchunk & 1) ? halo1 : halo0, 0, 0, pf[0]);
-        read_w(wbuf0, 0, 0, wf[0]);
-        for (int c = 0; c < nchunks; ++c, ++hchunk) {
-            const char *hcur = (hchunk & 1) ? halo1 : halo0;
-            const char *hnxt = (hchunk & 1) ? halo0 : halo1;
-            const bool chunk_follows = c + 1 < nchunks; // inside this tile
-            const unsigned gen0 = 3u * hchunk;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
-                const char *wnxt = (tap + 1) % 3 == 0 ? wbuf0 : ((tap + 1) % 3 == 1 ? wbuf1 : wbuf2);
-                const int tapoff = (tap / 3) * pitch + (tap % 3);
-                const int tapoff_n = tap < 8 ? ((tap + 1) / 3) * pitch + ((tap + 1) % 3) : 0;
-                const bool tap_follows = tap < 8 || chunk_follows;
-                const unsigned want_w = gen0 + (unsigned)((tap + 1) / 3) + 1u; // fills of the next tap's slot (tap 8: slot 0 of the next chunk = gen0 + 4)
-                unsigned fl_w = 0u, fl_h = 0u;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { // s = 2 * kh + cout half
-                    const int kh = s >> 1, ch = s & 1;
-                    if (s == 2 && tap_follows) { // look at the next tap's counters now, use the answer one sub-step later: the LDS latency hides under 16 MFMAs
-                        fl_w = peek4(&full_w[(tap + 1) % 3]);
-                        if (tap == 8) fl_h = peek4(&full_h[(hchunk + 1) & 1]);
-                    }
-                    if (s + 1 < 4) {
-                        if (((s + 1) & 1) == 0) read_p(hcur, tapoff, (s + 1) >> 1, pf[((s + 1) >> 1) & 1]);
-                        read_w(wcur, (s + 1) >> 1, (s + 1) & 1, wf[(s + 1) & 1]);
-                    } else if (tap_follows) {
-                        if (!all_ge(fl_w, want_w)) wait_all4(&full_w[(tap + 1) % 3], want_w);
-                        if (tap == 8 && !all_ge(fl_h, (hchunk + 1) / 2 + 1u)) wait_all4(&full_h[(hchunk + 1) & 1], (hchunk + 1) / 2 + 1u);
-                        read_p(tap < 8 ? hcur : hnxt, tapoff_n, 0, pf[0]); // this sub-step multiplies pf[1] x wf[1]: set 0 is free
-                        read_w(wnxt, 0, 0, wf[0]);
-                    }
-                    // the reads of the NEXT sub-step stay in front of this sub-step's MFMAs (hipcc otherwise sinks each one to just before its first use
-                    // and waits for it there): their latency runs under the 16 MFMAs below
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < TP; ++j) mma_h(wf[s & 1][i], pf[kh & 1][j], acc[ch * 4 + i][j], (T *)nullptr);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the last MFMAs of the tap have issued, so every fragment of its slab (and, at tap 8, of the chunk's window) is in registers: hand them back
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("" ::: "memory");
-                if (lane == 0) {
-                    atomicAdd(&free_w[tap % 3], 1u);
-                    if (tap == 8) atomicAdd(&free_h[hchunk & 1], 1u);
-                }
-            }
-        }
-        // ---- epilogue of the finished tile (conv3x3_halo_pkernel's, 32 couts per lane)
-        {
-            const int cb = n0 + lg * NV;
-            int pix_e, col_e;
-            halo_out_pixel(a, o0 + cq * WP, xs, lane, pix_e, col_e);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const long long pix = lane_fetch(j * 16 + lr, pix_e);
-                if (cb + NV > a.Cout || pix < 0) continue;
-                float vv[NV];
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[i * 4 + r] = acc[i][j][r];
-                if (a.act) wtk_silu_scaled_run<NV>(vv);
-                if (res) {
-                    float rv[NV];
-                    load_run_h<NV>(res + pix * a.res_ld + a.res_coff + cb, rv);
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) vv[i] += rv[i];
-                }
-                store_run_h<NV>(out + pix * a.out_ld + a.out_coff + cb, vv);
-            }
-        }
-        if (!has_next) break;
-        v += G;
-        tile_origin(v, n0, o0, xs, n_base);
-        arm_acc(n0);
-    }
-    if (lc_error && a.dbg_stamps && lane == 0) a.dbg_stamps[0] = 0xdeadbeefULL;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Weight-stationary window kernel for the 64 -> 64 channel 3x3 layers (fp16: the c = 64 bottlenecks on the 80x80 maps).
 //
 // All nine tap slabs of such a layer are 9 x 64 x 64 x 2 B = 72 KiB: they fit LDS next to two window buffers, so they are
@@ -2016,22 +1687,6 @@ template <typename T, int BN, int HROWS> hipError_t launch_hp(HaloArgs a, int nu
     return hipGetLastError();
 }
 
-template <int HROWS> hipError_t launch_hlc(HaloArgs a, int num_cus, hipStream_t stream) {
-    const long long tiles = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / 128);
-    if (tiles <= 0 || tiles > 0x3fffffffLL || num_cus < 8) return hipErrorInvalidValue;
-    if (kBM + 2 * a.pitch + 2 > HROWS || (a.Cin / 64) % 2 != 0 || a.out2 || a.tail_w) return hipErrorInvalidValue;
-    a.d_nct = make_fastdiv((unsigned)(a.CoutPad / 128));
-    a.d_bps = make_fastdiv((unsigned)a.blocks_per_strip);
-    a.d_strips = make_fastdiv((unsigned)a.strips);
-    a.d_pitch = make_fastdiv((unsigned)a.pitch);
-    a.d_h1 = make_fastdiv((unsigned)(a.H + 1));
-    const long long cap = num_cus / 8 * 8;
-    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
-    a.grid = (int)grid;
-    hipLaunchKernelGGL((conv3x3_halo_lckernel<HROWS>), dim3(grid), dim3(512), 0, stream, a);
-    return hipGetLastError();
-}
-
 template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false, bool SPLIT = false> hipError_t launch_h(HaloArgs a, hipStream_t stream) {
     const long long blocks = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -2158,9 +1813,6 @@ hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream
     // persistent form only where a block gets to walk several tiles (measured: -5..-8 % at 6-7 tiles per CU, -1..2 % at 1.75, but
     // +4 % when every block has exactly one tile: its per-tile bookkeeping then buys nothing)
     const long long tiles = (long long)a.strips * a.blocks_per_strip * (a.CoutPad / bn);
-    // loader / consumer form (fp16, 128-cout tile): opt-in while it is being measured (a.lc, WTK_HALO_LC=1)
-    if (a.lc && is_f16 && bn == 128 && a.slabs != 2 && !a.tail_w && !a.out2 && bm == kBM && a.persist_cus > 0 && nchunks % 2 == 0 && a.Cout == a.CoutPad)
-        return launch_hlc<kHaloRowsMax>(a, a.persist_cus, stream);
     if (a.slabs != 2 && !a.tail_w && bm == kBM && a.persist_cus > 0 && 2 * tiles >= 3 * (long long)a.persist_cus && nchunks % 2 == 0 && (bn == 128 || bn == 192)) {
         if (is_f16) return bn == 128 ? launch_hp<_Float16, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<_Float16, 192, kHaloRowsSmall>(a, a.persist_cus, stream);
         return bn == 128 ? launch_hp<float, 128, kHaloRowsMax>(a, a.persist_cus, stream) : launch_hp<float, 192, kHaloRowsSmall>(a, a.persist_cus, stream);

@@ -540,7 +540,6 @@ struct wtk_yolo {
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
     int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
-    int halo_lc = 0;    // WTK_HALO_LC=1: loader / consumer form of the persistent window kernel (fp16, 128-cout tiles)
     int ws64_weave = 0; // pixel tiles (of 4) of a 64-channel 3x3 tile whose epilogue rides on the next multiply phase (WTK_WS64_WEAVE=0..3; 0: the round-2 schedule)
     int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
     int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
@@ -932,7 +931,6 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
-    if (const char *e = std::getenv("WTK_HALO_LC")) h->halo_lc = e[0] == '1';
     if (const char *e = std::getenv("WTK_NO_S2WIN")) h->use_s2win = e[0] != '1';
     {
         hipDeviceProp_t prop;
@@ -1546,7 +1544,6 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     g.tail_f32 = h->bufs[t.out_buf].f32;
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
-                g.lc = h->halo_lc;
                 const int rows_max = (op.halo == 2 || h->split) ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
                 bool ws64 = false;
                 if (op.halo == 1 && h->use_ws64 && h->halo_slabs == 3 &&
