@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16", hybrid=False, comm=None):
+def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, scale="n", size=128, dtype="fp16", hybrid=False, comm=None, defer=1):
     """Shared by the rank processes and by the single-rank comparison run in the test.  `hybrid`: scale-s HybridDetector lanes (fp16 +
     an f16x3 second look at every row below the margin: ceiling = batch, so the replaced rows do not depend on how frames are batched)."""
     import torch
@@ -36,7 +36,10 @@ def run_pipeline(frames_np, batch, steps, rank, world, group, device, lanes, sca
     if hybrid:
         from wtracker_amd.hybrid import HybridDetector
 
-        dets = [HybridDetector(handle("fp16"), handle("f16x3"), margin=0.5, k=batch) for _ in range(lanes)]  # wide margin: plenty of rows take the second look
+        # wide margin: plenty of rows take the second look; defer > 1: the weak rows of `defer` steps of a lane share one full-precision pass, the
+        # lane's all-gathers and the ResMLP of those steps follow the flush (wtracker_amd/pipeline.py)
+        big = lambda: hip.HipYolo(w, (size, size), batch * defer, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch, device=device.index or 0)
+        dets = [HybridDetector(handle("fp16"), big(), margin=0.5, k=batch * defer, defer=defer) for _ in range(lanes)]
     else:
         dets = [handle(dtype) for _ in range(lanes)]
     mlp = hip.HipMLP(folded.layers, folded.n_blocks, folded.layers_per_block, device=device.index or 0)
@@ -65,6 +68,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--hybrid", action="store_true")
+    ap.add_argument("--defer", type=int, default=1)
     ap.add_argument("--wtkcomm", default="", help="rendezvous file: exchange tracks through the C ABI's own RCCL communicator (hip.WtkComm) instead of torch.distributed")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -95,7 +99,7 @@ def main():
             time.sleep(0.05)
         comm = hip.WtkComm(dev.index, rank, world, open(args.wtkcomm, "rb").read())
         frames_np, _ = fr.synthetic_frames(args.steps * args.batch * world, 128, seed=4)
-        out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes, hybrid=args.hybrid, comm=comm)
+        out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes, hybrid=args.hybrid, comm=comm, defer=args.defer)
         np.savez(args.out, **out)
         comm.close()
         return
@@ -104,7 +108,7 @@ def main():
     else:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     frames_np, _ = fr.synthetic_frames(args.steps * args.batch * world, 128, seed=4)
-    out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes, hybrid=args.hybrid)
+    out = run_pipeline(frames_np, args.batch, args.steps, rank, world, None, dev, args.lanes, hybrid=args.hybrid, defer=args.defer)
     np.savez(args.out, **out)
     dist.barrier()
     dist.destroy_process_group()

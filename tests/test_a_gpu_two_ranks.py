@@ -25,7 +25,9 @@ def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
 
     assert not torch.cuda.is_initialized(), "this test must run before anything touches the GPU in this process"
     world, B, steps = 2, 32, 4
-    for tag, extra in (("rank", []), ("hyb", ["--hybrid"])):  # two worlds of two ranks, one after the other, both before this process touches the GPU
+    # three worlds of two ranks, one after the other, all before this process touches the GPU ("hybd": deferred second look — the lanes'
+    # all-gathers and ResMLP steps follow their flushes)
+    for tag, extra in (("rank", []), ("hyb", ["--hybrid"]), ("hybd", ["--hybrid", "--defer", "2"])):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -65,11 +67,12 @@ def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
     # the hybrid lanes (fp16 + device-side f16x3 second look, merged BEFORE the exchange): the same rows are replaced however the frames are batched
     hyb = run_pipeline(frames_np, B * world, steps, 0, 1, None, torch.device("cuda", 0), lanes=1, hybrid=True)
     assert int(hyb["replaced"][0]) > 0
-    replaced = 0
-    for r in range(world):
-        z = np.load(tmp_path / f"hyb{r}.npz")
-        np.testing.assert_array_equal(z["track"], hyb["track"])
-        np.testing.assert_array_equal(z["valid"], hyb["valid"])
-        np.testing.assert_array_equal(z["moves"], hyb["moves"])
-        replaced += int(z["replaced"][0])
-    assert replaced == int(hyb["replaced"][0])  # every rank replaces the weak rows of its own share
+    for tag in ("hyb", "hybd"):
+        replaced = 0
+        for r in range(world):
+            z = np.load(tmp_path / f"{tag}{r}.npz")
+            np.testing.assert_array_equal(z["track"], hyb["track"], err_msg=tag)
+            np.testing.assert_array_equal(z["valid"], hyb["valid"], err_msg=tag)
+            np.testing.assert_array_equal(z["moves"], hyb["moves"], err_msg=tag)
+            replaced += int(z["replaced"][0])
+        assert replaced == int(hyb["replaced"][0]), tag  # every rank replaces the weak rows of its own share
