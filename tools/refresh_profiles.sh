@@ -7,6 +7,7 @@ cd "$(dirname "$0")/.."
 R=${1:-r02}
 python tools/stats_from_trace.py gpurun_out/pf_layers/bench_kernel_trace.csv > profiles/${R}_kernel_stats_single_stream_fp16_b64.csv
 cp gpurun_out/pf_stats/bench_kernel_stats.csv profiles/${R}_kernel_stats_bench_fp16_b64.csv
+if [ -f gpurun_out/pf_stats_hyb/bench_kernel_stats.csv ]; then cp gpurun_out/pf_stats_hyb/bench_kernel_stats.csv profiles/${R}_kernel_stats_bench_hybrid_b64.csv; fi
 python tools/layer_profile.py gpurun_out/pf_layers/bench_kernel_trace.csv > profiles/${R}_layer_table_bench_fp16_b64.txt
 cp gpurun_out/pf_fetch/p_counter_collection.csv profiles/${R}_pmc_fetch_size.csv
 cp gpurun_out/pf_write/p_counter_collection.csv profiles/${R}_pmc_write_size.csv
