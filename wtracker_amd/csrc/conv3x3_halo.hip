@@ -957,7 +957,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
                 for (int q = 0; q < kMaxPiecesPerWave; ++q) sel.hoff[q] = to_next ? nxt.hoff[q] : cur.hoff[q];
                 issue_piece(hnext, tap, sel, cn);
             }
+#ifdef WTK_TIMING_DEEP // TIMING experiment (garbage results): what would a slab ring one slot deeper buy?  The requests of the PREVIOUS tap may stay in flight too
+            {
+                const int prev_issued = tap == 0 ? WR + 1 : (WR + ((tap - 1) < kMaxPiecesPerWave ? 1 : 0));
+                wait_vmcnt(issued + prev_issued > 8 ? 8 : issued + prev_issued);
+            }
+#else
             wait_vmcnt(issued);
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (!(WTK_TIMING_SKIP & 4)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
