@@ -1,0 +1,151 @@
+"""CPU: the SCHEDULE of wtracker_amd.pipeline.TrackPipeline — which step's exchange and ResMLP run when — with stand-in detector and
+predictor objects (no GPU, no libwtk_hip.so call).  What is under test is host logic only:
+
+  * a detector that holds rows back (HybridDetector(defer = D): the rows of a call are final only after the lane's next flush) must not
+    let the ResMLP of a step run before the rows of that step AND of the step it looks back into are final, whatever the lane count;
+  * the all-gather of a step happens after its rows are final, so every rank ends with final rows only (two gloo ranks);
+  * steps that are never enqueued are gaps, not obstacles; flush() / synchronize() finalise a trailing partial group.
+
+The stand-ins make a violation visible: the detector writes PROVISIONAL rows (negative numbers) at predict time and the final rows only at
+its flush; the predictor copies what it sees of the track into its outputs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from wtracker_amd.pipeline import TrackPipeline
+
+
+class _Folded:
+    input_frames = [0, -2, -9, -11, -18, -20, -27]
+    pred_frames = [9]
+
+
+class HoldBackDetector:
+    """Rows of a call are -1 (provisional) until the flush that follows `defer` calls; final row of frame f = (f, 2f, 3, 4)."""
+
+    def __init__(self, defer: int):
+        self.defer, self.device, self.max_batch = defer, 0, 1 << 20
+        self._calls, self._waiting, self.flushes = 0, [], 0
+
+    @property
+    def pending(self):
+        return self._calls if self.defer > 1 else 0
+
+    def predict(self, frames_dev, B, H, W, C, out_xywh, out_conf=None, out_anchor=None, conf=0.1, iou=0.7, max_det=1, stream=0):
+        ids = frames_dev.reshape(B, -1)[:, 0].to(torch.float32)  # the test encodes the global frame number in the first pixel pair
+        ids = ids + 256.0 * frames_dev.reshape(B, -1)[:, 1].to(torch.float32)
+        final = torch.stack([ids, 2 * ids, torch.full_like(ids, 3.0), torch.full_like(ids, 4.0)], dim=1)
+        if self.defer <= 1:
+            out_xywh.copy_(final)
+            return
+        out_xywh.fill_(-1.0)
+        self._waiting.append((out_xywh, final))
+        self._calls += 1
+        if self._calls % self.defer == 0:
+            self.flush(stream)
+
+    def flush(self, stream=0):
+        for out, final in self._waiting:
+            out.copy_(final)
+        self._waiting, self._calls = [], 0
+        self.flushes += 1
+
+
+class CopyPredictor:
+    """moves[i] = (x of the anchor frame's row, x of the row 27 frames back); valid = both rows final (>= 0) and inside the track."""
+
+    def __init__(self):
+        self.launches = []
+
+    def predict_track(self, track, total_frames, anchors, n, input_frames, moves, valid, stream=0):
+        self.launches.append((int(anchors[0]), int(n)))
+        for i in range(n):
+            a = int(anchors[i])
+            back = a + min(input_frames)
+            if back < 0:
+                valid[i] = 0
+                moves[i] = 0
+                continue
+            moves[i, 0], moves[i, 1] = track[a, 0], track[back, 0]
+            valid[i] = 1 if (track[a, 0] >= 0 and track[back, 0] >= 0) else -1  # -1: the predictor saw a provisional or missing row
+
+
+def _frames(first, B):
+    f = torch.zeros((B, 4, 4), dtype=torch.uint8)
+    ids = torch.arange(first, first + B)
+    f[:, 0, 0] = (ids % 256).to(torch.uint8)
+    f[:, 0, 1] = (ids // 256).to(torch.uint8)
+    return f
+
+
+def _run(defer, lanes, steps=11, B=32, skip=(), world=1, rank=0, group=None):
+    dets = [HoldBackDetector(defer) for _ in range(lanes)]
+    mlp = CopyPredictor()
+    pipe = TrackPipeline(dets, mlp, _Folded(), B, steps * B * world, imaging_frame_num=6, pred_frame_num=3, cycle_frame_num=9, rank=rank, world=world,
+                         group=group, device=torch.device("cpu"))
+    for s in range(steps):
+        if s in skip:
+            continue
+        f0, _ = pipe.plan.local_range(s, rank)
+        pipe.step(s, _frames(f0, B))
+    pipe.synchronize()
+    return pipe.track.numpy().copy(), pipe.moves.numpy().copy(), pipe.valid.numpy().copy(), mlp.launches, dets
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+@pytest.mark.parametrize("defer", [2, 3, 5])
+def test_deferred_rows_never_reach_the_predictor_before_they_are_final(lanes, defer):
+    t1, m1, v1, l1, _ = _run(1, lanes)
+    td, md, vd, ld, dets = _run(defer, lanes)
+    np.testing.assert_array_equal(t1, td)
+    np.testing.assert_array_equal(v1, vd)
+    np.testing.assert_array_equal(m1, md)
+    assert (vd >= 0).all() and vd.sum() > 20          # no cycle was predicted from a provisional row
+    assert (td[:, 0] == np.arange(len(td))).all()     # every row final at the end (the trailing partial group was flushed)
+    assert all(d.pending == 0 for d in dets)
+    assert sum(n for _, n in ld) == sum(n for _, n in l1) == len(md)  # every cycle predicted exactly once
+    assert len(ld) < len(l1)                          # ... in fewer, larger launches (one per run of steps that became final together)
+
+
+def test_steps_that_are_never_enqueued_are_gaps_not_obstacles():
+    t, m, v, launches, _ = _run(3, 2, skip=(4, 5))
+    B = 32
+    assert np.isnan(t[4 * B : 6 * B]).all() and (t[: 4 * B, 0] >= 0).all() and (t[6 * B :, 0] >= 0).all()
+    # cycles whose rows (or look-back) fall into the gap come out invalid (-1 from the stand-in: it saw NaN), the others are predicted
+    assert (v == 1).sum() > 10 and (v == -1).sum() > 0
+
+
+def _rank_main(rank, world, port, defer, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _run(defer, 2, steps=7, B=32, world=world, rank=rank)
+    q.put((rank, out[0], out[1], out[2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("defer", [1, 3])
+def test_two_gloo_ranks_gather_final_rows_only(defer):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, defer, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = _run(1, 1, steps=7, B=64)  # one rank, the whole super-batch per step
+    for _, t, m, v in res:
+        np.testing.assert_array_equal(t, one[0])  # rank order == frame order, final rows only
+        np.testing.assert_array_equal(v, one[2])
+        np.testing.assert_array_equal(m, one[1])

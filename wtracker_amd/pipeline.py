@@ -83,6 +83,7 @@ class TrackPipeline:
         self.rank, self.world, self.group, self.comm = rank, world, group, comm
         self.conf = conf
         self.device = device or torch.device("cuda", self.dets[0].device)
+        self._cuda = self.device.type == "cuda"  # a CPU device runs the same schedule without streams / events (tests/test_pipeline_schedule.py drives it with stand-in detectors)
         self.plan = ShardPlan(batch, world, total_frames, imaging_frame_num, pred_frame_num, cycle_frame_num)
         lookback = -min(folded.input_frames) + pred_frame_num
         if len(self.dets) > 1 and self.plan.super_batch < lookback:
@@ -92,13 +93,13 @@ class TrackPipeline:
         # out pooled streams round-robin, and which hardware queue a stream sits on changes what runs concurrently with what)
         if streams is not None and len(streams) != n_lanes:
             raise ValueError("one stream per lane")
-        self.streams = list(streams) if streams is not None else ([torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 else [None])
+        self.streams = list(streams) if streams is not None else ([torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 and self._cuda else [None] * n_lanes)
         # A lane whose detector holds rows back (HybridDetector(defer = D): the weak rows of D calls share one full-precision pass) hands out
         # rows that are FINAL only after its next flush.  Everything downstream of the rows — the exchange between ranks and the ResMLP —
         # runs when a lane's rows become final, for every step that is final on ALL lanes by then; a detector without `defer` is final at
         # once and the schedule is the plain one (detect, exchange, predict, per step).
         self._ring = [max(int(getattr(d, "defer", 1)), 1) for d in self.dets]
-        self.final_ev = [torch.cuda.Event() for _ in range(n_lanes)]
+        self.final_ev = [torch.cuda.Event() if self._cuda else None for _ in range(n_lanes)]
         self.det_done = self.final_ev  # (older name)
         # device-resident track of the whole run: xywh per frame (NaN = no detection yet / none found)
         self.track = torch.full((total_frames, 4), float("nan"), dtype=torch.float32, device=self.device)
@@ -118,14 +119,15 @@ class TrackPipeline:
     def _finalize_lane(self, lane: int) -> int:
         """The rows of every step this lane holds are final in the order of the current stream (= the lane's): exchange them between the
         ranks, then run the ResMLP for the cycles of every step that is now final on all lanes.  Returns the cycles launched."""
-        cur = torch.cuda.current_stream(self.device)
-        st = cur.cuda_stream
+        cur = torch.cuda.current_stream(self.device) if self._cuda else None
+        st = cur.cuda_stream if cur is not None else 0
         for t, k in self._held[lane]:
             if self.world > 1:
                 exchange_tracks(self.track, self.local_xywh[lane][k], self.plan, t, self.group, self.comm, st)
             self._ready[t] = lane
         self._held[lane] = []
-        self.final_ev[lane].record(cur)
+        if cur is not None:
+            self.final_ev[lane].record(cur)
         # A final step can be processed once no lane still holds an earlier step back (the ResMLP of step t looks back into step t - 1);
         # steps that were never enqueued are gaps, not obstacles (their rows stay NaN and the cycles that need them come out invalid).
         first_held = min((t for h in self._held for t, _ in h), default=None)
@@ -133,7 +135,7 @@ class TrackPipeline:
         if not todo:
             return 0
         for other in range(len(self.dets)):  # the look-back of these steps reaches into rows that other lanes finalised on their own streams
-            if other != lane and self._calls[other] > 0:
+            if other != lane and self._calls[other] > 0 and cur is not None:
                 cur.wait_event(self.final_ev[other])
         n, i = 0, 0
         while i < len(todo):  # one launch per run of consecutive steps (their cycles are contiguous)
@@ -154,7 +156,7 @@ class TrackPipeline:
         H, W = frames_dev.shape[1], frames_dev.shape[2]
         C = frames_dev.shape[3] if frames_dev.dim() == 4 else 1
         det = self.dets[lane]
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = torch.cuda.current_stream(self.device).cuda_stream if self._cuda else 0
         f0, f1 = self.plan.local_range(s, 0)
         k = self._calls[lane] % self._ring[lane]
         self._calls[lane] += 1
@@ -194,7 +196,7 @@ class TrackPipeline:
             stream = self.streams[lane]
             if stream is None:
                 if getattr(det, "pending", 0):
-                    det.flush(torch.cuda.current_stream(self.device).cuda_stream)
+                    det.flush(torch.cuda.current_stream(self.device).cuda_stream if self._cuda else 0)
                 n += self._finalize_lane(lane)
             else:
                 with torch.cuda.stream(stream):
@@ -212,7 +214,8 @@ class TrackPipeline:
         n = len(self.plan.anchors)
         st = torch.cuda.current_stream(self.device)
         for ev in self.det_done:
-            st.wait_event(ev)
+            if ev is not None:
+                st.wait_event(ev)
         cycles = torch.arange(n, dtype=torch.int32, device=self.device)
         out = {}
         tgt = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
