@@ -797,6 +797,42 @@ def test_stride2_window_kernel_matches_implicit_gemm(hip_lib, monkeypatch, B, H,
     np.testing.assert_allclose(res_a[0][same & (res_r[2] >= 0)], res_r[0][same & (res_r[2] >= 0)], rtol=0, atol=0.05)
 
 
+@pytest.mark.parametrize("B,H,W", [(8, 640, 640), (3, 352, 224), (5, 1280, 736)])
+def test_split_32ch_window_kernel_matches_implicit_gemm(hip_lib, monkeypatch, B, H, W):
+    """conv3x3_c32_split_kernel (f16x3 handles: model.2's 32 -> 32 channel 3x3 layers with the window and all nine weight slabs in LDS,
+    one barrier per block) against the implicit-GEMM path it replaces (WTK_NO_C32S=1).  Both sum the same split products (hi.hi apart from
+    the 2^-11 cross terms) in fp32, in different orders: the two layers' outputs agree to a few fp32 ulps of their scale, the head logits
+    to 1e-4 of theirs, and the survivors are the same rows; two default runs are bit-identical.  Shapes: four 40-column strips (BASELINE
+    map), ragged strips on a small map (88 x 56), eight strips on a non-square map."""
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(B * H + W).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    table = ys.conv_table("s", 1)
+    idx = {nm: [i for i, t in enumerate(table) if t["name"] == nm][0] for nm in ("model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv2")}
+    outs = []
+    for off in ("1", "0", "0"):
+        monkeypatch.setenv("WTK_NO_C32S", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        nb = min(B, 4)
+        outs.append((res, det.debug_head(nb), {nm: det.debug_tensor(i, nb) for nm, i in idx.items()}))
+        det.close()
+    (res_r, (box_r, cls_r), t_r), (res_a, (box_a, cls_a), t_a), (res_b, (box_b, cls_b), t_b) = outs
+    for x, y in zip(res_a, res_b):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(cls_a, cls_b)
+    for nm in idx:
+        np.testing.assert_array_equal(t_a[nm], t_b[nm])
+        scale = max(1.0, float(np.abs(t_r[nm]).max()))
+        err = float(np.abs(t_a[nm] - t_r[nm]).max())
+        assert err <= 16 * scale * 2.0 ** -23, (nm, err, scale)
+    lscale = max(1.0, float(np.abs(cls_r).max()), float(np.abs(box_r).max()))
+    assert np.abs(cls_a - cls_r).max() < 1e-4 * lscale and np.abs(box_a - box_r).max() < 1e-4 * lscale
+    np.testing.assert_array_equal(res_a[2], res_r[2])
+    det_rows = res_r[2] >= 0
+    np.testing.assert_allclose(res_a[0][det_rows], res_r[0][det_rows], rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("H,W,C", [(128, 128, 1), (96, 160, 3)])
 def test_fused_front_and_c2f_tail_match_oracle_layers(hip_lib, H, W, C):
     """Layer-level parity of the two fused kernels against the CPU restatement (not only through the head logits):

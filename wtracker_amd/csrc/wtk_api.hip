@@ -539,6 +539,7 @@ struct wtk_yolo {
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
+    int use_c32s = 1;  // WTK_NO_C32S=1: the 32 -> 32 channel 3x3 layers of a split (f16x3) handle through conv_igemm_kernel (A/B switch)
     int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
     int ws64_weave = 0; // pixel tiles (of 4) of a 64-channel 3x3 tile whose epilogue rides on the next multiply phase (WTK_WS64_WEAVE=0..3; 0: the round-2 schedule)
     int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
@@ -835,6 +836,7 @@ struct Planner {
         op.halo = halo_eligible(op.k, op.stride, op.cin, h->is_f16) && h->use_halo ? 1 : 0;
         if (h->split) op.halo = split_halo_eligible(op.k, op.stride, op.cin, op.cout) && h->use_halo ? 1 : 0;
         if (!h->split && h->use_halo && c32_eligible(op.k, op.stride, op.cin, op.cout, h->is_f16, out2_buf >= 0)) op.halo = 2;
+        if (h->split && h->use_halo && h->use_c32s && c32_split_eligible(op.k, op.stride, op.cin, op.cout, out2_buf < 0 && in2_buf < 0 && !ob.f32)) op.halo = 2;
         op.macs_per_image = (double)ho * wo * cout * op.k * op.k * op.cin;
         if (pack_conv(h, op, wp, bp, couts)) {
             failed = true;
@@ -932,6 +934,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
     if (const char *e = std::getenv("WTK_NO_S2WIN")) h->use_s2win = e[0] != '1';
+    if (const char *e = std::getenv("WTK_NO_C32S")) h->use_c32s = e[0] != '1';
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
@@ -1544,7 +1547,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     g.tail_f32 = h->bufs[t.out_buf].f32;
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
-                const int rows_max = (op.halo == 2 || h->split) ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
+                const int rows_max = (op.halo == 2 && h->split) ? c32_split_rows_max() : (op.halo == 2 || h->split) ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
                 bool ws64 = false;
                 if (op.halo == 1 && h->use_ws64 && h->halo_slabs == 3 &&
                     ws64_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, h->is_f16, op.out2_buf >= 0, op.tail_op >= 0)) {
@@ -1579,7 +1582,9 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 }
                 g.zeros = h->zero_page;
                 if (ws64) {
-                } else if (h->split)
+                } else if (h->split && op.halo == 2)
+                    HIP_TRY(launch_conv3x3_c32_split(g, st));
+                else if (h->split)
                     HIP_TRY(launch_conv3x3_halo_split(g, st));
                 else if (op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32(g, st));

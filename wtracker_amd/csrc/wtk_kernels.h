@@ -259,6 +259,10 @@ hipError_t launch_conv3x3_ws64(const HaloArgs &a, int num_cus, hipStream_t strea
 // thin fp16 layers (Cin = 32, Cout <= 96): conv3x3_c32.hip
 bool c32_eligible(int k, int stride, int cin, int cout_stored, int is_f16, bool has_out2);
 hipError_t launch_conv3x3_c32(HaloArgs a, hipStream_t stream);
+// ... and the split-fp16 form of the 32 -> 32 channel layers (one 128-byte [hi32 | lo32] row per pixel); real channel counts here
+bool c32_split_eligible(int k, int stride, int cin, int cout, bool plain_out);
+int c32_split_rows_max();
+hipError_t launch_conv3x3_c32_split(HaloArgs a, hipStream_t stream); // channel counts / offsets but Cout in pseudo-channels
 
 // ---------------------------------------------------------------------------------------------
 // Stem: uint8 frame -> (BGR->RGB, /255) -> 3x3 stride-2 conv (Cin=3) + bias + SiLU -> NHWC.
