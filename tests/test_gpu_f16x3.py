@@ -47,6 +47,7 @@ def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, monkeypatch, H, W, C,
     product carries the error of an fp32 product (2^-22 relative per operand pair), so the tensors agree to fp32 rounding
     accumulated over the layers in front of them — three orders of magnitude below the fp16 mode's 2^-11 per layer."""
     B = 3
+    monkeypatch.setenv("WTK_FRONT_DEBUG", "1")  # the fused front (front_fused_split_kernel) also writes the model.0 / model.1 tensors it keeps in LDS
     monkeypatch.setenv("WTK_NO_HALO", no_halo)  # "1": every 3x3 conv through the split implicit GEMM instead of the split window kernels
     monkeypatch.setenv("WTK_NO_S2WIN", no_halo)
     rng = np.random.default_rng(H + W)
@@ -76,6 +77,36 @@ def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, monkeypatch, H, W, C,
     assert np.abs(cls_s - cls_r).max() < 2e-5 * lscale and np.abs(box_s - box_r).max() < 2e-5 * lscale
     np.testing.assert_array_equal(res_s[2], res_r[2])
     np.testing.assert_allclose(res_s[0], res_r[0], rtol=0, atol=2e-3, equal_nan=True)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(3, 128, 128, 1), (3, 96, 160, 3), (3, 352, 224, 1), (4, 640, 640, 3), (2, 1280, 736, 1)])
+def test_f16x3_fused_front_equals_layer_by_layer(hip_lib, monkeypatch, B, H, W, C):
+    """front_fused_split_kernel (preprocess + model.0 + model.1 + model.2.cv1 of an f16x3 handle in one persistent kernel, intermediates
+    as split rows in LDS) against the three stand-alone launches (WTK_NO_FUSED_FRONT=1): the same operands, K order and instruction
+    sequence per stage, so model.0, model.1 (test hook WTK_FRONT_DEBUG=1), model.2.cv1, every head logit and every result are
+    bit-identical — full tiles, ragged tiles (maps that are no multiple of the 16 x 4 tile), gray and BGR frames; two fused runs
+    catch a missing wait as a run-to-run difference."""
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    rng = np.random.default_rng(H * 7 + W + C)
+    frames = rng.integers(0, 256, size=(B, H, W) if C == 1 else (B, H, W, 3), dtype=np.uint8)
+    monkeypatch.setenv("WTK_FRONT_DEBUG", "1")
+    outs = []
+    for off in ("1", "0", "0"):
+        monkeypatch.setenv("WTK_NO_FUSED_FRONT", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        outs.append((res, det.debug_head(B), [det.debug_tensor(i, B) for i in (0, 1, 2, 3)]))  # model.0, model.1, model.2.cv1, model.2.cv2
+        det.close()
+    ref_res, (ref_box, ref_cls), ref_t = outs[0]
+    assert all(np.abs(t).max() > 0 for t in ref_t)
+    for res, (box, cls), ts in outs[1:]:
+        for t, r in zip(ts, ref_t):
+            np.testing.assert_array_equal(t, r)
+        np.testing.assert_array_equal(box, ref_box)
+        np.testing.assert_array_equal(cls, ref_cls)
+        for x, y in zip(res, ref_res):
+            np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize("size,B", [(640, 4), (1280, 2)])

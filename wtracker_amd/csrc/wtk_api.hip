@@ -1127,7 +1127,8 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         h->use_front = !off && h->ops.size() > 3 && h->ops[0].kind == OP_STEM && h->ops[1].kind == OP_CONV && h->ops[2].kind == OP_CONV &&
                        h->ops[1].k == 3 && h->ops[1].stride == 2 && h->ops[2].k == 1 && h->ops[1].act && h->ops[2].act &&
                        h->ops[2].out2_buf < 0 && h->ops[2].res_buf < 0 &&
-                       front_fused_eligible(h->is_f16, h->ops[0].cout, h->ops[1].cout, h->ops[2].cout);
+                       (front_fused_eligible(h->is_f16, h->ops[0].cout, h->ops[1].cout, h->ops[2].cout) ||
+                        (h->split && h->ops[1].cin == 32 && front_fused_split_eligible(h->ops[0].cout, h->ops[1].cout, h->ops[2].cout)));
         // ops[3..5] are the first C2f's bottleneck convs and cv2 (dims.n[0] == 1)
         const char *e2 = std::getenv("WTK_NO_FUSED_C2F");
         const bool off2 = e2 && e2[0] == '1';
@@ -1387,7 +1388,12 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         f.out_ld = h->bufs[o2.out_buf].C;
         f.out_coff = o2.out_coff;
         if (h->front_debug) f.dbg_t0 = h->bufs[o0.out_buf].ptr, f.dbg_t1 = h->bufs[o1.out_buf].ptr;
-        HIP_TRY(launch_front_fused(f, h->num_cus, st));
+        if (h->split) { // pseudo-channels (see the conv path below)
+            f.Kpad1 *= 2, f.Kpad2 *= 2, f.out_ld *= 2, f.out_coff *= 2;
+            f.n_dyn = h->n_dyn;
+            HIP_TRY(launch_front_fused_split(f, h->num_cus, st));
+        } else
+            HIP_TRY(launch_front_fused(f, h->num_cus, st));
         ++launches[5];
         flops[5] += op_flops(o0) + op_flops(o1) + op_flops(o2);
         first_op = 3;

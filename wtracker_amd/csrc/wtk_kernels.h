@@ -297,6 +297,7 @@ struct FrontArgs {
     int out_ld, out_coff;
     unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_FRONT_STAMPS) only: [grid][8 waves][8 stages] cycle sums
     void *dbg_t0, *dbg_t1; // test hook (normally null): also materialise model.0 [N][H/2][W/2][32] / model.1 [N][H/4][W/4][64]
+    const int *n_dyn;      // nullable: device-side image count <= N (front_fused_split_kernel: the tiles of images beyond it are not visited)
     int Ho, Wo, tiles_x, tiles_y, total_tiles; // filled by the launcher
     FastDiv d_tpi, d_tilesx;
 };
@@ -323,6 +324,10 @@ bool c2f_fused_eligible(int is_f16, int c_hidden, int n_bottlenecks, int shortcu
 hipError_t launch_c2f_fused(C2fArgs a, int num_cus, hipStream_t stream);
 
 bool front_fused_eligible(int is_f16, int c0, int c1, int c2_out);
+// split-fp16 ("f16x3") handles: front_fused_split.hip.  w0 = the fp32 stem packing, w1 / w2 split rows, Kpad1 / Kpad2 / out_ld /
+// out_coff in pseudo-channels (2 x real)
+bool front_fused_split_eligible(int c0, int c1, int c2_out);
+hipError_t launch_front_fused_split(FrontArgs a, int num_cus, hipStream_t stream);
 hipError_t launch_front_fused(FrontArgs a, int num_cus, hipStream_t stream);
 
 // Letterbox (ultralytics LetterBox, cv2.INTER_LINEAR fixed-point bilinear + pad 114) of uint8
