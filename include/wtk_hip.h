@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WTK_ABI_VERSION 5 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted; 5: + wtk_recheck_enqueue / _scatter (additive: every earlier entry point is unchanged) */
+#define WTK_ABI_VERSION 6 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted; 5: + wtk_recheck_enqueue / _scatter; 6: + wtk_hybrid_* (additive: every earlier entry point is unchanged) */
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
@@ -296,6 +296,43 @@ int wtk_recheck_enqueue(const float *margins_dev, int32_t B, float margin, const
 int wtk_recheck_scatter(int32_t *q_len_dev, int32_t q_cap, const float *src_xywh, const float *src_conf,
                         const int32_t *src_anchor, void **q_xywh_ptrs_dev, void **q_conf_ptrs_dev,
                         void **q_anchor_ptrs_dev, int32_t *n_replaced_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hybrid detector: the two-handle "look twice where fp16 is unsure" scheme above as ONE object behind this boundary, so that a
+ * C / C++ host gets the fast mode with full-precision decisions from a single call per batch — what YoloController.predict
+ * (yolo_controller.py:62-90, every frame in fp32: yolo/yolo_train_config.yaml:51 `half: False`) returns, at the fp16 handle's
+ * speed on the frames whose decision is clear.  `fast` and `exact` are wtk_yolo handles of the same model on the same device
+ * (typically WTK_F16 and WTK_F16X3); the object borrows them (the caller destroys them AFTER wtk_hybrid_destroy) and owns the
+ * exact handle's dynamic batch while it lives.
+ *   margin  rows whose fast-pass decision margin is below it are looked at again (choose it from measurements on the model:
+ *           see wtracker_amd/hybrid.py calibrate(); a fixed number is not a guarantee).
+ *   k       ceiling of rows per second look; 0 = the largest value that can never cut a weak row off (the whole batch; the
+ *           exact handle's max_batch in deferred mode).  A smaller k COUNTS what it cuts off (wtk_hybrid_counters).
+ *   defer   1: every call looks again before it returns its rows to the stream.  D > 1: the weak rows of D consecutive calls
+ *           share one full-precision pass (device-side queue of k frame copies); the rows a call named are final only after
+ *           the flush that follows — automatically on every D-th call, or wtk_hybrid_flush.  The output buffers named by a
+ *           call must stay valid until then; every call must bring frames of the same shape.
+ * Everything is enqueued on `stream`; no entry point but _counters synchronises.  One thread per object.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wtk_hybrid wtk_hybrid;
+int wtk_hybrid_create(wtk_hybrid **out, wtk_yolo *fast, wtk_yolo *exact, float margin, int32_t k, int32_t defer);
+void wtk_hybrid_destroy(wtk_hybrid *h);
+int wtk_hybrid_set_margin(wtk_hybrid *h, float margin);
+/* same arguments and results as wtk_yolo_predict with max_det = 1 */
+int wtk_hybrid_predict(wtk_hybrid *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf,
+                       float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream);
+/* same arguments and results as wtk_yolo_predict_views with max_det = 1; defer must be 1 */
+int wtk_hybrid_predict_views(wtk_hybrid *h, const uint8_t *frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t C,
+                             const int32_t *frame_index_dev, const int32_t *pos_xy_dev, int32_t B, int32_t view_w,
+                             int32_t view_h, float conf, float *out_xywh, float *out_conf, int32_t *out_anchor,
+                             void *stream);
+int wtk_hybrid_flush(wtk_hybrid *h, void *stream);
+/* calls whose weak rows still wait for their full-precision pass (0: every row handed out so far is final); -1 on a null handle */
+int wtk_hybrid_pending(wtk_hybrid *h);
+/* rows replaced so far / weak rows the ceiling cut off so far (must read 0 for the full-precision claim).  Synchronises the device. */
+int wtk_hybrid_counters(wtk_hybrid *h, int64_t *rows_replaced, int64_t *rows_overflowed);
+/* the configuration in effect: ceiling k, defer, margin (each nullable) */
+int wtk_hybrid_config(wtk_hybrid *h, int32_t *k, int32_t *defer, float *margin);
 
 /* ------------------------------------------------------------------------------------------
  * Detector on camera views of device-resident full frames: view cropping fused with the letterbox in front of

@@ -150,3 +150,109 @@ def test_pipeline_with_deferred_second_look_equals_the_immediate_one(hip_lib, go
     np.testing.assert_array_equal(m1, m3)
     assert r1 == r3 > 0 and n1 == n3 == len(m1) and o1 == o3 == 0 and p3 == [0] * lanes
     assert v1.sum() >= 10
+
+
+@pytest.mark.gpu
+def test_native_hybrid_object_through_the_c_abi(hip_lib):
+    """wtk_hybrid_* called directly (ctypes, raw device pointers): the error paths of create, and immediate / deferred / views forms against a
+    full-precision pass — with a margin that makes every row weak the merged rows ARE the full-precision rows, bit for bit."""
+    import ctypes as C
+
+    import torch
+
+    from wtracker_amd import frames as fr
+    from wtracker_amd import hip
+    from wtracker_amd import yolo_spec as ys
+
+    B, S = 6, 256
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    mk = lambda dtype, mb: hip.HipYolo(w, (S, S), mb, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch)
+    fast, exact, exact_ref = mk("fp16", B), mk("f16x3", 3 * B), mk("f16x3", B)
+    frames, _ = fr.synthetic_frames(3 * B, S, seed=11)
+    dev = torch.from_numpy(frames).cuda()
+    lib = hip_lib
+    vp = C.c_void_p
+    h = vp()
+    # ---- create: argument checks
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, fast._h, C.c_float(0.1), 0, 1) != 0 and b"two handles" in lib.wtk_last_error()
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, exact._h, C.c_float(0.1), 0, 0) != 0 and b"defer" in lib.wtk_last_error()
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, exact._h, C.c_float(0.1), 3 * B + 1, 1) != 0 and b"max_batch" in lib.wtk_last_error()
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, exact._h, C.c_float(float("nan")), 0, 1) != 0
+    small = hip.HipYolo(w, (128, 128), B, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, small._h, C.c_float(0.1), 0, 1) != 0 and b"same model" in lib.wtk_last_error()
+    small.close()
+    assert lib.wtk_hybrid_pending(None) == -1
+
+    def ref_rows(fb):
+        o = torch.empty((fb.shape[0], 4), dtype=torch.float32, device="cuda"), torch.empty((fb.shape[0],), dtype=torch.float32, device="cuda"), \
+            torch.empty((fb.shape[0],), dtype=torch.int32, device="cuda")
+        exact_ref.predict(fb, fb.shape[0], S, S, 1, *o, conf=0.1)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in o]
+
+    def outs(n):
+        return torch.full((n, 4), -7.0, dtype=torch.float32, device="cuda"), torch.full((n,), -7.0, dtype=torch.float32, device="cuda"), \
+            torch.full((n,), -7, dtype=torch.int32, device="cuda")
+
+    # ---- immediate form, every row weak (margin 1e9): rows = full-precision rows
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, exact._h, C.c_float(1e9), 0, 1) == 0, lib.wtk_last_error()
+    k, d, m = C.c_int32(), C.c_int32(), C.c_float()
+    assert lib.wtk_hybrid_config(h, C.byref(k), C.byref(d), C.byref(m)) == 0 and (k.value, d.value) == (B, 1) and m.value == 1e9
+    o = outs(B)
+    assert lib.wtk_hybrid_predict(h, vp(dev[:B].data_ptr()), B, S, S, 1, C.c_float(0.1), vp(o[0].data_ptr()), vp(o[1].data_ptr()), vp(o[2].data_ptr()), None) == 0
+    r, ov = C.c_int64(), C.c_int64()
+    assert lib.wtk_hybrid_counters(h, C.byref(r), C.byref(ov)) == 0 and (r.value, ov.value) == (B, 0)
+    for x, y in zip(o, ref_rows(dev[:B])):
+        np.testing.assert_array_equal(x.cpu().numpy(), y)
+    # views form: a 128 x 128 window of each frame, through both handles
+    pos = torch.tensor([[100 + 5 * i, 90 + 7 * i] for i in range(B)], dtype=torch.int32, device="cuda")
+    ov_ = outs(B)
+    assert lib.wtk_hybrid_predict_views(h, vp(dev.data_ptr()), 3 * B, S, S, 1, None, vp(pos.data_ptr()), B, 128, 128, C.c_float(0.1), vp(ov_[0].data_ptr()),
+                                        vp(ov_[1].data_ptr()), vp(ov_[2].data_ptr()), None) == 0
+    oe = outs(B)
+    exact_ref.predict_views(dev, 3 * B, S, S, 1, None, pos, B, 128, 128, *oe, conf=0.1)
+    torch.cuda.synchronize()
+    for x, y in zip(ov_, oe):
+        np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+    # margin 0: nothing is weak, the rows are the fast handle's
+    assert lib.wtk_hybrid_set_margin(h, C.c_float(0.0)) == 0
+    o0, of = outs(B), outs(B)
+    assert lib.wtk_hybrid_predict(h, vp(dev[:B].data_ptr()), B, S, S, 1, C.c_float(0.1), vp(o0[0].data_ptr()), vp(o0[1].data_ptr()), vp(o0[2].data_ptr()), None) == 0
+    fast.predict(dev[:B], B, S, S, 1, *of, conf=0.1)
+    torch.cuda.synchronize()
+    for x, y in zip(o0, of):
+        np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+    lib.wtk_hybrid_destroy(h)
+
+    # ---- deferred form: three calls share one pass (queue = the exact handle's 3 B rows); rows final after the automatic flush
+    h = vp()
+    assert lib.wtk_hybrid_create(C.byref(h), fast._h, exact._h, C.c_float(1e9), 0, 3) == 0, lib.wtk_last_error()
+    assert lib.wtk_hybrid_predict_views(h, vp(dev.data_ptr()), 3 * B, S, S, 1, None, vp(pos.data_ptr()), B, 128, 128, C.c_float(0.1), vp(ov_[0].data_ptr()), None, None,
+                                        None) != 0 and b"deferred" in lib.wtk_last_error()
+    od = [outs(B) for _ in range(3)]
+    for i in range(3):
+        assert lib.wtk_hybrid_pending(h) == i
+        assert lib.wtk_hybrid_predict(h, vp(dev[i * B:(i + 1) * B].data_ptr()), B, S, S, 1, C.c_float(0.1), vp(od[i][0].data_ptr()), vp(od[i][1].data_ptr()),
+                                      vp(od[i][2].data_ptr()), None) == 0
+    assert lib.wtk_hybrid_pending(h) == 0
+    assert lib.wtk_hybrid_counters(h, C.byref(r), C.byref(ov)) == 0 and (r.value, ov.value) == (3 * B, 0)
+    for i in range(3):
+        for x, y in zip(od[i], ref_rows(dev[i * B:(i + 1) * B])):
+            np.testing.assert_array_equal(x.cpu().numpy(), y)
+    # a partial group is finalised by wtk_hybrid_flush; frames of another shape are refused
+    o1 = outs(B)
+    assert lib.wtk_hybrid_predict(h, vp(dev[:B].data_ptr()), B, S, S, 1, C.c_float(0.1), vp(o1[0].data_ptr()), vp(o1[1].data_ptr()), vp(o1[2].data_ptr()), None) == 0
+    assert lib.wtk_hybrid_pending(h) == 1 and lib.wtk_hybrid_flush(h, None) == 0 and lib.wtk_hybrid_pending(h) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(o1[2].cpu().numpy(), ref_rows(dev[:B])[2])
+    assert lib.wtk_hybrid_predict(h, vp(dev.data_ptr()), 2, S, S // 2, 1, C.c_float(0.1), vp(o1[0].data_ptr()), None, None, None) != 0
+    lib.wtk_hybrid_destroy(h)
+    # the full-precision handle has its static batch back
+    oe2 = outs(2 * B)
+    exact.predict(dev[:2 * B], 2 * B, S, S, 1, *oe2, conf=0.1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oe2[2][:B].cpu().numpy(), ref_rows(dev[:B])[2])
+    np.testing.assert_array_equal(oe2[2][B:].cpu().numpy(), ref_rows(dev[B:2 * B])[2])
+    for d_ in (fast, exact, exact_ref):
+        d_.close()

@@ -288,7 +288,22 @@ __global__ __launch_bounds__(64) void recheck_scatter_kernel(const RecheckQueueA
     if (a.n_replaced) atomicAdd(a.n_replaced, 1);
 }
 
+// the weak rows' (frame, view centre) for the second look of the views entry point: row i of the second look = batch row slots[i]
+__global__ __launch_bounds__(64) void recheck_gather_views_kernel(const int *slots, int K, const int *frame_index, const int *pos_xy, int *idx_out, int *pos_out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= K) return;
+    const int b = slots[i];
+    idx_out[i] = frame_index ? frame_index[b] : b;
+    pos_out[2 * i] = pos_xy[2 * b], pos_out[2 * i + 1] = pos_xy[2 * b + 1];
+}
+
 } // namespace
+
+hipError_t launch_recheck_gather_views(const int *slots, int K, const int *frame_index, const int *pos_xy, int *idx_out, int *pos_out, hipStream_t stream) {
+    if (K <= 0 || !slots || !pos_xy || !idx_out || !pos_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recheck_gather_views_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, stream, slots, K, frame_index, pos_xy, idx_out, pos_out);
+    return hipGetLastError();
+}
 
 hipError_t launch_recheck_enqueue(const RecheckQueueArgs &a, hipStream_t stream) {
     if (a.B <= 0 || a.B > 1024 || a.q_cap <= 0 || a.frame_bytes <= 0 || a.frame_bytes % 16) return hipErrorInvalidValue;

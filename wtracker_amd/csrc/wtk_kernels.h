@@ -543,5 +543,7 @@ struct RecheckQueueArgs {
 };
 hipError_t launch_recheck_enqueue(const RecheckQueueArgs &a, hipStream_t stream);
 hipError_t launch_recheck_scatter(const RecheckQueueArgs &a, hipStream_t stream);
+// slots[i] (a batch row of the fast pass) -> frame index and view centre of row i of the second look (wtk_hybrid_predict_views)
+hipError_t launch_recheck_gather_views(const int *slots, int K, const int *frame_index, const int *pos_xy, int *idx_out, int *pos_out, hipStream_t stream);
 
 } // namespace wtk

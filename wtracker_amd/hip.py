@@ -59,6 +59,8 @@ SYMBOLS = [
     "wtk_yolo_margin_buffer", "wtk_yolo_last_margins_host",
     "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch", "wtk_yolo_set_side_streams",
     "wtk_release_cached_memory", "wtk_recheck_select_counted", "wtk_recheck_enqueue", "wtk_recheck_scatter",
+    "wtk_hybrid_create", "wtk_hybrid_destroy", "wtk_hybrid_set_margin", "wtk_hybrid_predict", "wtk_hybrid_predict_views", "wtk_hybrid_flush",
+    "wtk_hybrid_pending", "wtk_hybrid_counters", "wtk_hybrid_config",
 ]
 
 
@@ -156,6 +158,16 @@ def load() -> C.CDLL:
     lib.wtk_comm_destroy.restype = None
     lib.wtk_allgather_tracks.argtypes = [vp, vp, i32, vp, vp]
     lib.wtk_yolo_predict_views.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
+    lib.wtk_hybrid_create.argtypes = [C.POINTER(vp), vp, vp, f32, i32, i32]
+    lib.wtk_hybrid_destroy.argtypes = [vp]
+    lib.wtk_hybrid_destroy.restype = None
+    lib.wtk_hybrid_set_margin.argtypes = [vp, f32]
+    lib.wtk_hybrid_predict.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]
+    lib.wtk_hybrid_predict_views.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
+    lib.wtk_hybrid_flush.argtypes = [vp, vp]
+    lib.wtk_hybrid_pending.argtypes = [vp]
+    lib.wtk_hybrid_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.wtk_hybrid_config.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32)]
     _lib = lib
     return lib
 
@@ -409,6 +421,8 @@ class HipYolo:
         self.anchors = anchors.value
 
     def close(self):
+        for d in self.__dict__.pop("_dependents", []):  # native objects that borrow this handle (wtk_hybrid) go first
+            d._release()
         if getattr(self, "_h", None) is not None and self._h:
             load().wtk_yolo_destroy(self._h)
             self._h = None

@@ -34,118 +34,94 @@ import torch
 from . import hip
 
 
+class _Counter:
+    """A device counter of the native object read through wtk_hybrid_counters (synchronises): .item() / int()."""
+
+    def __init__(self, read):
+        self._read = read
+
+    def item(self) -> int:
+        return self._read()
+
+    def __int__(self) -> int:
+        return self._read()
+
+
 class HybridDetector:
+    """Thin shell over the library's wtk_hybrid object (include/wtk_hip.h): the orchestration — fast pass, slot selection or queue,
+    second look with a device-side dynamic batch, merge / scatter, counters — runs behind the C ABI; what stays here is the detector
+    interface TrackPipeline duck-types and `calibrate()` (host-side statistics over two passes)."""
+
     def __init__(self, fast: hip.HipYolo, exact: hip.HipYolo, margin: float = 0.04, k: int | None = None, defer: int = 1):
+        import ctypes as C
+
         if fast.device != exact.device:
             raise hip.WtkError("HybridDetector: both handles must live on the same device")
         if defer < 1:
             raise hip.WtkError("HybridDetector: defer >= 1")
-        self.defer = int(defer)
-        if k is None:
-            k = exact.max_batch if defer > 1 else min(fast.max_batch, exact.max_batch)
-        if k < 1 or k > exact.max_batch:
-            raise hip.WtkError("HybridDetector: 1 <= k <= max_batch of the full-precision handle")
-        self.fast, self.exact, self.margin, self.k = fast, exact, float(margin), int(k)
+        lib = hip.load()
+        self._h = C.c_void_p()
+        hip._check(lib.wtk_hybrid_create(C.byref(self._h), fast._h, exact._h, float(margin), 0 if k is None else int(k), int(defer)), "wtk_hybrid_create")
+        kk, dd = C.c_int32(), C.c_int32()
+        hip._check(lib.wtk_hybrid_config(self._h, C.byref(kk), C.byref(dd), None), "wtk_hybrid_config")
+        self.fast, self.exact, self.k, self.defer = fast, exact, int(kk.value), int(dd.value)
+        self._margin = float(margin)
         self.device, self.max_batch = fast.device, fast.max_batch
         self.dtype = f"{fast.dtype}+{exact.dtype}"
         self.macs_per_frame, self.anchors = fast.macs_per_frame, fast.anchors
-        dev = torch.device("cuda", self.device)
-        self._slots = torch.zeros((self.k,), dtype=torch.int32, device=dev)
-        self._xywh = torch.empty((self.k, 4), dtype=torch.float32, device=dev)
-        self._conf = torch.empty((self.k,), dtype=torch.float32, device=dev)
-        self._anchor = torch.empty((self.k,), dtype=torch.int32, device=dev)
-        self._pos = None  # view centre that makes a "view" the whole frame, per frame shape (defer = 1) / enqueue scratch (defer > 1)
-        self._idx_tmp = torch.empty((self.k,), dtype=torch.int32, device=dev)
-        self._pos_tmp = torch.empty((self.k, 2), dtype=torch.int32, device=dev)
-        self.replaced = torch.zeros((1,), dtype=torch.int32, device=dev)  # rows replaced so far (device counter)
-        self._n_weak = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows of the current batch: the second look's dynamic batch size
-        self.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)  # weak rows so far that the ceiling k cut off (0 by construction when k >= B)
-        exact.set_dynamic_batch(self._n_weak)
-        # ---- deferred mode (defer = D > 1): the weak rows of D consecutive calls share ONE full-precision pass (wtk_recheck_enqueue /
-        # wtk_recheck_scatter): `_n_weak` is then the length of a device-side queue of frame copies + output-row addresses.  The pass has a
-        # fixed cost of ~1.2 ms however few frames are live (62 launches of a few tiles each); per call that is 1.2 ms / D instead of 1.2 ms.
-        # With k >= D x (fast batch) no weak row can find the queue full.  A smaller queue (the full-precision pass launches its grids for k frames
-        # and the blocks of slots beyond the queue's length exit at once, ~5 us per unused slot: k should not be much larger than what is
-        # expected) COUNTS what it has to drop (`overflow`): such rows keep their fp16 result, and a caller that promises full-precision
-        # decisions must check the counter (bench.py does, and demotes the mode if it is not 0).
-        # Rows named in a call are FINAL only after the flush that follows (every D-th call, or flush()): `pending` says how many calls wait.
-        self._calls = 0
-        self._q_frames = None
-        self._q_shape = None
-        if self.defer > 1:
-            self._q_ptrs = [torch.zeros((self.k,), dtype=torch.int64, device=dev) for _ in range(3)]
-            self._pos = torch.empty((max(fast.max_batch, 1),), dtype=torch.int32, device=dev)
-        # (the second look keeps the default concurrency: with ONE pair of side streams per process, shared by every handle, its towers cost no
-        # extra streams — 17.7 k frames/s against 17.1 k with wtk_yolo_set_side_streams(0); with a pair per handle it was the other way round)
+        # the native object borrows the two handles: closing either of them first releases it (HipYolo.close)
+        for d in (fast, exact):
+            d.__dict__.setdefault("_dependents", []).append(self)
+        self.replaced = _Counter(lambda: self._counters()[0])  # rows replaced so far
+        self.overflow = _Counter(lambda: self._counters()[1])  # weak rows so far that the ceiling k cut off (0 by construction when k covers every call of a flush group)
+
+    # the threshold lives in the native object
+    @property
+    def margin(self) -> float:
+        return self._margin
+
+    @margin.setter
+    def margin(self, value: float):
+        hip._check(hip.load().wtk_hybrid_set_margin(self._h, float(value)), "wtk_hybrid_set_margin")
+        self._margin = float(value)
+
+    def _counters(self):
+        import ctypes as C
+
+        r, o = C.c_int64(), C.c_int64()
+        hip._check(hip.load().wtk_hybrid_counters(self._h, C.byref(r), C.byref(o)), "wtk_hybrid_counters")
+        return int(r.value), int(o.value)
 
     # -- the detector interface -------------------------------------------------------------------------------------------
     def predict(self, frames_dev, B: int, H: int, W: int, Cc: int, out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1,
                 iou: float = 0.7, max_det: int = 1, stream: int = 0):
+        import ctypes as C
+
         if max_det != 1:
             raise hip.WtkError("HybridDetector: max_det must be 1")
-        self.fast.predict(frames_dev, B, H, W, Cc, out_xywh, out_conf, out_anchor, conf=conf, iou=iou, max_det=1, stream=stream)
-        if self.defer > 1:
-            if self._q_frames is None:
-                self._q_shape = (H, W, Cc)
-                self._q_frames = torch.empty((self.k, H, W, Cc), dtype=torch.uint8, device=self._slots.device)
-            elif self._q_shape != (H, W, Cc):
-                raise hip.WtkError("HybridDetector(defer > 1): every call must bring frames of the same shape")
-            if (H * W * Cc) % 16:
-                raise hip.WtkError("HybridDetector(defer > 1): frames must be a multiple of 16 bytes")
-            hip.recheck_enqueue(self.fast.margin_buffer(), B, self.margin, frames_dev, H * W * Cc, self._q_frames, self.k, self._n_weak, *self._q_ptrs,
-                                out_xywh, out_conf, out_anchor, self._pos, self.overflow, stream=stream)
-            self._calls += 1
-            self._conf_thr = conf
-            if self._calls % self.defer == 0:
-                self.flush(stream)
-            return
-        k = min(self.k, B)
-        m = self.fast.margin_buffer()
-        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream, n_overflow_dev=self.overflow)
-        if self._pos is None or self._pos[0] != (H, W):
-            # wtk_yolo_predict_views cuts frame[y0 : y0 + view_w, x0 : x0 + view_h] with (x0, y0) = pos - (view_w // 2, view_h // 2)
-            # (view_controller.py:158-172): view (H, W) centred there is the frame itself
-            p = torch.tensor([[H // 2, W // 2]] * self.k, dtype=torch.int32).to(self._slots.device)
-            self._pos = ((H, W), p)
-        self.exact.predict_views(frames_dev, B, H, W, Cc, self._slots, self._pos[1], k, H, W, self._xywh, self._conf, self._anchor, conf=conf, iou=iou,
-                                 max_det=1, stream=stream)
-        hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
+        hip._check(hip.load().wtk_hybrid_predict(self._h, hip._ptr(frames_dev), B, H, W, Cc, conf, hip._ptr(out_xywh), hip._ptr(out_conf), hip._ptr(out_anchor),
+                                                 C.c_void_p(stream)), "wtk_hybrid_predict")
 
     @property
     def pending(self) -> int:
         """Calls whose weak rows still wait for their full-precision pass (deferred mode; 0 = every row handed out so far is final)."""
-        return self._calls if self.defer > 1 else 0
+        return int(hip.load().wtk_hybrid_pending(self._h))
 
     def flush(self, stream: int = 0):
         """Deferred mode: look again at everything queued so far and write the rows back (enqueued on `stream`, no host synchronisation)."""
-        if self.defer <= 1 or self._q_frames is None or self._calls == 0:
-            return
-        H, W, Cc = self._q_shape
-        self.exact.predict(self._q_frames, self.k, H, W, Cc, self._xywh, self._conf, self._anchor, conf=getattr(self, "_conf_thr", 0.1), max_det=1, stream=stream)
-        hip.recheck_scatter(self._n_weak, self.k, self._xywh, self._conf, self._anchor, *self._q_ptrs, self.replaced, stream=stream)
-        self._calls = 0
+        import ctypes as C
+
+        hip._check(hip.load().wtk_hybrid_flush(self._h, C.c_void_p(stream)), "wtk_hybrid_flush")
 
     def predict_views(self, frames_dev, n_frames: int, H: int, W: int, Cc: int, frame_index_dev, pos_xy_dev, B: int, view_w: int, view_h: int,
                       out_xywh, out_conf=None, out_anchor=None, conf: float = 0.1, iou: float = 0.7, max_det: int = 1, stream: int = 0):
+        import ctypes as C
+
         if max_det != 1:
             raise hip.WtkError("HybridDetector: max_det must be 1")
-        if self.defer > 1:
-            raise hip.WtkError("HybridDetector(defer > 1): the views entry point has no deferred form (use defer = 1)")
-        self.fast.predict_views(frames_dev, n_frames, H, W, Cc, frame_index_dev, pos_xy_dev, B, view_w, view_h, out_xywh, out_conf, out_anchor, conf=conf,
-                                iou=iou, max_det=1, stream=stream)
-        k = min(self.k, B)
-        m = self.fast.margin_buffer()
-        hip.recheck_select(m, B, k, self.margin, self._slots, self._n_weak, stream=stream, n_overflow_dev=self.overflow)
-        # the weak rows' (frame, position): gathered by torch on the caller's stream (it must be torch's current stream)
-        sl = self._slots[:k].long()
-        if frame_index_dev is None:
-            self._idx_tmp[:k] = self._slots[:k]
-        else:
-            torch.index_select(frame_index_dev, 0, sl, out=self._idx_tmp[:k])
-        torch.index_select(pos_xy_dev, 0, sl, out=self._pos_tmp[:k])
-        self.exact.predict_views(frames_dev, n_frames, H, W, Cc, self._idx_tmp, self._pos_tmp, k, view_w, view_h, self._xywh, self._conf, self._anchor,
-                                 conf=conf, iou=iou, max_det=1, stream=stream)
-        hip.recheck_merge(m, self._slots, B, k, self.margin, self._xywh, self._conf, self._anchor, out_xywh, out_conf, out_anchor, self.replaced, stream=stream)
+        hip._check(hip.load().wtk_hybrid_predict_views(self._h, hip._ptr(frames_dev), n_frames, H, W, Cc, hip._ptr(frame_index_dev), hip._ptr(pos_xy_dev), B, view_w,
+                                                       view_h, conf, hip._ptr(out_xywh), hip._ptr(out_conf), hip._ptr(out_anchor), C.c_void_p(stream)),
+                   "wtk_hybrid_predict_views")
 
     def calibrate(self, batches, H: int, W: int, Cc: int = 1, conf: float = 0.1, safety: float = 2.0, z: float = 6.0, floor: float = 0.02, tail: float = 1.5) -> dict:
         """Set `margin` from measurements on THIS model: every batch of `batches` (device uint8 tensors [B, H, W(, C)], B <= max_batch of both
@@ -161,7 +137,7 @@ class HybridDetector:
             raise hip.WtkError("calibrate: the full-precision handle must take whole batches (max_batch >= the fast handle's)")
         import numpy as np
 
-        self.exact.set_dynamic_batch(None)
+        self._suspend()  # the full-precision handle takes whole batches while it is measured
         dev = torch.device("cuda", self.device)
         worst, n_frames, n_bad, margins_bad, noise, all_margins = 0.0, 0, 0, [], [], []
         try:
@@ -183,7 +159,7 @@ class HybridDetector:
                     margins_bad.extend(float(v) for v in m[bad])
                     worst = max(worst, float(np.nanmax(m[bad])))
         finally:
-            self.exact.set_dynamic_batch(self._n_weak)
+            self._resume()
         noise = np.asarray(noise, dtype=np.float64)
         if len(noise) >= 8:
             mad = float(np.median(np.abs(noise - np.median(noise))))
@@ -195,6 +171,24 @@ class HybridDetector:
         share = float((np.asarray(all_margins) < self.margin).mean()) if all_margins else 0.0
         return {"frames": n_frames, "share_below_margin": share, "fast_mismatches": n_bad, "largest_mismatch_margin": worst, "margin_noise_sigma": sigma, "margin_noise_max_abs": d_max,
                 "safety": safety, "z": z, "tail": tail, "floor": floor, "margin": self.margin, "mismatch_margins_sorted_desc": sorted(margins_bad, reverse=True)[:8]}
+
+    def _suspend(self):
+        """Give the full-precision handle back its static batch (calibration): the native object is destroyed and re-created afterwards —
+        it holds no state worth keeping between flush groups but its counters, which are carried over."""
+        if self.pending:
+            raise hip.WtkError("HybridDetector: flush() before calibrating")
+        self._carry = self._counters()
+        hip.load().wtk_hybrid_destroy(self._h)
+        self._h = None
+
+    def _resume(self):
+        import ctypes as C
+
+        self._h = C.c_void_p()
+        hip._check(hip.load().wtk_hybrid_create(C.byref(self._h), self.fast._h, self.exact._h, self._margin, self.k, self.defer), "wtk_hybrid_create")
+        base = self._carry
+        self.replaced = _Counter(lambda: self._counters()[0] + base[0])
+        self.overflow = _Counter(lambda: self._counters()[1] + base[1])
 
     def overflow_count(self) -> int:
         """Weak rows (margin below the threshold) that kept their fp16 result because more than k rows of a batch were weak.  Synchronises."""
@@ -209,7 +203,18 @@ class HybridDetector:
     def get_kernel_profile(self) -> dict:
         return self.fast.get_kernel_profile()
 
+    def _release(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            hip.load().wtk_hybrid_destroy(self._h)  # hands the full-precision handle its static batch back
+        self._h = None
+
     def close(self):
+        self._release()
         self.fast.close()
-        self.exact.set_dynamic_batch(None)
         self.exact.close()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
