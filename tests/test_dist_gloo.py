@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -42,8 +43,7 @@ def _worker(rank, world, port, B, steps, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_allgather_matches_single_process():
-    world, B, steps = 2, 8, 5
+def _run_world(world, B, steps):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -63,6 +63,17 @@ def test_two_rank_gloo_allgather_matches_single_process():
         assert cycles[0][0] == 0 and all(cycles[i][1] == cycles[i + 1][0] for i in range(len(cycles) - 1))
     plan = ShardPlan(B, world, total, 6, 3, 9)
     assert res[0][2][-1][1] == len(plan.anchors)
+
+
+def test_two_rank_gloo_allgather_matches_single_process():
+    _run_world(2, 8, 5)
+
+
+@pytest.mark.parametrize("world,B,steps", [(3, 5, 4), (4, 8, 3)])
+def test_three_and_four_rank_gloo_allgather_matches_single_process(world, B, steps):
+    """The rank count of the driver's scaling runs is 1, 2, 4, 8: the interleaved super-batches and the gather must not assume two ranks
+    (odd world size and a batch that is no power of two included)."""
+    _run_world(world, B, steps)
 
 
 def test_shard_plan_single_rank_degenerate_case():
