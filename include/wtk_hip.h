@@ -331,6 +331,9 @@ int wtk_hybrid_flush(wtk_hybrid *h, void *stream);
 int wtk_hybrid_pending(wtk_hybrid *h);
 /* rows replaced so far / weak rows the ceiling cut off so far (must read 0 for the full-precision claim).  Synchronises the device. */
 int wtk_hybrid_counters(wtk_hybrid *h, int64_t *rows_replaced, int64_t *rows_overflowed);
+/* hold = 1: the full-precision handle gets its static batch back so that the caller can run it directly on whole batches (calibration of
+ * the margin); hold = 0: the object takes it again.  Needs wtk_hybrid_pending() == 0; predict / flush are refused while held. */
+int wtk_hybrid_hold(wtk_hybrid *h, int32_t hold);
 /* the configuration in effect: ceiling k, defer, margin (each nullable) */
 int wtk_hybrid_config(wtk_hybrid *h, int32_t *k, int32_t *defer, float *margin);
 

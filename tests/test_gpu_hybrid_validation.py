@@ -215,6 +215,14 @@ def test_native_hybrid_object_through_the_c_abi(hip_lib):
     torch.cuda.synchronize()
     for x, y in zip(ov_, oe):
         np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+    # hold: the full-precision handle is the caller's (whole batches), the object refuses to run meanwhile
+    assert lib.wtk_hybrid_hold(h, 1) == 0
+    assert lib.wtk_hybrid_predict(h, vp(dev[:B].data_ptr()), B, S, S, 1, C.c_float(0.1), vp(o[0].data_ptr()), None, None, None) != 0 and b"held" in lib.wtk_last_error()
+    oh = outs(2 * B)
+    exact.predict(dev[:2 * B], 2 * B, S, S, 1, *oh, conf=0.1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oh[2][B:].cpu().numpy(), ref_rows(dev[B:2 * B])[2])
+    assert lib.wtk_hybrid_hold(h, 0) == 0
     # margin 0: nothing is weak, the rows are the fast handle's
     assert lib.wtk_hybrid_set_margin(h, C.c_float(0.0)) == 0
     o0, of = outs(B), outs(B)

@@ -1970,6 +1970,7 @@ struct wtk_hybrid {
     int32_t *pos_scratch = nullptr;
     int calls = 0;
     float conf_thr = 0.1f;
+    bool held = false; // wtk_hybrid_hold: the full-precision handle is the caller's for a while
     std::vector<void *> allocs;
 };
 
@@ -2040,10 +2041,19 @@ extern "C" int wtk_hybrid_config(wtk_hybrid *h, int32_t *k, int32_t *defer, floa
     return 0;
 }
 
+extern "C" int wtk_hybrid_hold(wtk_hybrid *h, int32_t hold) {
+    if (!h) return fail("wtk_hybrid_hold: null handle");
+    if (h->defer > 1 && h->calls > 0) return fail("wtk_hybrid_hold: rows are pending (wtk_hybrid_flush first)");
+    if (wtk_yolo_set_dynamic_batch(h->exact, hold ? nullptr : h->n_weak)) return 1;
+    h->held = hold != 0;
+    return 0;
+}
+
 extern "C" int wtk_hybrid_pending(wtk_hybrid *h) { return h ? (h->defer > 1 ? h->calls : 0) : -1; }
 
 extern "C" int wtk_hybrid_flush(wtk_hybrid *h, void *stream) {
     if (!h) return fail("wtk_hybrid_flush: null handle");
+    if (h->held) return fail("wtk_hybrid_flush: the full-precision handle is held by the caller (wtk_hybrid_hold)");
     DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
     if (h->defer <= 1 || !h->q_frames || h->calls == 0) return 0;
     // the full-precision handle runs over the queue with its device-side dynamic batch = the queue's length; rows go back to the addresses queued with them
@@ -2061,6 +2071,7 @@ static int hybrid_select(wtk_hybrid *h, int B, int kk, void *stream) {
 extern "C" int wtk_hybrid_predict(wtk_hybrid *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
                                   float *out_conf, int32_t *out_anchor, void *stream) {
     if (!h) return fail("wtk_hybrid_predict: null handle");
+    if (h->held) return fail("wtk_hybrid_predict: the full-precision handle is held by the caller (wtk_hybrid_hold)");
     DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
     if (wtk_yolo_predict(h->fast, frames_dev, B, H, W, C, conf, 0.7f, 1, out_xywh, out_conf, out_anchor, stream)) return 1;
     if (h->defer > 1) {
@@ -2100,6 +2111,7 @@ extern "C" int wtk_hybrid_predict_views(wtk_hybrid *h, const uint8_t *frames_dev
                                         float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
     if (!h) return fail("wtk_hybrid_predict_views: null handle");
     if (h->defer > 1) return fail("wtk_hybrid_predict_views: the views entry point has no deferred form (create the object with defer = 1)");
+    if (h->held) return fail("wtk_hybrid_predict_views: the full-precision handle is held by the caller (wtk_hybrid_hold)");
     DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
     if (wtk_yolo_predict_views(h->fast, frames_dev, n_frames, H, W, C, frame_index_dev, pos_xy_dev, B, view_w, view_h, conf, 0.7f, 1, out_xywh, out_conf,
                                out_anchor, stream))

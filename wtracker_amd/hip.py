@@ -60,7 +60,7 @@ SYMBOLS = [
     "wtk_recheck_select", "wtk_recheck_merge", "wtk_yolo_set_dynamic_batch", "wtk_yolo_set_side_streams",
     "wtk_release_cached_memory", "wtk_recheck_select_counted", "wtk_recheck_enqueue", "wtk_recheck_scatter",
     "wtk_hybrid_create", "wtk_hybrid_destroy", "wtk_hybrid_set_margin", "wtk_hybrid_predict", "wtk_hybrid_predict_views", "wtk_hybrid_flush",
-    "wtk_hybrid_pending", "wtk_hybrid_counters", "wtk_hybrid_config",
+    "wtk_hybrid_pending", "wtk_hybrid_counters", "wtk_hybrid_config", "wtk_hybrid_hold",
 ]
 
 
@@ -166,6 +166,7 @@ def load() -> C.CDLL:
     lib.wtk_hybrid_predict_views.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
     lib.wtk_hybrid_flush.argtypes = [vp, vp]
     lib.wtk_hybrid_pending.argtypes = [vp]
+    lib.wtk_hybrid_hold.argtypes = [vp, i32]
     lib.wtk_hybrid_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.wtk_hybrid_config.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32)]
     _lib = lib

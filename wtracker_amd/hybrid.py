@@ -173,22 +173,11 @@ class HybridDetector:
                 "safety": safety, "z": z, "tail": tail, "floor": floor, "margin": self.margin, "mismatch_margins_sorted_desc": sorted(margins_bad, reverse=True)[:8]}
 
     def _suspend(self):
-        """Give the full-precision handle back its static batch (calibration): the native object is destroyed and re-created afterwards —
-        it holds no state worth keeping between flush groups but its counters, which are carried over."""
-        if self.pending:
-            raise hip.WtkError("HybridDetector: flush() before calibrating")
-        self._carry = self._counters()
-        hip.load().wtk_hybrid_destroy(self._h)
-        self._h = None
+        """The full-precision handle takes whole batches while it is measured (wtk_hybrid_hold)."""
+        hip._check(hip.load().wtk_hybrid_hold(self._h, 1), "wtk_hybrid_hold")
 
     def _resume(self):
-        import ctypes as C
-
-        self._h = C.c_void_p()
-        hip._check(hip.load().wtk_hybrid_create(C.byref(self._h), self.fast._h, self.exact._h, self._margin, self.k, self.defer), "wtk_hybrid_create")
-        base = self._carry
-        self.replaced = _Counter(lambda: self._counters()[0] + base[0])
-        self.overflow = _Counter(lambda: self._counters()[1] + base[1])
+        hip._check(hip.load().wtk_hybrid_hold(self._h, 0), "wtk_hybrid_hold")
 
     def overflow_count(self) -> int:
         """Weak rows (margin below the threshold) that kept their fp16 result because more than k rows of a batch were weak.  Synchronises."""
