@@ -30,6 +30,20 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.wtk_device_count() >= 0
 
 
+def test_binding_argument_counts_match_the_header(hip_lib):
+    """Every prototype of include/wtk_hip.h against the ctypes `argtypes` wtracker_amd.hip.load() declares: a parameter added to one side only
+    would otherwise surface as a corrupted call on the GPU box."""
+    text = open(os.path.join(ROOT, "include", "wtk_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = re.findall(r"\b(wtk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    assert sorted({n for n, _ in protos}) == header_symbols()
+    for name, params in protos:
+        p = params.strip()
+        n = 0 if p in ("", "void") else p.count(",") + 1
+        at = getattr(hip_lib, name).argtypes
+        assert (0 if at is None else len(at)) == n, (name, n, at)
+
+
 @pytest.mark.parametrize("scale,nc", [("n", 1), ("s", 1), ("s", 80), ("m", 3)])
 def test_conv_table_matches_python_spec(hip_lib, scale, nc):
     w, d, m = ys.scale_params(scale)
