@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DWTK_FRONT_STAMPS -I wtracker_amd/csrc tools/front_split_stamps.hip -o /tmp/front_split_stamps
 #include "../wtracker_amd/csrc/front_fused_split.hip"
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -23,10 +24,10 @@ int main(int argc, char **argv) {
     const int cus = prop.multiProcessorCount;
     std::vector<uint8_t> fr((size_t)N * S * S);
     for (auto &v : fr) v = (uint8_t)(std::rand() & 0xff);
-    std::vector<float> w0(32 * 9 * 4);
+    std::vector<float> w0(2048); // fp32 packing (1152 floats) or split packing (4096 halves): either fits, values are arbitrary small numbers
     std::vector<uint16_t> w1(64 * 576), w2(64 * 128);
     auto rh = []() { return (uint16_t)(0x2800 + (std::rand() & 0x3ff) + ((std::rand() & 1) << 15)); }; // ~ +-0.03..0.06
-    for (auto &v : w0) v = 0.05f * (float)((std::rand() & 0xff) - 128) / 128.0f;
+    for (auto &v : w0) { const uint16_t hb = rh(); const uint32_t wd = (uint32_t)hb | ((uint32_t)rh() << 16); std::memcpy(&v, &wd, 4); } // two small fp16 numbers per word = one small-ish fp32 number
     for (auto &v : w1) v = rh();
     for (auto &v : w2) v = rh();
     std::vector<float> b(64, 0.01f);
@@ -49,6 +50,7 @@ int main(int argc, char **argv) {
     wtk::FrontArgs a{};
     a.frames = dfr, a.N = N, a.H = S, a.W = S, a.C = 1;
     a.w0 = dw0, a.b0 = db, a.w1 = dw1, a.b1 = db, a.Kpad1 = 576, a.w2 = dw2, a.b2 = db, a.Kpad2 = 128;
+    a.stem_split = argc > 3 ? std::atoi(argv[3]) : 1;
     a.out = dout, a.out_ld = 192, a.out_coff = 0;
     a.dbg_stamps = dst;
     hipEvent_t e0, e1;

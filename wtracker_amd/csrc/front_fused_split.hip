@@ -43,7 +43,8 @@ constexpr int kStemIters = (kStemTiles + 7) / 8; // 3
 constexpr int kW1Bytes = 9 * 64 * 128; // [tap][cout] rows [hi32 | lo32]
 constexpr int kW2Bytes = 2 * 64 * 128; // [block of 32 input channels][cout] rows
 constexpr int kSBytes = kSRows * 128;
-constexpr int kPBytes = kPR * kPC * 16;
+constexpr int kPBytes = kPR * kPC * 16;   // fp32 form: (R,G,B,0) fp32 per pixel; split form: 8 bytes of hi halves per pixel, then the lo halves
+constexpr int kPHalf = kPR * kPC * 8;
 constexpr int kO1Bytes = 2 * 64 * 128; // [block of 32 channels][pixel] rows
 constexpr int kPOBytes = ((kPBytes > kO1Bytes ? kPBytes : kO1Bytes) + 63) / 64 * 64;
 static_assert(kW1Bytes + kW2Bytes + kSBytes + kPOBytes + 1024 <= 160 * 1024, "LDS budget");
@@ -80,7 +81,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8 &hv, half8 &lv
     }
 }
 
-template <bool DBG>
+// SS: the stem on split operands (default of the handles; FrontArgs::stem_split) instead of the fp32 matrix instructions (WTK_STEM_FP32=1)
+template <bool DBG, bool SS>
 __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontArgs a) {
     __shared__ __attribute__((aligned(16))) char w1s[kW1Bytes];
     __shared__ __attribute__((aligned(16))) char w2s[kW2Bytes];
@@ -95,7 +97,15 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
     int total_tiles = a.total_tiles;
     if (a.n_dyn) total_tiles = min(max(*a.n_dyn, 0), a.N) * tpi; // dynamic batch: the tiles of the first *n_dyn images
     if ((int)blockIdx.x >= total_tiles) return;
-    if (tid < 256) norm_lut[tid] = (float)tid / 255.0f;
+    if (tid < 256) {
+        const float x = (float)tid / 255.0f;
+        if constexpr (SS) { // the split pair of the normalised byte: hi in the low half of the word, lo in the high half
+            const _Float16 hi = (_Float16)x, lo = (_Float16)((x - (float)hi) * kSplitScale);
+            norm_lut[tid] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16));
+        } else {
+            norm_lut[tid] = x;
+        }
+    }
 
     // ---- one-time: model.1 and cv1 weights -> LDS (LDS-DMA, swizzle applied on the source chunk); row key of cout co:
     // ((co >> 1) & 1) | (((co >> 3) & 3) << 1) — with the lane -> row map (lr >> 2) * 8 + (lr & 3) + 4 i of stages C / D the
@@ -127,9 +137,31 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
         }
     }
 
-    // ---- stem weights -> registers (stem_mfma_kernel<float, 2>'s packing and lane map: [cout][9 taps][4] fp32, lane holds k = lg)
-    float wf0[2][9];
-    {
+    // ---- stem weights -> registers.  fp32 form: stem_mfma_kernel<float, 2>'s packing and lane map ([cout][9 taps][4] fp32, lane holds k = lg);
+    // split form: stem_mfma_kernel<_Float16, 2, true>'s ([cout][16 taps][4] hi halves, then the lo halves; lane holds taps 2 lg, 2 lg + 1 of a k-step)
+    float wf0[SS ? 1 : 2][SS ? 1 : 9];
+    half8 wh0[SS ? 2 : 1][SS ? 2 : 1], wl0[SS ? 2 : 1][SS ? 2 : 1];
+    int tap_off[2][2] = {{0, 0}, {0, 0}};
+    if constexpr (SS) {
+        const _Float16 *w0 = reinterpret_cast<const _Float16 *>(a.w0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co = (lr >> 2) * 8 + i * 4 + (lr & 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                wh0[i][ks] = *reinterpret_cast<const half8 *>(w0 + (co * 16 + ks * 8 + 2 * lg) * 4);
+                wl0[i][ks] = *reinterpret_cast<const half8 *>(w0 + 32 * 64 + (co * 16 + ks * 8 + 2 * lg) * 4);
+            }
+        }
+        // per-lane patch offsets of the two taps this lane feeds in each k-step; taps 9..15 have zero weights and may read any finite value: offset 0
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int tap = ks * 8 + 2 * lg + hh;
+                tap_off[ks][hh] = tap < 9 ? ((tap * 11) >> 5) * kPC + (tap - 3 * ((tap * 11) >> 5)) : 0;
+            }
+    } else {
         const float *w0 = reinterpret_cast<const float *>(a.w0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -219,27 +251,40 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
         int n, oy0, ox0;
         tile_coords(tile, n, oy0, ox0);
 
-        // ======== A: raw registers -> P (RGB0 fp32, byte / 255 as the stand-alone stem divides)
+        // ======== A: raw registers -> P.  fp32 form: (R,G,B,0) fp32, byte / 255 as the stand-alone stem divides; split form: the hi halves of the
+        // four pixels (8 bytes each) in the first half of P, their lo halves in the second
         if (tid < kUnits) {
-            floatx4 px[4];
+            uint32_t w3[4][3]; // table words of the (R, G, B) bytes of the unit's four pixels
             if (a.C == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = norm_lut[(raw[0] >> (8 * j)) & 0xffu];
-                    px[j] = (floatx4){v, v, v, 0.f};
-                }
+                for (int j = 0; j < 4; ++j) w3[j][0] = w3[j][1] = w3[j][2] = __builtin_bit_cast(uint32_t, norm_lut[(raw[0] >> (8 * j)) & 0xffu]);
             } else {
                 const uint64_t d01 = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
                 const uint64_t d12 = (uint64_t)raw[1] | ((uint64_t)raw[2] << 32);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { // pixel j = bytes 3j (B), 3j+1 (G), 3j+2 (R) of the 12-byte unit
                     const uint32_t bgr = j < 2 ? (uint32_t)(d01 >> (24 * j)) : (uint32_t)(d12 >> (24 * j - 32));
-                    px[j] = (floatx4){norm_lut[(bgr >> 16) & 0xffu], norm_lut[(bgr >> 8) & 0xffu], norm_lut[bgr & 0xffu], 0.f};
+                    w3[j][0] = __builtin_bit_cast(uint32_t, norm_lut[(bgr >> 16) & 0xffu]);
+                    w3[j][1] = __builtin_bit_cast(uint32_t, norm_lut[(bgr >> 8) & 0xffu]);
+                    w3[j][2] = __builtin_bit_cast(uint32_t, norm_lut[bgr & 0xffu]);
                 }
             }
-            floatx4 *dstp = reinterpret_cast<floatx4 *>(pobuf + tid * 64); // (pr*68 + 4*pu) * 16 = tid * 64
+            if constexpr (SS) {
+                uint4 hi[2], lo[2]; // pixel j: (R | G << 16, B) of the hi halves, the same of the lo halves
+                uint32_t *hw = reinterpret_cast<uint32_t *>(hi), *lw = reinterpret_cast<uint32_t *>(lo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dstp[j] = px[j];
+                for (int j = 0; j < 4; ++j) {
+                    hw[2 * j] = (w3[j][0] & 0xffffu) | (w3[j][1] << 16), hw[2 * j + 1] = w3[j][2] & 0xffffu;
+                    lw[2 * j] = (w3[j][0] >> 16) | (w3[j][1] & 0xffff0000u), lw[2 * j + 1] = w3[j][2] >> 16;
+                }
+                uint4 *dh = reinterpret_cast<uint4 *>(pobuf + tid * 32), *dl = reinterpret_cast<uint4 *>(pobuf + kPHalf + tid * 32);
+                dh[0] = hi[0], dh[1] = hi[1], dl[0] = lo[0], dl[1] = lo[1];
+            } else {
+                floatx4 *dstp = reinterpret_cast<floatx4 *>(pobuf + tid * 64); // (pr*68 + 4*pu) * 16 = tid * 64
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dstp[j] = (floatx4){__builtin_bit_cast(float, w3[j][0]), __builtin_bit_cast(float, w3[j][1]), __builtin_bit_cast(float, w3[j][2]), 0.f};
+            }
         }
         STAMP(0);
         flush_pending(); // previous tile's output -> global
@@ -251,25 +296,57 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
         {
             // all matrix instructions of the wave's (up to three) pixel tiles first — six independent accumulator chains — then the
             // SiLU + split epilogues, which run beside the matrix work of the SIMD's other wave
-            const float *patch = reinterpret_cast<const float *>(pobuf);
             const bool third = wave + 16 < kStemTiles; // wave uniform: waves 0..2 own a third tile
-            floatx4 acc[kStemIters][2];
+            floatx4 acc[kStemIters][2], acc1[SS ? kStemIters : 1][2];
 #pragma unroll
             for (int it = 0; it < kStemIters; ++it)
                 acc[it][0] = (floatx4){bias0[0], bias0[1], bias0[2], bias0[3]}, acc[it][1] = (floatx4){bias0[4], bias0[5], bias0[6], bias0[7]};
+            if constexpr (SS) {
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                const half4 *ph4 = reinterpret_cast<const half4 *>(pobuf), *pl4 = reinterpret_cast<const half4 *>(pobuf + kPHalf);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int off = (tap / 3) * kPC + tap % 3;
-                float pv[kStemIters];
+                for (int it = 0; it < kStemIters; ++it) acc1[it][0] = acc1[it][1] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int it = 0; it < kStemIters; ++it)
-                    if (it < 2 || third) pv[it] = patch[(st_pb[it] + off) * 4 + lg];
+                for (int ks = 0; ks < 2; ++ks) {
+                    half8 ph[kStemIters], pl[kStemIters];
 #pragma unroll
-                for (int it = 0; it < kStemIters; ++it)
-                    if (it < 2 || third) {
+                    for (int it = 0; it < kStemIters; ++it)
+                        if (it < 2 || third) {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[it][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[i][tap], pv[it], acc[it][i], 0, 0, 0);
-                    }
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const half4 vh = ph4[st_pb[it] + tap_off[ks][hh]], vl = pl4[st_pb[it] + tap_off[ks][hh]];
+                                ph[it][4 * hh + 0] = vh.x, ph[it][4 * hh + 1] = vh.y, ph[it][4 * hh + 2] = vh.z, ph[it][4 * hh + 3] = vh.w;
+                                pl[it][4 * hh + 0] = vl.x, pl[it][4 * hh + 1] = vl.y, pl[it][4 * hh + 2] = vl.z, pl[it][4 * hh + 3] = vl.w;
+                            }
+                        }
+#pragma unroll
+                    for (int it = 0; it < kStemIters; ++it)
+                        if (it < 2 || third) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                acc[it][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0[i][ks], ph[it], acc[it][i], 0, 0, 0);
+                                acc1[it][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0[i][ks], ph[it], acc1[it][i], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) acc1[it][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0[i][ks], pl[it], acc1[it][i], 0, 0, 0);
+                        }
+                }
+            } else {
+                const float *patch = reinterpret_cast<const float *>(pobuf);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = (tap / 3) * kPC + tap % 3;
+                    float pv[kStemIters];
+#pragma unroll
+                    for (int it = 0; it < kStemIters; ++it)
+                        if (it < 2 || third) pv[it] = patch[(st_pb[it] + off) * 4 + lg];
+#pragma unroll
+                    for (int it = 0; it < kStemIters; ++it)
+                        if (it < 2 || third) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) acc[it][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[i][tap], pv[it], acc[it][i], 0, 0, 0);
+                        }
+                }
             }
 #pragma unroll
             for (int it = 0; it < kStemIters; ++it) {
@@ -281,7 +358,12 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[i * 4 + r] = acc[it][i][r];
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (SS)
+                            t[i * 4 + r] = acc[it][i][r] + ffs_pin(acc1[it][i][r] * kSplitInv);
+                        else
+                            t[i * 4 + r] = acc[it][i][r];
+                    }
                 wtk_silu_scaled_run<8, !WTK_FFS_PACKED>(t);
                 half8 hv, lv;
                 split8(t, hv, lv);
@@ -425,10 +507,18 @@ hipError_t launch_front_fused_split(FrontArgs a, int num_cus, hipStream_t stream
     a.d_tpi = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y));
     a.d_tilesx = make_fastdiv((unsigned)a.tiles_x);
     const unsigned grid = (unsigned)(total < num_cus ? total : num_cus);
-    if (a.dbg_t0 && a.dbg_t1)
-        hipLaunchKernelGGL(front_fused_split_kernel<true>, dim3(grid), dim3(512), 0, stream, a);
-    else
-        hipLaunchKernelGGL(front_fused_split_kernel<false>, dim3(grid), dim3(512), 0, stream, a);
+    const bool dbg = a.dbg_t0 && a.dbg_t1;
+    if (a.stem_split) {
+        if (dbg)
+            hipLaunchKernelGGL((front_fused_split_kernel<true, true>), dim3(grid), dim3(512), 0, stream, a);
+        else
+            hipLaunchKernelGGL((front_fused_split_kernel<false, true>), dim3(grid), dim3(512), 0, stream, a);
+    } else {
+        if (dbg)
+            hipLaunchKernelGGL((front_fused_split_kernel<true, false>), dim3(grid), dim3(512), 0, stream, a);
+        else
+            hipLaunchKernelGGL((front_fused_split_kernel<false, false>), dim3(grid), dim3(512), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

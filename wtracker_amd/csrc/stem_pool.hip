@@ -29,10 +29,15 @@ template <> struct StemElem<float> {
     using px_t = float4;
 };
 
-template <typename T, int TC>
+// SPLIT (T = fp16, split-fp16 handles): pixels / 255 and the weights as split pairs (hi = fp16(x), lo = fp16((x - hi) * 2^11), wtk_kernels.h):
+// per k-step acc += Wh.Xh; acc1 += Wl.Xh; acc1 += Wh.Xl, value = acc + 2^-11 acc1 — the arithmetic of every other conv of such a handle, a third of
+// the matrix time of the fp32 path; split store.  a.w = [Cout][16][4] hi halves followed by [Cout][16][4] lo halves.
+template <typename T, int TC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
     using px_t = typename StemElem<T>::px_t;
+    static_assert(!SPLIT || (sizeof(T) == 2 && TC % 2 == 0), "split stem: fp16 operands, 32-channel blocks");
     __shared__ __attribute__((aligned(16))) px_t patch[kStemPatch * kStemPatch + 3];
+    __shared__ __attribute__((aligned(16))) px_t patch_lo[SPLIT ? kStemPatch * kStemPatch + 3 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int tiles_x = (a.Wo + 15) >> 4, tiles_y = (a.Ho + 15) >> 4;
@@ -62,6 +67,11 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
         px_t v;
         v.x = (T)r, v.y = (T)g, v.z = (T)b, v.w = (T)0.f;
         patch[i] = v;
+        if constexpr (SPLIT) {
+            px_t l;
+            l.x = (T)((r - (float)v.x) * kSplitScale), l.y = (T)((g - (float)v.y) * kSplitScale), l.z = (T)((b - (float)v.z) * kSplitScale), l.w = (T)0.f;
+            patch_lo[i] = l;
+        }
     }
 
     // ---- weights -> registers.  cout of (tile tc, MFMA row r): (r>>2)*4*TC + tc*4 + (r&3)
@@ -76,7 +86,51 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
     }
     __syncthreads();
 
-    if constexpr (sizeof(T) == 2) {
+    floatx4_s acc1[SPLIT ? TC : 1][SPLIT ? 4 : 1]; // split mode: the 2^-11 cross terms
+    if constexpr (SPLIT) {
+        typedef _Float16 half8_s __attribute__((ext_vector_type(8)));
+        const _Float16 *w = reinterpret_cast<const _Float16 *>(a.w);
+        const _Float16 *wlo = w + (long long)a.Cout * 64;
+        half8_s wh[TC][2], wl[TC][2];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co = (lr >> 2) * 4 * TC + i * 4 + (lr & 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                wh[i][ks] = *reinterpret_cast<const half8_s *>(w + (co * 16 + ks * 8 + 2 * lg) * 4);
+                wl[i][ks] = *reinterpret_cast<const half8_s *>(wlo + (co * 16 + ks * 8 + 2 * lg) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[i][j] = (floatx4_s){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = (wave * 4 + j) * 2, px = lr * 2;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8_s ph, pl;
+                const int tap0 = ks * 8 + 2 * lg;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tap = tap0 + h;
+                    half4_s vh = (half4_s){0, 0, 0, 0}, vl = vh;
+                    if (tap < 9) {
+                        vh = patch[(py + tap / 3) * kStemPatch + px + tap % 3];
+                        vl = patch_lo[(py + tap / 3) * kStemPatch + px + tap % 3];
+                    }
+                    ph[4 * h + 0] = vh.x, ph[4 * h + 1] = vh.y, ph[4 * h + 2] = vh.z, ph[4 * h + 3] = vh.w;
+                    pl[4 * h + 0] = vl.x, pl[4 * h + 1] = vl.y, pl[4 * h + 2] = vl.z, pl[4 * h + 3] = vl.w;
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i][ks], ph, acc[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i][ks], ph, acc1[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i][ks], pl, acc1[i][j], 0, 0, 0);
+            }
+        }
+    } else if constexpr (sizeof(T) == 2) {
         typedef _Float16 half8_s __attribute__((ext_vector_type(8)));
         // packed weights: [cout][16 taps][4] fp16, taps 9..15 zero; lane holds k = 8*lg .. 8*lg+7 = taps 2lg, 2lg+1
         const _Float16 *w = reinterpret_cast<const _Float16 *>(a.w);
@@ -141,9 +195,14 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
         for (int i = 0; i < TC; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = acc[i][j][r]; // bias already inside
+                float s = acc[i][j][r]; // bias already inside
+                if constexpr (SPLIT) s += acc1[i][j][r] * kSplitInv;
                 v[i * 4 + r] = wtk_silu_scaled(s);
             }
+        if constexpr (SPLIT) { // one pixel = 2 * Cout halves
+            wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out) + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout * 2, cb, v);
+            continue;
+        }
         T *o = out + (((long long)n * a.Ho + oy) * a.Wo + ox) * a.Cout + cb;
         if constexpr (sizeof(T) == 4 && NV % 8 == 0) {
             if (a.out_split) { // one pixel = 2 * Cout halves = Cout floats
@@ -170,11 +229,17 @@ hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream) {
     if ((a.Cout != 16 && a.Cout != 32 && a.Cout != 48 && a.Cout != 64) || (a.C != 1 && a.C != 3)) return hipErrorInvalidValue;
     if (a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2) return hipErrorInvalidValue;
     if (a.out_split && (is_f16 || a.Cout % 32 != 0)) return hipErrorInvalidValue;
+    if (a.in_split && (is_f16 || !a.out_split || (a.Cout != 32 && a.Cout != 64))) return hipErrorInvalidValue;
     const long long blocks = (long long)a.N * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
 #define WTK_STEM(T, TC) hipLaunchKernelGGL((stem_mfma_kernel<T, TC>), grid, dim3(256), 0, stream, a)
-    if (is_f16) {
+    if (a.in_split) { // split-fp16 handles: split operands on the fp16 matrix instruction
+        if (a.Cout == 32)
+            hipLaunchKernelGGL((stem_mfma_kernel<_Float16, 2, true>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((stem_mfma_kernel<_Float16, 4, true>), grid, dim3(256), 0, stream, a);
+    } else if (is_f16) {
         switch (a.Cout / 16) {
         case 1: WTK_STEM(_Float16, 1); break;
         case 2: WTK_STEM(_Float16, 2); break;

@@ -539,6 +539,7 @@ struct wtk_yolo {
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
+    int stem_fp32 = 0; // WTK_STEM_FP32=1: a split (f16x3) handle's stem on the fp32 matrix instructions (round 2) instead of split operands (A/B switch)
     int use_c32s = 1;  // WTK_NO_C32S=1: the 32 -> 32 channel 3x3 layers of a split (f16x3) handle through conv_igemm_kernel (A/B switch)
     int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
     int ws64_weave = 0; // pixel tiles (of 4) of a 64-channel 3x3 tile whose epilogue rides on the next multiply phase (WTK_WS64_WEAVE=0..3; 0: the round-2 schedule)
@@ -977,7 +978,11 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         op.spec = i0;
         // repack [cout][3][3][3(RGB)] -> K = tap*4 + channel (see stem_mfma_kernel)
         const float *w0 = d->convs[i0].weight;
-        const int taps = h->is_f16 ? 16 : 9; // split mode: the fp32 stem (pixels / 255 are not fp16 numbers), split store
+        // split mode: split-fp16 operands like every other conv of the handle (pixels / 255 and the weights as hi + lo pairs); WTK_STEM_FP32=1 keeps
+        // round 2's fp32 matrix instructions with a split store (A/B switch)
+        if (const char *e = std::getenv("WTK_STEM_FP32")) h->stem_fp32 = e[0] == '1';
+        const bool stem_split = h->split && !h->stem_fp32;
+        const int taps = (h->is_f16 || stem_split) ? 16 : 9;
         std::vector<float> wp((size_t)c[0] * taps * 4, 0.f);
         for (int co = 0; co < c[0]; ++co)
             for (int tap = 0; tap < 9; ++tap)
@@ -993,6 +998,15 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         if (h->is_f16) {
             wh.resize(wp.size());
             for (size_t i = 0; i < wp.size(); ++i) wh[i] = f32_to_f16_bits(wp[i]);
+            src = wh.data();
+            bytes = wh.size() * 2;
+        } else if (stem_split) { // [cout][16][4] hi halves, then [cout][16][4] lo halves
+            wh.resize(2 * wp.size());
+            for (size_t i = 0; i < wp.size(); ++i) {
+                const uint16_t hb = f32_to_f16_bits(wp[i]);
+                wh[i] = hb;
+                wh[wp.size() + i] = f32_to_f16_bits((wp[i] - f16_bits_to_f32(hb)) * kSplitScale);
+            }
             src = wh.data();
             bytes = wh.size() * 2;
         }
@@ -1391,6 +1405,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         if (h->split) { // pseudo-channels (see the conv path below)
             f.Kpad1 *= 2, f.Kpad2 *= 2, f.out_ld *= 2, f.out_coff *= 2;
             f.n_dyn = h->n_dyn;
+            f.stem_split = !h->stem_fp32;
             HIP_TRY(launch_front_fused_split(f, h->num_cus, st));
         } else
             HIP_TRY(launch_front_fused(f, h->num_cus, st));
@@ -1437,7 +1452,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.out = h->bufs[op.out_buf].ptr;
             a.Cout = op.cout;
             a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
-            a.out_split = h->split; // fp32 arithmetic (pixels / 255 are not fp16 numbers), split store
+            a.out_split = h->split; // split store
+            a.in_split = h->split && !h->stem_fp32; // split operands (default) or fp32 arithmetic (WTK_STEM_FP32=1)
             a.n_dyn = h->n_dyn;
             HIP_TRY(launch_stem(a, h->is_f16, st));
             ++launches[0];

@@ -271,12 +271,13 @@ hipError_t launch_conv3x3_c32_split(HaloArgs a, hipStream_t stream); // channel 
 struct StemArgs {
     const uint8_t *frames; // [N][H][W][C], C = 1 or 3 (BGR)
     int N, H, W, C;
-    const void *w; // packed: fp16 [Cout][16 taps][4] (taps 9..15 and channel 3 zero), fp32 [Cout][9][4]
+    const void *w; // packed: fp16 [Cout][16 taps][4] (taps 9..15 and channel 3 zero), fp32 [Cout][9][4]; in_split: see below
     const float *bias;
     void *out; // [N][H/2][W/2][Cout]
     int Cout;
     int Ho, Wo;
     int out_split; // fp32 kernel only: store split-fp16 pairs (Cout % 32 == 0)
+    int in_split;  // with out_split: split-fp16 OPERANDS too (w = [Cout][16][4] hi halves, then the lo halves): three fp16 matrix instructions per k-step instead of the fp32 ones
     const int *n_dyn; // nullable: device-side image count <= N (wtk_yolo_set_dynamic_batch): blocks of images beyond it exit at once
 };
 hipError_t launch_stem(const StemArgs &a, int is_f16, hipStream_t stream);
@@ -298,6 +299,7 @@ struct FrontArgs {
     unsigned long long *dbg_stamps; // diagnostic builds (-DWTK_FRONT_STAMPS) only: [grid][8 waves][8 stages] cycle sums
     void *dbg_t0, *dbg_t1; // test hook (normally null): also materialise model.0 [N][H/2][W/2][32] / model.1 [N][H/4][W/4][64]
     const int *n_dyn;      // nullable: device-side image count <= N (front_fused_split_kernel: the tiles of images beyond it are not visited)
+    int stem_split;        // front_fused_split_kernel: w0 = the split stem packing ([32][16][4] hi halves, then lo) instead of the fp32 one
     int Ho, Wo, tiles_x, tiles_y, total_tiles; // filled by the launcher
     FastDiv d_tpi, d_tilesx;
 };
