@@ -1,5 +1,5 @@
 // Fused network front of the split-fp16 ("f16x3") handles, YOLOv8s widths: predictor preprocess + model.0 (stem, 3x3/s2, 3 -> 32,
-// exact fp32 matrix instructions as the stand-alone stem of these handles) + model.1 (3x3/s2, 32 -> 64) + model.2.cv1 (1x1, 64 -> 64)
+// split operands — or, WTK_STEM_FP32=1, exact fp32 matrix instructions — as the stand-alone stem of these handles) + model.1 (3x3/s2, 32 -> 64) + model.2.cv1 (1x1, 64 -> 64)
 // in ONE persistent kernel.
 //
 // Why: split tensors double the bytes of the largest maps of the network.  Run one by one these three layers move 839 MB (stem
@@ -15,7 +15,7 @@
 //     -> O1    model.1 output 64 px x 64 ch = two split rows per pixel, block-major  16 KB   (aliases P)
 //     -> cv1   -> global (split NHWC slice view)
 //   weights of model.1 ([9][64] rows of 128 B) and cv1 ([2][64] rows) stay resident in LDS (88 KB), the stem's in registers.
-// Every stage uses the operands, the K order and the instruction sequence of the layer-by-layer path (stem_mfma_kernel<float>,
+// Every stage uses the operands, the K order and the instruction sequence of the layer-by-layer path (stem_mfma_kernel<fp16, 2, SPLIT> / <float, 2>,
 // conv_igemm_kernel's split form: per K step hi.hi into `acc`, lo.hi then hi.lo into `acc1`; v = acc + acc1 * 2^-11; SiLU; split),
 // so the result equals the unfused kernels' bit for bit (tests/test_gpu_f16x3.py switches the fusion off and on).
 // Barriers are raw s_barrier + lgkmcnt(0) so the next tile's patch loads and the previous tile's output stores stay in flight.
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
 
 bool front_fused_split_eligible(int c0, int c1, int c2_out) { return c0 == 32 && c1 == 64 && c2_out == 64; }
 
-// a.out_ld / a.out_coff in pseudo-channels (2 x real); a.Kpad1 / a.Kpad2 pseudo as well (576 / 128); a.w0 the fp32 stem packing
+// a.out_ld / a.out_coff in pseudo-channels (2 x real); a.Kpad1 / a.Kpad2 pseudo as well (576 / 128); a.w0 the split stem packing (a.stem_split) or the fp32 one
 hipError_t launch_front_fused_split(FrontArgs a, int num_cus, hipStream_t stream) {
     if (a.C != 1 && a.C != 3) return hipErrorInvalidValue;
     if (a.H % 32 || a.W % 32 || a.H <= 0 || a.W <= 0 || a.N <= 0) return hipErrorInvalidValue;

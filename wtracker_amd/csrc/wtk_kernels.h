@@ -326,7 +326,7 @@ bool c2f_fused_eligible(int is_f16, int c_hidden, int n_bottlenecks, int shortcu
 hipError_t launch_c2f_fused(C2fArgs a, int num_cus, hipStream_t stream);
 
 bool front_fused_eligible(int is_f16, int c0, int c1, int c2_out);
-// split-fp16 ("f16x3") handles: front_fused_split.hip.  w0 = the fp32 stem packing, w1 / w2 split rows, Kpad1 / Kpad2 / out_ld /
+// split-fp16 ("f16x3") handles: front_fused_split.hip.  w0 = the split stem packing (stem_split) or the fp32 one, w1 / w2 split rows, Kpad1 / Kpad2 / out_ld /
 // out_coff in pseudo-channels (2 x real)
 bool front_fused_split_eligible(int c0, int c1, int c2_out);
 hipError_t launch_front_fused_split(FrontArgs a, int num_cus, hipStream_t stream);
