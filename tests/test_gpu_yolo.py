@@ -302,7 +302,7 @@ def test_full_size_640_matches_oracle(hip_lib, dtype, B):
 _SEED_ORACLE: dict = {}
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 7])
 def test_exact_modes_match_oracle_on_other_weight_draws(hip_lib, seed):
     """The detector's oracle is parity-unpinned (no ultralytics, no trained weights), so the evidence it can give is breadth: besides
     the weight draw every other test uses (seed 0), three more draws of all 63 convs at BASELINE's frame size — fp32 and f16x3 head
