@@ -48,6 +48,7 @@ def test_f16x3_every_tensor_against_the_fp32_mode(hip_lib, monkeypatch, H, W, C,
     accumulated over the layers in front of them — three orders of magnitude below the fp16 mode's 2^-11 per layer."""
     B = 3
     monkeypatch.setenv("WTK_FRONT_DEBUG", "1")  # the fused front (front_fused_split_kernel) also writes the model.0 / model.1 tensors it keeps in LDS
+    monkeypatch.setenv("WTK_NO_FUSED_TAIL", "1")  # the box towers' 3x3 outputs exist as tensors only when their 1x1 is a launch of its own
     monkeypatch.setenv("WTK_NO_HALO", no_halo)  # "1": every 3x3 conv through the split implicit GEMM instead of the split window kernels
     monkeypatch.setenv("WTK_NO_S2WIN", no_halo)
     rng = np.random.default_rng(H + W)
@@ -103,6 +104,30 @@ def test_f16x3_fused_front_equals_layer_by_layer(hip_lib, monkeypatch, B, H, W, 
     for res, (box, cls), ts in outs[1:]:
         for t, r in zip(ts, ref_t):
             np.testing.assert_array_equal(t, r)
+        np.testing.assert_array_equal(box, ref_box)
+        np.testing.assert_array_equal(cls, ref_cls)
+        for x, y in zip(res, ref_res):
+            np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 128, 128), (2, 352, 224), (4, 640, 640), (2, 1280, 736)])
+def test_f16x3_fused_box_tail_equals_two_launches(hip_lib, monkeypatch, B, H, W):
+    """The Detect box towers' last 1x1 (64 -> 64, fp32 logits out) inside the epilogue of the split 3x3 before it (split rows in LDS, wave-local)
+    against the two launches (WTK_NO_FUSED_TAIL=1): the same split products in the same order — every head logit and result bit-identical, at the
+    three levels' block sizes (256- and 128-pixel blocks) and on ragged maps; two fused runs catch a missing wait."""
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(H + 3 * W).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    outs = []
+    for off in ("1", "0", "0"):
+        monkeypatch.setenv("WTK_NO_FUSED_TAIL", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.05)
+        outs.append((res, det.debug_head(B)))
+        det.close()
+    ref_res, (ref_box, ref_cls) = outs[0]
+    assert np.abs(ref_box).max() > 0
+    for res, (box, cls) in outs[1:]:
         np.testing.assert_array_equal(box, ref_box)
         np.testing.assert_array_equal(cls, ref_cls)
         for x, y in zip(res, ref_res):

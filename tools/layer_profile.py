@@ -86,7 +86,7 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
         ops = ops[:i0] + [("model.3+4.cv1", "fused", st3, 0, 0, 0, (fl, by))] + ops[i0 + 2 :]
     # Detect towers: the last 1x1 runs in the epilogue of the 3x3 before it (TAIL instantiations of the window kernel:
     # 64-cout tile = box tower, 128-cout tile = class tower)
-    tails = {"box": any("conv3x3_halo_kernel" in k and "Li64E" in k and "Lb1ELb0EEEvNS_8HaloArgsE" in k for k in kernel_names),
+    tails = {"box": any("conv3x3_halo_kernel" in k and "Li64E" in k and ("Lb1ELb0EEEvNS_8HaloArgsE" in k or "Lb1ELb1EEEvNS_8HaloArgsE" in k) for k in kernel_names),  # (TAIL, SPLIT) = (1, 0) fp16 / (1, 1) f16x3
              "cls": any("conv3x3_halo_kernel" in k and "Li128E" in k and "Lb1ELb0EEEvNS_8HaloArgsE" in k for k in kernel_names)}
     for tower, on in tails.items():
         if not on:

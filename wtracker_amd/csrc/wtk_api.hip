@@ -1082,7 +1082,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         P.conv({cl + ".2"}, d2c, 0, h->cls_buf[i], 0, -1, 0, -1, 0, h->cls_ld);
         if (!P.failed && h->use_tail) { // box tower: the last 1x1 runs in the epilogue of the 3x3 before it (fp16, 64 channels)
             Op &b1 = h->ops[first_op + 1], &b2 = h->ops[first_op + 3];
-            if (h->is_f16 && b1.halo == 1 && b1.cout == 64 && b1.cout_pad == 64 && b2.k == 1 && b2.cin == 64 && b2.cout == 64 && !b2.act &&
+            if ((h->is_f16 || h->split) && b1.halo == 1 && b1.cout == 64 && b1.cout_pad == 64 && b2.k == 1 && b2.cin == 64 && b2.cout == 64 && !b2.act &&
                 b2.in_buf == b1.out_buf && b2.res_buf < 0 && b2.out2_buf < 0 && b1.res_buf < 0 && b1.out2_buf < 0 && h->halo_slabs == 3) {
                 b1.tail_op = (int)first_op + 3;
                 b2.folded = 1;
@@ -1567,6 +1567,10 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     g.tail_out = h->bufs[t.out_buf].ptr, g.tail_ld = h->bufs[t.out_buf].C, g.tail_coff = t.out_coff;
                     g.tail_cout = t.cout;
                     g.tail_f32 = h->bufs[t.out_buf].f32;
+                    if (h->split) { // pseudo-channels for the split weights (and for a split output; the fp32 head logits keep their real layout)
+                        g.tail_kpad *= 2;
+                        if (!g.tail_f32) g.tail_ld *= 2, g.tail_coff *= 2;
+                    }
                 }
                 g.persist_cus = h->halo_persist ? h->num_cus : 0;
                 const int rows_max = (op.halo == 2 && h->split) ? c32_split_rows_max() : (op.halo == 2 || h->split) ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
