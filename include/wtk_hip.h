@@ -303,7 +303,8 @@ int wtk_recheck_scatter(int32_t *q_len_dev, int32_t q_cap, const float *src_xywh
  * (yolo_controller.py:62-90, every frame in fp32: yolo/yolo_train_config.yaml:51 `half: False`) returns, at the fp16 handle's
  * speed on the frames whose decision is clear.  `fast` and `exact` are wtk_yolo handles of the same model on the same device
  * (typically WTK_F16 and WTK_F16X3); the object borrows them (the caller destroys them AFTER wtk_hybrid_destroy) and owns the
- * exact handle's dynamic batch while it lives.
+ * exact handle's dynamic batch while it lives: a full-precision handle serves at most one hybrid object at a time (create refuses
+ * a handle whose dynamic batch is already set).
  *   margin  rows whose fast-pass decision margin is below it are looked at again (choose it from measurements on the model:
  *           see wtracker_amd/hybrid.py calibrate(); a fixed number is not a guarantee).
  *   k       ceiling of rows per second look; 0 = the largest value that can never cut a weak row off (the whole batch; the

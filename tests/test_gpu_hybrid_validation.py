@@ -197,6 +197,8 @@ def test_native_hybrid_object_through_the_c_abi(hip_lib):
 
     # ---- immediate form, every row weak (margin 1e9): rows = full-precision rows
     assert lib.wtk_hybrid_create(C.byref(h), fast._h, exact._h, C.c_float(1e9), 0, 1) == 0, lib.wtk_last_error()
+    h2 = vp()  # a full-precision handle serves one hybrid object at a time
+    assert lib.wtk_hybrid_create(C.byref(h2), fast._h, exact._h, C.c_float(0.1), 0, 1) != 0 and b"already" in lib.wtk_last_error()
     k, d, m = C.c_int32(), C.c_int32(), C.c_float()
     assert lib.wtk_hybrid_config(h, C.byref(k), C.byref(d), C.byref(m)) == 0 and (k.value, d.value) == (B, 1) and m.value == 1e9
     o = outs(B)

@@ -2017,6 +2017,7 @@ extern "C" int wtk_hybrid_create(wtk_hybrid **out, wtk_yolo *fast, wtk_yolo *exa
     if (fast->device != exact->device) return fail("wtk_hybrid_create: both handles must live on the same device");
     if (fast->S_h != exact->S_h || fast->S_w != exact->S_w || fast->anchors != exact->anchors)
         return fail("wtk_hybrid_create: both handles must be the same model at the same network size");
+    if (exact->n_dyn) return fail("wtk_hybrid_create: the full-precision handle already takes its batch size from device memory (another hybrid object owns it, or wtk_yolo_set_dynamic_batch was called)");
     if (defer < 1) return fail("wtk_hybrid_create: defer >= 1");
     if (k == 0) k = defer > 1 ? exact->max_batch : std::min(fast->max_batch, exact->max_batch);
     if (k < 1 || k > exact->max_batch) return fail("wtk_hybrid_create: 1 <= k <= max_batch of the full-precision handle");
