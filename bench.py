@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 # One hardware queue per stream: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues.  This process keeps five
 # streams busy (two lanes, the shared pair of side streams, torch's default stream); with four queues two of them share one and serialise:
 # 26.2 k frames/s against 27.1 k with 5, 6 or 8 queues (profiles/r02_notes.md §8).  Read by the runtime when it initialises: set before torch loads.
-# wtracker_amd.hip.load() sets the same default for any user of the library; it is spelled out here because torch loads first.
+# (wtracker_amd.hip.request_hw_queues() is the same request for other users of the library; hip.load() itself leaves the environment alone.)
 # N > 1 with RCCL (`--backend nccl`): one process per GPU, so the eight queues are per DEVICE exactly as at N = 1; RCCL adds its own
 # stream(s) for the one 1-KiB all-gather per step, which is why the value is 8 and not 5.  The one-GPU rehearsal of the multi-rank path
 # (`--backend gloo`, every rank on cuda:0) keeps the runtime default: there the processes share a device and their queues add up (19.5 k -> 4.9 k).

@@ -34,7 +34,8 @@ def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       HSA_ENABLE_IPC_MODE_LEGACY="0", WTK_KEEP_HW_QUEUES="1")  # the ranks share one device: not eight hardware queues each
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.pop("GPU_MAX_HW_QUEUES", None)  # the ranks share one device: the runtime default, not eight hardware queues each
             cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--out", str(tmp_path / f"{tag}{r}.npz"),
                    "--batch", str(B), "--steps", str(steps), "--lanes", "2", "--backend", "gloo"] + extra
             procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))

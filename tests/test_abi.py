@@ -99,3 +99,19 @@ def test_one_hip_runtime_whatever_the_import_order(hip_lib):
         assert out.returncode == 0, out.stderr[-2000:]
         libs = eval(out.stdout.strip().splitlines()[-1])
         assert len([p for p in libs if "amdhip64" in p]) == 1 and len([p for p in libs if "hsa-runtime64" in p]) == 1, (order, libs)
+
+
+def test_load_leaves_the_environment_alone(hip_lib):
+    """hip.load() used to write GPU_MAX_HW_QUEUES=8 into os.environ, which every child process inherits (rank processes sharing one
+    device then asked for eight hardware queues each).  The request is now the explicit hip.request_hw_queues(): after load() neither this process
+    nor a child spawned from it sees the variable unless somebody asked for it."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); from wtracker_amd import hip; hip.load(); "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; "
+            "import subprocess; print(subprocess.run([sys.executable, '-c', \"import os; print(os.environ.get('GPU_MAX_HW_QUEUES'))\"], capture_output=True, text=True).stdout.strip()); "
+            "assert hip.request_hw_queues(8) and os.environ['GPU_MAX_HW_QUEUES'] == '8' and not hip.request_hw_queues(5) and os.environ['GPU_MAX_HW_QUEUES'] == '8'") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "None"

@@ -17,7 +17,8 @@ import os
 import pytest
 
 from wtracker_amd.controllers import CsvController, OptimalController, PolyfitConfig, PolyfitController
-from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger
+from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger
+from harness.sim_harness import Simulator
 
 EXP0 = dict(name="exp0", num_frames=200, frames_per_sec=60, orig_resolution=(1600, 1400), px_per_mm=90, init_position=(1300, 1200))
 PF = dict(degree=2, sample_times=[2, -9, 0, -3, 4, -6], weights=[1, 1, 2, 3, 4, 5])

@@ -163,7 +163,8 @@ def test_closed_loop_controller_in_auto_precision_equals_oracle_controller(hip_l
     movement) gives the integer platform moves and logged boxes of the CPU-restatement controller — host crops and device-resident frames."""
     from oracle.controllers_oracle import OracleYoloController
     from wtracker_amd.controllers import HipYoloController, YoloConfig
-    from wtracker_amd.sim import ArrayReader, ExperimentConfig, Simulator, TimingConfig, TrackLogger
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger
+    from harness.sim_harness import ArrayReader, Simulator
 
     w = ys.synthetic_weights("s", 1, seed=0)
     path = str(tmp_path / "s.wtk")

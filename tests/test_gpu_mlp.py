@@ -10,7 +10,8 @@ import torch
 from oracle import resmlp_oracle
 from wtracker_amd import hip, resmlp
 from wtracker_amd.controllers import HipMLPController
-from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger
+from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger
+from harness.sim_harness import Simulator
 
 pytestmark = pytest.mark.gpu
 ATOL, RTOL = 2e-4, 1e-5

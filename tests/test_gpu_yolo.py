@@ -17,12 +17,19 @@ pytestmark = pytest.mark.gpu
 # fp32 mode: exact-fp32 MFMA vs torch-CPU fp32 — only summation order and expf differ
 F32_LOGIT_ATOL = 2e-3
 F32_BOX_ATOL = 2e-2   # pixels
-# fp16 mode: fp16 storage of every activation; logits are O(1..10).  FIXED bounds (round 3: no tolerance is derived from the run under test,
-# so a kernel that got noisier fails): the largest class-logit error over all anchors of a batch, and — for a frame whose survivor differs
-# from the fp32 restatement's — how far below the restatement's best logit the chosen anchor's restatement logit may lie.  Measured on this
-# build: logit error <= 0.184 (the largest: scale n at 160^2; scale s at 128^2 .. 1280^2 <= 0.12), mismatch gaps <= 0.019 for the seed-0 draw
-# these tests use (1 792 frames at 640^2, profiles/r02_margin_study.json; other weight draws are noisier: tests/test_gpu_hybrid_validation.py).
-F16_LOGIT_ATOL = 0.25
+# fp16 mode: fp16 storage of every activation; logits are O(1..10).  Bounds on the largest class- / box-logit error over all anchors of a batch,
+# per model scale:
+#   scale s (the benchmarked model, BASELINE configs 2-5): 0.15 — the bound this suite was written with, BEFORE any run was compared against
+#     it; every measurement since lies below it (128^2 .. 1280^2: <= 0.12).  Round 3 had raised the one shared constant to 0.25 after a red
+#     run (0.1834); that run was scale n, so scale s is back at its original bound.
+#   scale n (width 0.25: 16-64-channel layers; not a BASELINE configuration, used by the small-shape tests): 0.25.  It is a REGRESSION bound
+#     and carries no accuracy claim: with a quarter of the channels every output averages a quarter of the rounding errors of its inputs'
+#     fp16 storage (error ~ 1 / sqrt(K) relative to the signal), i.e. ~ 2 x scale s's noise at equal depth -> 2 x 0.12 = 0.24, rounded up.
+#     Measured: 0.184 (160^2).
+# For a frame whose survivor differs from the fp32 restatement's: how far below the restatement's best logit the chosen anchor's restatement
+# logit may lie (mismatch gaps <= 0.019 for the seed-0 draw these tests use, 1 792 frames at 640^2, profiles/r02_margin_study.json; other weight
+# draws are noisier: tests/test_gpu_hybrid_validation.py).
+F16_LOGIT_ATOL = {"s": 0.15, "n": 0.25}
 F16_MISMATCH_GAP_MAX = 0.05
 F16_IOU_MIN = 0.90
 
@@ -66,18 +73,18 @@ def test_fp32_head_logits_and_boxes_match_oracle(hip_lib, scale, size, B):
     np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
 
 
-def _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, net_hw, hw, conf):
+def _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, net_hw, hw, conf, scale="s"):
     """fp16 mode against the fp32 oracle, with NO escape for frames whose survivor differs: (1) the selection the
     GPU made from ITS OWN logits is bit-exact in index vs the oracle's selection logic on those logits; (2) the class- and
-    box-logit error over ALL anchors stays below the fixed F16_LOGIT_ATOL; (3) every frame whose survivor differs from the
+    box-logit error over ALL anchors stays below the fixed F16_LOGIT_ATOL[scale]; (3) every frame whose survivor differs from the
     fp32 oracle's is counted, and the anchor it chose must lie within the fixed F16_MISMATCH_GAP_MAX of the oracle's best logit
     (a NaN row on one side only: the oracle's best within that distance of the threshold); (4) matched survivors have
     IoU > F16_IOU_MIN.  Returns the number of mismatching frames (the rate is asserted at BASELINE scale in test_gpu_configs.py)."""
     cls_o_np, box_o_np = cls_o.numpy(), box_o.numpy()
     eps = F16_MISMATCH_GAP_MAX / 2
     measured = float(np.abs(cls_g - cls_o_np).max())
-    print(f"\nfp16 logit error over all anchors: cls {measured:.4f}, box {float(np.abs(box_g - box_o_np).max()):.4f} (bound {F16_LOGIT_ATOL})")
-    assert measured < F16_LOGIT_ATOL and np.abs(box_g - box_o_np).max() < F16_LOGIT_ATOL
+    print(f"\nfp16 logit error over all anchors: cls {measured:.4f}, box {float(np.abs(box_g - box_o_np).max()):.4f} (bound {F16_LOGIT_ATOL[scale]})")
+    assert measured < F16_LOGIT_ATOL[scale] and np.abs(box_g - box_o_np).max() < F16_LOGIT_ATOL[scale]
     xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), net_hw, hw, conf=conf)
     np.testing.assert_array_equal(anchor, anchor_s)
     np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=2e-2)
@@ -106,14 +113,14 @@ def test_fp16_matches_oracle_within_stated_tolerance(hip_lib, scale, size, B):
     box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
     xywh, conf, anchor = det.predict_host(frames, conf=0.1)
     box_g, cls_g = det.debug_head(B)
-    _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, (size, size), hw, 0.1)
+    _assert_fp16_survivors_explained(anchor, xywh, box_g, cls_g, box_o, cls_o, (size, size), hw, 0.1, scale=scale)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_decode_and_selection_bit_exact_on_given_logits(hip_lib, dtype):
     """Isolates box-decode / arg-max selection from conv rounding: identical logits in, survivor index
     must be identical, including ties (lowest anchor wins), the conf threshold, NaN rows, clipping."""
-    size, B = 128, 6
+    size, B = 128, 8
     _, det = _models("n", size, dtype)
     A = det.anchors
     rng = np.random.default_rng(4)
@@ -125,10 +132,24 @@ def test_decode_and_selection_bit_exact_on_given_logits(hip_lib, dtype):
     cls[4, 0, 0] = 7.0            # first anchor (corner -> clipping at 0)
     box[5] = 0.0                  # uniform DFL -> every side 7.5 bins
     cls[5, 100, 0] = 3.0
+    # saturated scores: the reference sorts fp32 SCORES, and every logit above 16.64 has the score 1.0f exactly -> a stable sort
+    # names the lowest INDEX among them, not the largest logit (25 at anchor 150 here; round 3's kernel compared logits and failed this)
+    cls[6, 311, 0], cls[6, 150, 0], cls[6, 42, 0], cls[6, 207, 0], cls[6, 41, 0] = 18.0, 25.0, 17.0, 18.0, 16.0
+    # ... and one saturated anchor against ordinary ones, the last index against the first
+    cls[7, A - 1, 0], cls[7, 0, 0] = 30.0, 9.0
     xywh, conf, anchor = det.decode_host(box, cls, size, size, conf=0.25)
     xywh_o, conf_o, anchor_o = yo.postprocess(torch.from_numpy(box), torch.from_numpy(cls), (size, size), (size, size), conf=0.25)
     np.testing.assert_array_equal(anchor, anchor_o)
     assert anchor[1] == -1 and np.isnan(xywh[1]).all() and anchor[2] == 37 and anchor[3] == A - 1 and anchor[4] == 0
+    assert anchor[6] == 42 and conf[6] == 1.0 and anchor[7] == A - 1
+    # the general NMS entry point with max_det = 1 is the same decision, row for row
+    xywh_n, conf_n, _, anchor_n, cnt_n = det.decode_nms_host(box, cls, size, size, 1, conf=0.25, iou=0.7)
+    np.testing.assert_array_equal(anchor_n[:, 0], anchor)
+    np.testing.assert_array_equal(xywh_n[:, 0], xywh)
+    np.testing.assert_array_equal(cnt_n, (anchor >= 0).astype(cnt_n.dtype))
+    # the decision margin stays logit-based: frame 6's winner (logit 17) trails the largest other logit (25) by 8
+    margins = det.last_margins(B)
+    assert margins[6] == np.float32(17.0 - 25.0) and margins[7] == np.float32(30.0 - 9.0) and margins[2] == 0.0
     ok = anchor >= 0
     np.testing.assert_allclose(xywh[ok], xywh_o[ok], rtol=0, atol=1e-3)
     np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-6)
@@ -336,13 +357,10 @@ def test_widest_class_count_at_scale_s_640(hip_lib):
     restatement's, survivor index equal, at BASELINE's frame size."""
     size, B, nc = 640, 2, 32
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    # The stored gains were measured for nc = 1; with 32 classes the class logits of this draw exceed 16.6, where the reference's fp32 sigmoid is
-    # exactly 1.0f for every such anchor and its stable sort then names the LOWEST index among them, while the device compares logits (DESIGN.md
-    # section 2, "saturated scores").  The test is about the wide head, not about saturation: the class towers' last 1x1 is scaled down.
+    # The stored gains were measured for nc = 1; with 32 classes the class logits of this draw exceed 16.64, where the fp32 sigmoid is exactly
+    # 1.0f for every such anchor and the reference's stable sort names the LOWEST index among them (round 3 found the device comparing logits
+    # there: anchors 7254 / 7130 against the restatement's 6484).  The selection now orders by the fp32 score, so the draw is used as it is.
     w = ys.synthetic_weights("s", nc, seed=0)
-    for lvl in range(3):
-        wt, b = w[f"model.22.cv3.{lvl}.2"]
-        w[f"model.22.cv3.{lvl}.2"] = (wt * np.float32(0.2), b)
     depth, width, maxch = ys.SCALES["s"]
     oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, nc))
     det = hip.HipYolo(w, (size, size), B, dtype="fp32", nc=nc, width=width, depth=depth, max_channels=maxch)
@@ -352,18 +370,20 @@ def test_widest_class_count_at_scale_s_640(hip_lib):
     box_g, cls_g = det.debug_head(B)
     assert cls_g.shape == (B, 8400, nc)
     assert np.abs(cls_g - cls_o.numpy()).max() < F32_LOGIT_ATOL and np.abs(box_g - box_o.numpy()).max() < F32_LOGIT_ATOL
-    assert cls_o.numpy().max() < 12.0, cls_o.numpy().max()  # no score anywhere near fp32 saturation
-    # selection: bit-exact against the restatement's selection logic on the SAME logits (268 800 candidates per frame: the best few lie
-    # closer together than the 2e-3 the logits are compared at, so the two nets' own arg-maxes may legitimately name different anchors) ...
-    xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (size, size), hw, conf=0.01)
+    assert cls_o.numpy().max() > 16.64, cls_o.numpy().max()  # this draw saturates the fp32 sigmoid: the case round 3 scaled away
+    # selection: bit-exact against the restatement's selection logic on the SAME logits (268 800 candidates per frame, many of them at a score of
+    # exactly 1.0f: lowest anchor index) ...
+    xywh_s, conf_s, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (size, size), hw, conf=0.01)
     np.testing.assert_array_equal(anchor, anchor_s)
     np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=F32_BOX_ATOL)
-    # ... and the anchor the device chose is, in the restatement's own logits, within twice that tolerance of the restatement's best
+    np.testing.assert_allclose(conf, conf_s, rtol=0, atol=1e-6)
+    # ... and on its OWN logits (within 2e-3 of the device's) the restatement either names the same anchor or one whose score the device's anchor
+    # equals to 1e-4 (saturated frames: both are exactly 1.0f and only the lowest saturated index can differ, by which side of 16.64 a logit fell)
     _, _, anchor_o = yo.postprocess(box_o, cls_o, (size, size), hw, conf=0.01)
-    best_o = cls_o.numpy().max(axis=2)
+    score_o = torch.sigmoid(cls_o).numpy().max(axis=2)
     for n in range(B):
         if anchor[n] != anchor_o[n]:
-            assert anchor[n] >= 0 and anchor_o[n] >= 0 and best_o[n].max() - best_o[n, anchor[n]] <= 2 * F32_LOGIT_ATOL, (n, anchor[n], anchor_o[n])
+            assert anchor[n] >= 0 and anchor_o[n] >= 0 and score_o[n].max() - score_o[n, anchor[n]] <= 1e-4, (n, anchor[n], anchor_o[n])
     det.close()
     with pytest.raises(hip.WtkError, match="nc"):
         _models("s", size, "fp32", nc=80, max_batch=1)
@@ -393,7 +413,8 @@ def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib,
     integer platform moves and every logged box equal to the CPU-restatement controller's."""
     from oracle.controllers_oracle import OracleYoloController
     from wtracker_amd.controllers import HipYoloController, YoloConfig
-    from wtracker_amd.sim import ArrayReader, ExperimentConfig, Simulator, TimingConfig, TrackLogger
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger
+    from harness.sim_harness import ArrayReader, Simulator
 
     w = ys.synthetic_weights("n", 1, seed=0)
     path = str(tmp_path / "n.wtk")
@@ -459,7 +480,7 @@ def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib,
 def test_device_view_cropping_matches_view_controller(hip_lib):
     """camera views cut on the device equal ViewController.camera_view (replicate-padded
     frame, window centred on the platform position), including windows hanging over every border."""
-    from wtracker_amd.sim import ArrayReader, ViewController
+    from harness.sim_harness import ArrayReader, ViewController
 
     rng = np.random.default_rng(0)
     frames = rng.integers(0, 256, size=(6, 90, 120), dtype=np.uint8)
@@ -623,7 +644,7 @@ def test_non_square_frames(hip_lib, dtype):
         box_o, cls_o = oracle.forward(x)
     xywh, conf, anchor = det.predict_host(frames, conf=0.05)
     box_g, cls_g = det.debug_head(3)
-    tol = F32_LOGIT_ATOL if dtype == "fp32" else F16_LOGIT_ATOL
+    tol = F32_LOGIT_ATOL if dtype == "fp32" else F16_LOGIT_ATOL["n"]
     assert np.abs(cls_g - cls_o.numpy()).max() < tol and np.abs(box_g - box_o.numpy()).max() < tol
     xywh_s, _, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (H, W), hw, conf=0.05)
     np.testing.assert_array_equal(anchor, anchor_s)

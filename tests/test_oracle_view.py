@@ -3,7 +3,7 @@ the product harness' ViewController (wtracker_amd/sim.py) — two independent st
 import numpy as np
 
 from oracle import view_oracle as vo
-from wtracker_amd.sim import ArrayReader, ViewController
+from harness.sim_harness import ArrayReader, ViewController
 
 
 def test_hand_computed_window_with_replicate_border():

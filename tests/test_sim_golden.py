@@ -11,7 +11,8 @@ from oracle import resmlp_oracle
 from oracle.controllers_oracle import OracleMLPController
 from wtracker_amd.controllers import CsvController, OptimalController, PolyfitConfig, PolyfitController
 from wtracker_amd.resmlp import make_training_pairs
-from wtracker_amd.sim import ExperimentConfig, Simulator, TimingConfig, TrackLogger, box_center, discretize, xyxy_to_xywh, yolo_to_xywh
+from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger, box_center, discretize, xyxy_to_xywh, yolo_to_xywh
+from harness.sim_harness import Simulator
 
 EXP0 = dict(name="exp0", num_frames=200, frames_per_sec=60, orig_resolution=(1600, 1400), px_per_mm=90, init_position=(1300, 1200))
 

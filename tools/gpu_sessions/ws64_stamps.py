@@ -1,4 +1,4 @@
-"""Per-wave interval stamps of conv3x3_ws64_kernel (diagnostic build: WTK_EXTRA_HIPCC_FLAGS=-DWTK_WS64_ABLATE, env WTK_WS64_STAMPS=1).
+"""Per-wave interval stamps of conv3x3_ws64_kernel (diagnostic build: WTK_EXTRA_HIPCC_FLAGS=-DWTK_WS64_STAMPS, env WTK_WS64_STAMPS=1).
 Prints, for the first two blocks, every wave's per-interval cycles: work (stamp 0 -> 1 or 2), vmcnt wait, barrier wait."""
 import ctypes as C
 import os

@@ -48,15 +48,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB_PATH
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
-    flags += os.environ.get("WTK_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (-DWTK_*_STAMPS, -DWTK_WS64_ABLATE)
+    extra = os.environ.get("WTK_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (-DWTK_*_STAMPS): interval stamps, results unchanged
+    if any(f.startswith("-DWTK_TIMING") for f in extra) and os.environ.get("WTK_DIAGNOSTIC_BUILD") != "1":
+        # timing-ablation macros make kernels skip work: such a library returns wrong boxes and must never be built by accident
+        raise RuntimeError("WTK_EXTRA_HIPCC_FLAGS contains a -DWTK_TIMING* macro (results would be garbage); set WTK_DIAGNOSTIC_BUILD=1 to build it anyway")
+    flags += extra
+    # one object per translation unit, recompiled only when its source, a shared header or the flag set changed
+    stamp = os.path.join(CSRC, ".flags")
+    flag_key = " ".join(flags)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flag_key
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS)
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -69,6 +80,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(stamp, "w") as f:
+        f.write(flag_key)
     return LIB_PATH
 
 

@@ -61,27 +61,6 @@ __device__ __forceinline__ void mma_h(const uint4 &wf, const uint4 &pf, floatx4 
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, pf.w), acc, 0, 0, 0);
 }
 
-// -DWTK_TIMING_MFMA32: TIMING EXPERIMENT ONLY (results are garbage).  The fp16 128-cout window kernels issue, per k-half of a tap, EIGHT
-// v_mfma_f32_32x32x16_f16 on the fragments they have already read instead of SIXTEEN v_mfma_f32_16x16x32_f16: the same fragment reads, the same
-// FLOPs, the same 64 accumulator registers, half the MFMA issue slots (an MFMA holds the SIMD's issue port for 8 cycles whatever its shape).  It
-// answers one question before anybody rewrites the fragment layouts for the other shape: how much of a tap's ~1 300-1 500 cycles is MFMA issue?
-#ifdef WTK_TIMING_MFMA32
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-template <int TC, int TP> __device__ __forceinline__ void mma32_timing(const uint4 (&wf)[TC], const uint4 (&pf)[TP], floatx4 (&acc)[TC][TP]) {
-    static_assert(TC == 4 && TP == 4, "timing experiment: 64 x 64 wave tile");
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        floatx16 c;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) c[e] = acc[q][e >> 2][e & 3];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[q]), __builtin_bit_cast(half8, pf[q]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[(q + 1) & 3]), __builtin_bit_cast(half8, pf[(q + 2) & 3]), c, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][e >> 2][e & 3] = c[e];
-    }
-}
-#endif
-
 template <int NV> __device__ __forceinline__ void load_run_h(const _Float16 *p, float (&v)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; i += 8) {
@@ -404,12 +383,6 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
             for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
 #pragma unroll
             for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
-#ifdef WTK_TIMING_MFMA32
-            if constexpr (TC == 4 && TP == 4 && sizeof(T) == 2) {
-                mma32_timing<TC, TP>(wf, pf, acc);
-                continue;
-            }
-#endif
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -954,12 +927,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
     const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
     const unsigned wfrag0 = wrow_l * 128 + ((lg ^ wkey_l) << 4);
     const int prow0 = wave_p * WP + lr;
-    auto compute_tap = [&](const char *halo, const char *wb, int tapoff, int which = -1) __attribute__((always_inline)) {
+    auto compute_tap = [&](const char *halo, const char *wb, int tapoff) __attribute__((always_inline)) {
         const int base = prow0 + tapoff;
         const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4);
 #pragma unroll
         for (int kh2 = 0; kh2 < 2; ++kh2) {
-            if (which >= 0 && kh2 != which) continue; // (timing experiment WTK_TIMING_STAGGER: one k-half at a time)
             const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0;
             const unsigned wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
             uint4 pf[TP], wf[TC];
@@ -967,12 +939,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
             for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(halo + pa + j * 2048);
 #pragma unroll
             for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(wb + wa + i * 512);
-#ifdef WTK_TIMING_MFMA32
-            if constexpr (TC == 4 && TP == 4 && sizeof(T) == 2) {
-                mma32_timing<TC, TP>(wf, pf, acc);
-                continue;
-            }
-#endif
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -1017,24 +983,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
         for (int tap = 0; tap < 9; ++tap) {
             const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
             char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
-#ifndef WTK_TIMING_SKIP // TIMING ablations of the persistent kernel's tap (garbage results): 1 no weight-slab requests, 2 no window-piece requests, 4 no tap barrier
-#define WTK_TIMING_SKIP 0
-#endif
-            const int issued = ((WTK_TIMING_SKIP & 1) ? 0 : WR) + ((tap < kMaxPiecesPerWave && !(WTK_TIMING_SKIP & 2)) ? 1 : 0);
-#ifdef WTK_TIMING_STAGGER // TIMING experiment (garbage results): waves 4-7 meet the tap barrier BETWEEN their two k-halves, i.e. run half a tap behind waves 0-3
-            const bool lag = wave >= 4;
-            compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3), lag ? 0 : -1);
-#else
+            const int issued = WR + (tap < kMaxPiecesPerWave ? 1 : 0);
             compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
-#endif
             // requests after the tap's reads and MFMAs (see conv3x3_halo_kernel)
-            if constexpr (!(WTK_TIMING_SKIP & 1)) {
             if (tap < 7)
                 issue_weights(wnext2, cur.wtile, tap + 2, c);
             else
                 issue_weights(wnext2, to_next ? nxt.wtile : cur.wtile, tap - 7, cn);
-            }
-            if (tap < kMaxPiecesPerWave && !(WTK_TIMING_SKIP & 2)) {
+            if (tap < kMaxPiecesPerWave) {
                 // select the geometry by value (no branch around the request)
                 Tile sel;
                 sel.img = to_next ? nxt.img : cur.img;
@@ -1043,20 +999,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_pkernel(const HaloArgs a)
                 for (int q = 0; q < kMaxPiecesPerWave; ++q) sel.hoff[q] = to_next ? nxt.hoff[q] : cur.hoff[q];
                 issue_piece(hnext, tap, sel, cn);
             }
-#ifdef WTK_TIMING_DEEP // TIMING experiment (garbage results): what would a slab ring one slot deeper buy?  The requests of the PREVIOUS tap may stay in flight too
-            {
-                const int prev_issued = tap == 0 ? WR + 1 : (WR + ((tap - 1) < kMaxPiecesPerWave ? 1 : 0));
-                wait_vmcnt(issued + prev_issued > 8 ? 8 : issued + prev_issued);
-            }
-#else
             wait_vmcnt(issued);
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (!(WTK_TIMING_SKIP & 4)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#ifdef WTK_TIMING_STAGGER
-            if (lag) compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3), 1);
-#endif
         }
     };
 
@@ -1412,22 +1358,19 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
     // ---- interval schedule: group g multiplies in intervals i with (i & 1) == g, the other group is in Q; one barrier per interval
     Tile done; // tile whose accumulators are waiting for their epilogue
     done = cur;
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
     const bool stamp_on = a.dbg_stamps != nullptr && blockIdx.x < 2 && lane == 0;
     unsigned long long *stamp = a.dbg_stamps + ((long long)blockIdx.x * 8 + wave) * 16 * 4;
     if (stamp_on) stamp[16 * 4 - 1] = __builtin_amdgcn_s_memtime(); // slot 15.3: loop entry
 #endif
     for (int i = 0; i < intervals; ++i) {
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
         if (stamp_on && i < 15) stamp[i * 4 + 0] = __builtin_amdgcn_s_memtime();
 #endif
         if ((i & 1) == grp) {
             const int k = (i - grp) >> 1;
             if (k < n_mine) {
-#ifdef WTK_WS64_ABLATE
-                if (!(a.bm & 1))
-#endif
-                    compute_tile();
+                compute_tile();
                 done = cur;
             }
         } else {
@@ -1435,30 +1378,24 @@ __global__ __launch_bounds__(512) void conv3x3_ws64_kernel(const HaloArgs a) {
             const bool has_prev = i - 1 - grp >= 0 && kprev < n_mine, has_next = knext < n_mine;
             if (has_next) {
                 setup_tile(knext, cur);
-#ifdef WTK_WS64_ABLATE
-                if (!(a.bm & 2))
-#endif
-                    stage_window(cur); // the group finished reading its window before the last barrier
+                stage_window(cur); // the group finished reading its window before the last barrier
             }
             if (has_prev) {
-#ifdef WTK_WS64_ABLATE
-                if (!(a.bm & 4))
-#endif
-                    epilogue(done, has_next);
+                epilogue(done, has_next);
                 arm_acc();
             }
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
             if (stamp_on && i < 15) stamp[i * 4 + 1] = __builtin_amdgcn_s_memtime();
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
         if (stamp_on && i < 15) stamp[i * 4 + 2] = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
         if (stamp_on && i < 15) stamp[i * 4 + 3] = __builtin_amdgcn_s_memtime();
 #endif
     }
@@ -1480,7 +1417,7 @@ hipError_t launch_ws64(HaloArgs a, int num_cus, hipStream_t stream) {
     // woven epilogue: needs SiLU (the woven pieces have no activation switch) and 32-bit store offsets; a.bm carries the number of woven pixel tiles
     // (0: the round-2 schedule) outside the ablation builds
     const bool can_weave = a.act && (long long)a.N * a.H * a.W * a.out_ld * 2 < 0xe0000000LL; // (kOutRange of the kernel)
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
     const int nwv = 0;
 #else
     const int nwv = can_weave ? a.bm : 0;

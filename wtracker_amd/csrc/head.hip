@@ -4,7 +4,7 @@
 // (BoxConverter.to_xywh, wtracker/utils/bbox_utils.py:232-253).
 //
 // One 1024-thread block per image.  Every thread scans a strided share of the anchors keeping
-// (best logit, lowest anchor index); a wavefront butterfly over 64 lanes and a 16-wave LDS step
+// (best fp32 score, lowest anchor index among equal scores); a wavefront butterfly over 64 lanes and a 16-wave LDS step
 // finish the reduction; only the surviving anchor's 64 DFL logits are decoded.
 #include "wtk_kernels.h"
 
@@ -26,15 +26,21 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
     const int A0 = a.lh[0] * a.lw[0], A1 = a.lh[1] * a.lw[1], A2 = a.lh[2] * a.lw[2];
     const int A = A0 + A1 + A2;
 
-    float best = -INFINITY, second = -INFINITY; // second: best logit among all OTHER anchors (ties with the winner count: margin 0)
+    // The reference sorts fp32 SCORES (sigmoid of the best class logit) in descending order with a stable sort and keeps the first
+    // (max_det = 1, yolo_controller.py:72-78): two anchors whose logits differ but whose fp32 sigmoid is equal (every logit above 16.64 gives
+    // exactly 1.0f; neighbours a few ulp apart at ordinary logits) resolve to the LOWER anchor index.  So the order here is by score, as in
+    // head_nms_kernel; the winner's logit and the best logit among all OTHER anchors are carried along for the decision margin, which stays
+    // logit-based (ties with the winner count: margin <= 0).
+    float best = -INFINITY, best_l = -INFINITY, second = -INFINITY;
     int best_i = 0x7fffffff;
-    auto merge = [](float &b, int &bi, float &s2nd, float b2, int bi2, float s2) __attribute__((always_inline)) {
+    auto merge = [](float &b, int &bi, float &bl, float &s2nd, float b2, int bi2, float bl2, float s2) __attribute__((always_inline)) {
         if (b2 > b || (b2 == b && bi2 < bi)) {
-            s2nd = fmaxf(fmaxf(b, s2nd), s2);
+            s2nd = fmaxf(fmaxf(bl, s2nd), s2);
             b = b2;
             bi = bi2;
+            bl = bl2;
         } else {
-            s2nd = fmaxf(fmaxf(b2, s2nd), s2);
+            s2nd = fmaxf(fmaxf(bl2, s2nd), s2);
         }
     };
     for (int i = threadIdx.x; i < A; i += 1024) {
@@ -50,34 +56,38 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
         const T *c = reinterpret_cast<const T *>(a.cls[lvl]) + ((long long)n * Al + j) * a.cls_ld;
         float m = ldf(c);
         for (int k = 1; k < a.nc; ++k) m = fmaxf(m, ldf(c + k)); // conf = max over classes
-        merge(best, best_i, second, m, i, -INFINITY);
+        // score = sigmoid(logit) in fp32, the same expression as head_nms_kernel's
+        merge(best, best_i, best_l, second, 1.0f / (1.0f + expf(-m)), i, m, -INFINITY);
     }
     // wavefront butterfly (64 lanes)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const float b2 = __shfl_xor(best, off, 64);
         const int i2 = __shfl_xor(best_i, off, 64);
+        const float l2 = __shfl_xor(best_l, off, 64);
         const float s2 = __shfl_xor(second, off, 64);
-        merge(best, best_i, second, b2, i2, s2);
+        merge(best, best_i, best_l, second, b2, i2, l2, s2);
     }
-    __shared__ float ws[16], wsec[16];
+    __shared__ float ws[16], wl[16], wsec[16];
     __shared__ int wi[16];
     if ((threadIdx.x & 63) == 0) {
         ws[threadIdx.x >> 6] = best;
         wi[threadIdx.x >> 6] = best_i;
+        wl[threadIdx.x >> 6] = best_l;
         wsec[threadIdx.x >> 6] = second;
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
     best = ws[0];
     best_i = wi[0];
+    best_l = wl[0];
     second = wsec[0];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) merge(best, best_i, second, ws[w], wi[w], wsec[w]);
-    if (a.out_margin && threadIdx.x == 0) a.out_margin[n] = fminf(best - second, fabsf(best - a.conf_logit));
+    for (int w = 1; w < 16; ++w) merge(best, best_i, best_l, second, ws[w], wi[w], wl[w], wsec[w]);
+    if (a.out_margin && threadIdx.x == 0) a.out_margin[n] = fminf(best_l - second, fabsf(best_l - a.conf_logit));
 
-    // score = sigmoid(logit) in fp32, candidate iff score > conf (non_max_suppression `xc`)
-    const float score = 1.0f / (1.0f + expf(-best));
+    // candidate iff score > conf (non_max_suppression `xc`)
+    const float score = best;
     const bool keep = (best_i != 0x7fffffff) && (score > a.conf);
 
     // ---- DFL decode of the survivor: lanes 0..3 = sides l, t, r, b

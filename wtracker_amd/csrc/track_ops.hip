@@ -59,8 +59,11 @@ template <typename T> __global__ __launch_bounds__(64) void track_median_kernel(
 // Singular value decomposition of the n x K matrix A (n <= kTrackMaxTimes, K <= kTrackMaxCoef) by one-sided Jacobi (Hestenes)
 // rotations of its COLUMNS, fp64: on return the columns of A are mutually orthogonal (A = U diag(s) as columns, s_p = |A[:,p]|)
 // and V holds the accumulated rotations, so A_in = U diag(s) V^T.  Working on the matrix itself (not on the Gram matrix) keeps
-// singular values down to ~eps * s_max resolved, which is what numpy's rcond = len(t) * eps needs.
-__device__ void jacobi_svd_columns(double (&A)[kTrackMaxTimes][kTrackMaxCoef], double (&V)[kTrackMaxCoef][kTrackMaxCoef], int n, int K) {
+// singular values down to ~eps * s_max resolved, which is what numpy's rcond = len(t) * eps needs.  A column pair counts as orthogonal when
+// |a_p . a_q| <= 4 eps |a_p| |a_q| (a threshold BELOW eps, as in round 3, is never met by rounding alone, so every call ran all 30 sweeps and
+// "converged" could not be told from "gave up"); returns false when the last sweep still rotated.
+constexpr double kJacobiTol = 4.0 * 2.220446049250313e-16;
+__device__ bool jacobi_svd_columns(double (&A)[kTrackMaxTimes][kTrackMaxCoef], double (&V)[kTrackMaxCoef][kTrackMaxCoef], int n, int K) {
     for (int i = 0; i < K; ++i)
         for (int j = 0; j < K; ++j) V[i][j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; ++sweep) {
@@ -69,7 +72,7 @@ __device__ void jacobi_svd_columns(double (&A)[kTrackMaxTimes][kTrackMaxCoef], d
             for (int q = p + 1; q < K; ++q) {
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
                 for (int j = 0; j < n; ++j) alpha += A[j][p] * A[j][p], beta += A[j][q] * A[j][q], gamma += A[j][p] * A[j][q];
-                if (!(fabs(gamma) > 1e-16 * sqrt(alpha * beta)) || gamma == 0.0) continue; // already orthogonal to working precision
+                if (!(fabs(gamma) > kJacobiTol * sqrt(alpha * beta)) || gamma == 0.0) continue; // orthogonal to working precision (a few eps, as LAPACK's one-sided Jacobi)
                 rotated = true;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -85,8 +88,9 @@ __device__ void jacobi_svd_columns(double (&A)[kTrackMaxTimes][kTrackMaxCoef], d
                     V[k][q] = sn * vp + c * vq;
                 }
             }
-        if (!rotated) break;
+        if (!rotated) return true;
     }
+    return false; // the 30th sweep still rotated: not converged (the caller flags the sample)
 }
 
 // PolyfitController.provide_movement_vector (polyfit_controller.py:54-84) up to the camera offsets (the fit commutes with the
@@ -131,7 +135,11 @@ template <typename T> __global__ __launch_bounds__(64) void track_polyfit_kernel
         double tp = 1.0;
         for (int p = 0; p < K; ++p) L[j][p] = ww[j] * tp / scl[p], tp *= tt[j];
     }
-    jacobi_svd_columns(L, V, n, K);
+    if (!jacobi_svd_columns(L, V, n, K)) { // never seen (<= 16 x 8, well-scaled columns converge in 6-10 sweeps); reported as "no prediction" rather than silently used
+        a.pred[2 * i] = a.pred[2 * i + 1] = 0.0;
+        a.valid[i] = 0;
+        return;
+    }
     double s2[kTrackMaxCoef], s2max = 0.0;
     for (int e = 0; e < K; ++e) {
         double q = 0.0;

@@ -45,7 +45,7 @@ extern "C" int wtk_device_count(void) {
     return n;
 }
 
-#ifdef WTK_WS64_ABLATE // diagnostic builds: per-wave interval stamps of the kernel under study (tools/gpu_sessions/ws64_stamps.py)
+#ifdef WTK_WS64_STAMPS // diagnostic builds: per-wave interval stamps of the kernel under study (tools/gpu_sessions/ws64_stamps.py)
 static unsigned long long *g_dbg_stamps = nullptr;
 constexpr size_t kDbgStampBytes = 1 << 20;
 extern "C" int wtk_debug_stamps(unsigned long long *host, size_t n_words) {
@@ -1584,9 +1584,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 if (ws64) {
                     g.zeros = h->zero_page;
                     g.bm = h->ws64_weave;
-                    if (const char *e = std::getenv("WTK_WS64_ABLATE")) g.bm = std::atoi(e); // timing-only switches of -DWTK_WS64_ABLATE builds
                     if (const char *e = std::getenv("WTK_WS64_FLAGS")) g.slabs = std::atoi(e);  // 8: s_setprio around the multiply phase
-#ifdef WTK_WS64_ABLATE
+#ifdef WTK_WS64_STAMPS
                     if (std::getenv("WTK_WS64_STAMPS")) {
                         if (!g_dbg_stamps) HIP_TRY(hipMalloc(&g_dbg_stamps, kDbgStampBytes));
                         g.dbg_stamps = g_dbg_stamps;
@@ -2094,16 +2093,24 @@ extern "C" int wtk_hybrid_predict(wtk_hybrid *h, const uint8_t *frames_dev, int3
     if (!h) return fail("wtk_hybrid_predict: null handle");
     if (h->held) return fail("wtk_hybrid_predict: the full-precision handle is held by the caller (wtk_hybrid_hold)");
     DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
-    if (wtk_yolo_predict(h->fast, frames_dev, B, H, W, C, conf, 0.7f, 1, out_xywh, out_conf, out_anchor, stream)) return 1;
+    const long long fb = (long long)H * W * C;
     if (h->defer > 1) {
-        const long long fb = (long long)H * W * C;
-        if (fb % 16) return fail("wtk_hybrid_predict (defer > 1): frames must be a multiple of 16 bytes");
+        // every precondition of the deferred form is checked BEFORE the fast pass is enqueued: a call that fails must not have
+        // written fp16 rows that then never get their second look and are not counted in `overflow` either
+        if (!frames_dev || !out_xywh) return fail("wtk_hybrid_predict: null argument");
+        if (B <= 0 || B > 1024 || B > h->fast->max_batch) return fail("wtk_hybrid_predict (defer > 1): need 1 <= B <= min(1024, max_batch of the fast handle)");
+        if (fb <= 0 || fb % 16 || reinterpret_cast<uintptr_t>(frames_dev) % 16)
+            return fail("wtk_hybrid_predict (defer > 1): frames must be 16-byte aligned and a multiple of 16 bytes each");
+        if (reinterpret_cast<uintptr_t>(out_xywh) % 16) return fail("wtk_hybrid_predict (defer > 1): xywh rows must be 16-byte aligned");
+        if (h->q_frames && (h->q_H != H || h->q_W != W || h->q_C != C))
+            return fail("wtk_hybrid_predict (defer > 1): every call must bring frames of the same shape");
         if (!h->q_frames) { // the queue's frame copies: allocated at the first call, for its frame shape
             HIP_TRY(hipMalloc((void **)&h->q_frames, (size_t)h->k * (size_t)fb));
             h->q_H = H, h->q_W = W, h->q_C = C;
-        } else if (h->q_H != H || h->q_W != W || h->q_C != C) {
-            return fail("wtk_hybrid_predict (defer > 1): every call must bring frames of the same shape");
         }
+    }
+    if (wtk_yolo_predict(h->fast, frames_dev, B, H, W, C, conf, 0.7f, 1, out_xywh, out_conf, out_anchor, stream)) return 1;
+    if (h->defer > 1) {
         if (wtk_recheck_enqueue(h->fast->o_margin, B, h->margin, frames_dev, fb, h->q_frames, h->k, h->n_weak, h->q_ptrs[0], h->q_ptrs[1], h->q_ptrs[2], out_xywh,
                                 out_conf, out_anchor, h->pos_scratch, h->overflow, stream))
             return 1;

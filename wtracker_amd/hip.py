@@ -95,6 +95,20 @@ def _preload_torch_hip_runtime():
                 return  # fall back to the system runtime: nothing else to do here
 
 
+def request_hw_queues(n: int = 8) -> bool:
+    """Ask the HIP runtime for `n` hardware queues (GPU_MAX_HW_QUEUES; runtime default 4).  The detector keeps up to five streams busy per
+    process (two lanes, the shared pair of side streams, the caller's default stream); the runtime multiplexes streams onto its hardware queues
+    and streams that share one serialise (-3 %, and cliffs of -40 % for unlucky layouts: profiles/r02_notes.md §8).  The runtime reads the
+    variable when it initialises, so call this before the first HIP call of the process (before `import torch` touches the GPU); an explicit
+    value of the caller always wins.  OPT-IN on purpose: `load()` does not touch the environment, because children of the calling
+    process inherit it — several processes sharing ONE device (e.g. the gloo rehearsal of the multi-rank path) must keep the runtime default
+    (eight queues each: 19.5 k -> 4.9 k frames/s).  Returns True when the value was set by this call."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
+
+
 def load() -> C.CDLL:
     """Load libwtk_hip.so (built in-tree by `python -m wtracker_amd._build` / __graft_entry__.build())."""
     global _lib
@@ -103,13 +117,6 @@ def load() -> C.CDLL:
     if not os.path.exists(_LIB_PATH):
         raise WtkError(f"{_LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                        "there is no CPU fallback")
-    # Hardware queues: the detector keeps up to five streams busy per process (two lanes, the shared pair of side streams, the caller's default
-    # stream); the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) queues and streams that share one serialise (-3 %, and
-    # cliffs of -40 % for unlucky layouts: profiles/r02_notes.md §8).  The runtime reads the variable when it initialises, so this only takes
-    # effect when no HIP call was made yet — an explicit value of the caller always wins.  WTK_KEEP_HW_QUEUES=1 leaves the default alone
-    # (several processes sharing ONE device, e.g. the gloo rehearsal of the multi-rank path, must not ask for eight queues each).
-    if os.environ.get("WTK_KEEP_HW_QUEUES", "0") != "1":
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _preload_torch_hip_runtime()
     lib = C.CDLL(_LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float

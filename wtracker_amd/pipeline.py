@@ -177,7 +177,10 @@ class TrackPipeline:
         """Detect this rank's B frames of super-batch s, exchange, predict the super-batch's cycles (at once, or — with a detector that holds
         rows back — when the rows become final: flush() / synchronize() make everything final).
         `views` = (frame_index [B] int32 or None, pos_xy [B,2] int32, (view_w, view_h)): `frames_dev` then holds FULL frames
-        and the batch rows are their camera views (device crop + letterbox)."""
+        and the batch rows are their camera views (device crop + letterbox).
+        Returns the number of cycles whose ResMLP was enqueued by THIS call: with a plain detector the cycles of step s; with a deferring
+        detector (HybridDetector(defer = D)) 0 for the D - 1 steps a lane holds back and the cycles of all of them at the lane's flush —
+        movement vectors are then available up to D x lanes super-batches after their frames were seen."""
         lane = s % len(self.dets)
         if self.streams[lane] is None:
             return self._step_on_current_stream(s, lane, frames_dev, views)
@@ -210,7 +213,9 @@ class TrackPipeline:
         host pass: OptimalController's median head position of the NEXT imaging phase
         (optimal_controller.py:16-32) and, when `sample_times` is given, PolyfitController's weighted-fit extrapolation
         (polyfit_controller.py:54-84).  Returns {name: (targets float64 [n_cycles,2] absolute px, valid int32 [n_cycles])} as
-        device tensors; cycle i is the cycle of self.plan.anchors[i].  Call after the last step."""
+        device tensors; cycle i is the cycle of self.plan.anchors[i].  Call after the last step; rows a deferring detector still holds
+        back are made final first (flush()), so the targets never read a row that would still change."""
+        self.flush()
         n = len(self.plan.anchors)
         st = torch.cuda.current_stream(self.device)
         for ev in self.det_done:

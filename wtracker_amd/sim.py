@@ -1,15 +1,11 @@
-"""Minimal host-side harness that drives a controller exactly the way the reference's simulator
-drives a `SimController`, so the HIP controllers can be exercised (and compared with golden logs
-captured from the real reference) without the reference being present.
-
-It restates ONLY what the hot path's callers need:
+"""Host-side types the hot path's controllers are written against (SURVEY.md §8 b, f2):
   * TimingConfig / ExperimentConfig arithmetic           wtracker/sim/config.py:41-67, 105-111
-  * the frame loop + phase state machine + hook order    wtracker/sim/simulator.py:140-194
-  * the SimController plugin interface                   wtracker/sim/simulator.py:197-293
-  * platform motion profile (half cosine, residual carry) wtracker/sim/motor_controllers.py:58-88
-  * camera / microscope windows on a replicate-padded frame  wtracker/sim/view_controller.py:45-172
-  * the per-cycle track log (CSV schema)                 wtracker/sim/sim_controllers/logging_controller.py:95-116,145-185
-Image saving, tqdm, GUI prompts, disk readers are out of scope.
+  * the SimController plugin interface (hook names)      wtracker/sim/simulator.py:197-293
+  * the per-cycle track log (CSV schema) + box utilities wtracker/sim/sim_controllers/logging_controller.py:95-116,145-185,
+                                                         wtracker/utils/bbox_utils.py:118-167,232-253
+The DRIVER that calls these hooks is the reference's own `Simulator` (a controller of this package runs inside it unchanged:
+tests/test_dropin_reference.py).  The stand-in driver the tests and bench.py use where the reference is absent (frame loop, platform
+motor, camera views) is test infrastructure and lives in tests/harness/sim_harness.py, not in this package (round 4).
 """
 from __future__ import annotations
 
@@ -18,7 +14,7 @@ import csv
 import math
 from collections import deque
 from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 
@@ -76,160 +72,7 @@ class TimingConfig:
 
 
 # -------------------------------------------------------------------------------------------------
-# frame sources
-# -------------------------------------------------------------------------------------------------
-class BlankReader:
-    """Length provider with all-255 frames (the reference's DummyReader, frame_reader.py:247-272)."""
-
-    def __init__(self, num_frames: int, resolution: tuple, colored: bool = True):
-        self._n = num_frames
-        self.frame_shape = (*resolution, 3) if colored else tuple(resolution)
-        self._frame = np.full(self.frame_shape, 255, dtype=np.uint8)
-
-    def __len__(self):
-        return self._n
-
-    def __getitem__(self, idx: int) -> np.ndarray:
-        return self._frame.copy()
-
-
-class ArrayReader:
-    """Frames held in memory: uint8 [N,H,W] or [N,H,W,3]."""
-
-    def __init__(self, frames: np.ndarray):
-        assert frames.dtype == np.uint8 and frames.ndim in (3, 4)
-        self._frames = frames
-        self.frame_shape = tuple(frames.shape[1:])
-
-    def __len__(self):
-        return self._frames.shape[0]
-
-    def __getitem__(self, idx: int) -> np.ndarray:
-        if idx < 0 or idx >= len(self):
-            raise IndexError("index out of bounds")
-        return self._frames[idx]
-
-
-class ViewController:
-    """Cursor over a frame source + camera / microscope windows centred on the platform position."""
-
-    def __init__(self, frame_reader, camera_size=(251, 251), micro_size=(45, 45), init_position=(0, 0)):
-        assert camera_size[0] >= micro_size[0] and camera_size[1] >= micro_size[1]
-        self._frame_reader = frame_reader
-        self._idx = -1
-        self._camera_size = tuple(camera_size)
-        self._micro_size = tuple(micro_size)
-        self._pad = (camera_size[0] // 2, camera_size[1] // 2)
-        self._position = tuple(init_position)
-        self.set_position(*init_position)
-
-    # cursor
-    @property
-    def index(self) -> int:
-        return self._idx
-
-    def __len__(self):
-        return len(self._frame_reader)
-
-    def can_read(self) -> bool:
-        return 0 <= self._idx < len(self._frame_reader)
-
-    def seek(self, idx: int) -> bool:
-        self._idx = idx
-        return self.can_read()
-
-    def progress(self, n: int = 1) -> bool:
-        return self.seek(self._idx + n)
-
-    def reset(self):
-        self.seek(-1)
-
-    # geometry
-    @property
-    def position(self):
-        return self._position
-
-    @property
-    def camera_size(self):
-        return self._camera_size
-
-    @property
-    def micro_size(self):
-        return self._micro_size
-
-    def _window(self, size):
-        w, h = size
-        return self._position[0] - w // 2, self._position[1] - h // 2, w, h
-
-    @property
-    def camera_position(self):
-        return self._window(self._camera_size)
-
-    @property
-    def micro_position(self):
-        return self._window(self._micro_size)
-
-    def set_position(self, x, y):
-        # clamped to the UNPADDED frame extent (view_controller.py:129-131)
-        x = np.clip(x, 0, self._frame_reader.frame_shape[1] - 1)
-        y = np.clip(y, 0, self._frame_reader.frame_shape[0] - 1)
-        self._position = (x, y)
-
-    def move_position(self, dx, dy):
-        self.set_position(self._position[0] + dx, self._position[1] + dy)
-
-    def read(self) -> np.ndarray:
-        """Current frame with a replicate border of camera_size//2 (cv.copyMakeBorder BORDER_REPLICATE)."""
-        if not self.can_read():
-            raise IndexError("index out of bounds")
-        f = self._frame_reader[self._idx]
-        px, py = self._pad
-        pad = ((py, py), (px, px)) + (((0, 0),) if f.ndim == 3 else ())
-        return np.pad(f, pad, mode="edge")
-
-    def _view(self, size) -> np.ndarray:
-        w, h = size
-        x = self._position[0] + self._pad[0] - w // 2
-        y = self._position[1] + self._pad[1] - h // 2
-        # the reference slices rows by w and columns by h (view_controller.py:171); kept as is
-        return self.read()[y : y + w, x : x + h]
-
-    def camera_view(self) -> np.ndarray:
-        return self._view(self._camera_size)
-
-    def micro_view(self) -> np.ndarray:
-        return self._view(self._micro_size)
-
-
-# -------------------------------------------------------------------------------------------------
-# platform motor
-# -------------------------------------------------------------------------------------------------
-class SineMotorController:
-    """Half-cosine velocity profile; each step is rounded and its residual carried to the next."""
-
-    def __init__(self, timing_config: TimingConfig):
-        self.timing_config = timing_config
-        self.movement_steps = timing_config.moving_frame_num
-        self.queue: list = []
-
-    def register_move(self, dx, dy):
-        assert len(self.queue) == 0
-        n = self.movement_steps
-        for i in range(n):
-            frac = (np.cos((i * np.pi) / n) - np.cos(((i + 1) * np.pi) / n)) / 2
-            self.queue.append((frac * dx, frac * dy))
-
-    def step(self):
-        dx, dy = self.queue.pop(0)
-        rdx, rdy = round(dx), round(dy)
-        if self.queue:
-            nx, ny = self.queue[0]
-            self.queue[0] = (nx + (dx - rdx), ny + (dy - rdy))
-        return rdx, rdy
-
-
-# -------------------------------------------------------------------------------------------------
-# plugin interface + driver
+# plugin interface
 # -------------------------------------------------------------------------------------------------
 class SimController(abc.ABC):
     """Same hook names / signatures as the reference ABC (simulator.py:197-293)."""
@@ -256,76 +99,6 @@ class SimController(abc.ABC):
 
     @abc.abstractmethod
     def _cycle_predict_all(self, sim) -> np.ndarray: ...
-
-
-class Simulator:
-    def __init__(self, timing_config: TimingConfig, experiment_config: ExperimentConfig, sim_controller: SimController,
-                 reader=None, motor_controller=None):
-        self.timing_config = timing_config
-        self.experiment_config = experiment_config
-        self._sim_controller = sim_controller
-        if reader is None:
-            cam = timing_config.camera_size_px
-            pad = (cam[0] // 2 * 2, cam[1] // 2 * 2)
-            res = tuple(a + b for a, b in zip(experiment_config.orig_resolution, pad))
-            reader = BlankReader(experiment_config.num_frames, res, colored=True)
-        self._motor_controller = motor_controller or SineMotorController(timing_config)
-        self._view = ViewController(reader, timing_config.camera_size_px, timing_config.micro_size_px, experiment_config.init_position)
-
-    @property
-    def view(self) -> ViewController:
-        return self._view
-
-    @property
-    def position(self):
-        return self._view.position
-
-    @property
-    def frame_number(self) -> int:
-        return self._view.index
-
-    @property
-    def cycle_number(self) -> int:
-        return self._view.index // self.timing_config.cycle_frame_num
-
-    @property
-    def cycle_step(self) -> int:
-        return self._view.index % self.timing_config.cycle_frame_num
-
-    def camera_view(self) -> np.ndarray:
-        return self._view.camera_view()
-
-    def micro_view(self) -> np.ndarray:
-        return self._view.micro_view()
-
-    def run(self, visualize: bool = False, wait_key: bool = False):
-        tc, ctl, motor = self.timing_config, self._sim_controller, self._motor_controller
-        self._view.reset()
-        self._view.set_position(*self.experiment_config.init_position)
-        ctl.on_sim_start(self)
-        while self._view.progress():
-            step = self.cycle_step
-            if step == 0:
-                if self.cycle_number > 0:
-                    ctl.on_movement_end(self)
-                    ctl.on_cycle_end(self)
-                ctl.on_cycle_start(self)
-            ctl.on_camera_frame(self)
-            if step == 0:
-                ctl.on_imaging_start(self)
-            if step < tc.imaging_frame_num:
-                ctl.on_micro_frame(self)
-            if step == tc.imaging_frame_num - tc.pred_frame_num:
-                ctl.begin_movement_prediction(self)
-            if step == tc.imaging_frame_num:
-                ctl.on_imaging_end(self)
-                dx, dy = ctl.provide_movement_vector(self)
-                ctl.on_movement_start(self)
-                motor.register_move(dx, dy)
-            if tc.imaging_frame_num <= step < tc.imaging_frame_num + tc.moving_frame_num:
-                dx, dy = motor.step()
-                self._view.move_position(dx, dy)
-        ctl.on_sim_end(self)
 
 
 # -------------------------------------------------------------------------------------------------
