@@ -20,6 +20,52 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_bench_n_gt_1_branch_with_two_gloo_ranks(hip_lib):
+    """bench.py's N > 1 branch as a driver-run test (until now it had only been run by hand): `bench.py --gpus 2 --backend gloo`
+    as two rank processes sharing cuda:0 (started before this process touches the GPU).  The printed line must say world_size 2, carry a track
+    checksum that is equal on both ranks, headline the reference-precision mode with its device-side check green, and its `value` must be the
+    frames BOTH ranks processed in a window over that window's time."""
+    import json
+
+    import torch
+
+    assert not torch.cuda.is_initialized(), "this test must run before anything touches the GPU in this process"
+    world, steps = 2, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("GPU_MAX_HW_QUEUES", None)  # the ranks share one device: the runtime default
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", str(steps), "--warmup", "1", "--repeats", "1",
+               "--no-fp32", "--cpu-frames", "0", "--pool", "64"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][1][-3000:]}"
+    assert not torch.cuda.is_initialized()
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")], "only rank 0 prints the line"
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dtype"] == "f16x3" and line["scaling"] == "weak" and line["steps"] == steps
+    d = line["dist"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["checksum_equal_on_all_ranks"] is True and d["track_rows"] > 0
+    w = line["windows"]
+    assert w["n"] == 1 and w["steps_each"] == steps
+    assert abs(line["value"] - world * 64 * steps / (w["median_ms"] * 1e-3)) <= 1e-6 * line["value"]  # whole-job frames of the window / its time
+    assert abs(line["ms_per_step"] - w["median_ms"] / steps) <= 1e-9 * w["median_ms"]
+    chk = line["headline_check"]
+    assert chk["frames"] == world * 64 and chk["index_mismatches"] == 0 and chk["verified"] is True and line["headline_exactness_verified"] is True
+    assert line["config"]["global_batch"] == 128 and "cpu_baseline" not in line and "closed_loop" not in line
+
+
 def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
     import torch
 

@@ -134,6 +134,31 @@ def test_f16x3_fused_box_tail_equals_two_launches(hip_lib, monkeypatch, B, H, W)
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("B,H,W,nc", [(3, 128, 128, 1), (2, 352, 224, 3), (4, 640, 640, 1), (1, 1280, 736, 20)])
+def test_f16x3_fused_class_tail_equals_two_launches(hip_lib, monkeypatch, B, H, W, nc):
+    """Round 4: the Detect class towers' last 1x1 (128 -> nc, stored as up to 32 couts, fp32 logits) inside the epilogue of the split 3x3 before it
+    (`TAIL + SPLIT` instantiation at the 128-cout tile: split rows of both cout-waves in LDS, one barrier, K order of the stand-alone split 1x1)
+    against the launch of its own (WTK_NO_SPLIT_CLS_TAIL=1; the box towers stay fused in both): every class and box logit and every result
+    bit-identical, on 256- and 128-pixel blocks, ragged maps and several class counts; two fused runs catch a missing wait."""
+    w = ys.synthetic_weights("s", nc, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = np.random.default_rng(H + 5 * W + nc).integers(0, 256, size=(B, H, W), dtype=np.uint8)
+    outs = []
+    for off in ("1", "0", "0"):
+        monkeypatch.setenv("WTK_NO_SPLIT_CLS_TAIL", off)
+        det = hip.HipYolo(w, (H, W), B, dtype="f16x3", nc=nc, width=width, depth=depth, max_channels=maxch)
+        res = det.predict_host(frames, conf=0.01)
+        outs.append((res, det.debug_head(B)))
+        det.close()
+    ref_res, (ref_box, ref_cls) = outs[0]
+    assert np.abs(ref_cls).max() > 0 and ref_cls.shape[2] == nc
+    for res, (box, cls) in outs[1:]:
+        np.testing.assert_array_equal(cls, ref_cls)
+        np.testing.assert_array_equal(box, ref_box)
+        for x, y in zip(res, ref_res):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("size,B", [(640, 4), (1280, 2)])
 def test_f16x3_full_size_survivors_equal_oracle(hip_lib, size, B):
     """BASELINE configs 2 and 5 frame shapes (1280x1280: the window kernels cut the 160-column maps into two strips)."""

@@ -453,7 +453,7 @@ def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib,
         c = HipYoloController(tc, cfg, device_frames=dev_frames)
         return c
 
-    import wtracker_amd.sim as simmod
+    import harness.sim_harness as simmod
     orig_view = simmod.Simulator.camera_view
     simmod.Simulator.camera_view = lambda self: calls.append(1) or orig_view(self)
     try:

@@ -378,6 +378,8 @@ class HipYoloController(SimController):
         self._model = yolo_config.load_model()
         self._device_frames = device_frames
         self.last_rechecked = 0  # frames of the last predict call that were detected again at full precision (YoloConfig.recheck_margin)
+        self._view_stream = None  # device-resident path: the controller's own stream + per-batch-size buffers (predict_views)
+        self._view_bufs: dict = {}
         if device_frames is not None:
             if not getattr(device_frames, "is_cuda", False) or str(device_frames.dtype) != "torch.uint8" or device_frames.dim() not in (3, 4):
                 raise hip.WtkError("device_frames must be a CUDA uint8 tensor [F,H,W] or [F,H,W,3]")
@@ -443,16 +445,30 @@ class HipYoloController(SimController):
         n = len(entries)
         det = self._model.detector(yolo_spec.letterbox_shape(vw, vh, imgsz), n)  # the view's shape is (rows = w, cols = h)
         dev = fr.device
-        meta = torch.tensor([[e[0], e[1], e[2]] for e in entries], dtype=torch.int32).to(dev)  # one small upload per call
-        idx, pos = meta[:, 0].contiguous(), meta[:, 1:3].contiguous()
-        out = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        cf = torch.empty((n,), dtype=torch.float32, device=dev)
-        an = torch.empty((n,), dtype=torch.int32, device=dev)
+        # One set of device buffers per batch size, kept for the controller's life: the view table (frame numbers + positions, one small upload
+        # per call from pinned memory) and the output rows.  The library replays a captured forward pass for a call that comes back with the same
+        # device addresses (wtk_yolo_predict_views: the reference's operating point — one cycle batch and one single-frame call per cycle — is
+        # launch bound), which needs a stream of the controller's own: the legacy default stream cannot be captured.
+        if self._view_stream is None:
+            self._view_stream = torch.cuda.Stream(device=dev)
+            self._view_stream.wait_stream(torch.cuda.current_stream(dev))  # whatever produced `device_frames`
+        bufs = self._view_bufs.get(n)
+        if bufs is None:
+            bufs = self._view_bufs[n] = dict(meta=torch.empty((3 * n,), dtype=torch.int32, device=dev), host=torch.empty((3 * n,), dtype=torch.int32).pin_memory(),
+                                             out=torch.empty((n, 4), dtype=torch.float32, device=dev), cf=torch.empty((n,), dtype=torch.float32, device=dev),
+                                             an=torch.empty((n,), dtype=torch.int32, device=dev))
+        host = bufs["host"]
+        host[:n] = torch.tensor([e[0] for e in entries], dtype=torch.int32)
+        host[n:] = torch.tensor([[e[1], e[2]] for e in entries], dtype=torch.int32).reshape(-1)
+        meta, out, cf, an = bufs["meta"], bufs["out"], bufs["cf"], bufs["an"]
+        idx, pos = meta[:n], meta[n:].view(n, 2)
         C = fr.shape[3] if fr.dim() == 4 else 1
         net_hw = yolo_spec.letterbox_shape(vw, vh, imgsz)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), torch.cuda.stream(self._view_stream):
+            meta.copy_(host, non_blocking=True)
             det.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx, pos, n, vw, vh, out, cf, an, conf=conf, iou=iou, max_det=1,
-                              stream=torch.cuda.current_stream(dev).cuda_stream)
+                              stream=self._view_stream.cuda_stream)
+            self._view_stream.synchronize()
         xywh, anchor = out.cpu().numpy(), an.cpu().numpy()
         self.last_rechecked = 0
         if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
@@ -461,10 +477,10 @@ class HipYoloController(SimController):
                 wsel = torch.from_numpy(weak).to(dev)
                 det32 = self._model.detector(net_hw, len(weak), dtype=self.yolo_config.recheck_mode(self._model.nc))
                 k = len(weak)
-                with torch.cuda.device(dev):
+                with torch.cuda.device(dev), torch.cuda.stream(self._view_stream):
                     det32.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx[wsel].contiguous(), pos[wsel].contiguous(), k, vw, vh,
-                                        out[:k], cf[:k], an[:k], conf=conf, iou=iou, max_det=1, stream=torch.cuda.current_stream(dev).cuda_stream)
-                xywh[weak], anchor[weak] = out[:k].cpu().numpy(), an[:k].cpu().numpy()
+                                        out[:k], cf[:k], an[:k], conf=conf, iou=iou, max_det=1, stream=self._view_stream.cuda_stream)
+                    xywh[weak], anchor[weak] = out[:k].cpu().numpy(), an[:k].cpu().numpy()
                 self.last_rechecked = k
         if (anchor < 0).any():
             res = xywh.astype(np.float64)

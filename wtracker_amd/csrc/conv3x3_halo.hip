@@ -207,7 +207,7 @@ __device__ __forceinline__ int lane_fetch(int src_lane, int v) { return __builti
 // three MFMAs (hi*hi into acc, hi*lo + lo*hi into acc1); a.Cin / in_ld / out_ld / ... are pseudo-channel counts (2 x real), a.Cout is real.
 template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
-    static_assert(!SPLIT || (sizeof(T) == 2 && (!TAIL || BN == 64) && BN != 192 && MINW <= 2), "split mode: fp16 storage, 64 / 128 couts (fused tail: 64), 256-register budget");
+    static_assert(!SPLIT || (sizeof(T) == 2 && BN != 192 && MINW <= 2), "split mode: fp16 storage, 64 / 128 couts, 256-register budget");
 #ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -516,7 +516,104 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // 64-channel tensor and launching a second kernel that reads it back, the SiLU'd fp16 values go to a wave-local LDS tile
     // (the window buffer is free after the last tap's barrier) and are multiplied by the 1x1 weights right here.  Same fp16
     // rounding of the intermediate, same K order (two 32-deep steps), same MFMA: bit-identical to the two-kernel path.
-    if constexpr (TAIL && SPLIT) {
+    if constexpr (TAIL && SPLIT && BN == 128) {
+        // ---- split-fp16 form of the 128-cout tail (f16x3 handles, Detect class towers: 3x3 128 -> 128, then 1x1 128 -> nc stored as 32 padded
+        // couts, fp32 logits).  A wave holds 64 pixels x ONE HALF of the channels; every wave writes its SiLU'd values as split rows — per pixel and
+        // block of 32 channels one 128-byte row [hi32 | lo32], 2 x WP rows = 16 KB per wave — into a tile of its own, the two cout-waves of a pixel
+        // group meet at one block barrier, and each then multiplies HALF of the group's pixels over all four channel blocks (blocks 0, 1 from the
+        // low-channel wave's tile, 2, 3 from the high-channel one: the K order of the stand-alone split 1x1, per block hi.hi into acc2, lo.hi then
+        // hi.lo into acc2l, value = acc2 + 2^-11 acc2l: bit-identical to the two-kernel path).  The eight tiles (128 KB) take both window buffers
+        // (three each) and two of the three slab buffers — all free once the last tap's requests have landed (the last taps re-request a slab nobody
+        // reads: it must not land on a tile, hence the drain in front of the first store).
+        static_assert(WAVES_C == 2 && TC == 4 && TP % 2 == 0 && NHALO == 2 && NWB == 3 && kHaloBytesT >= 3 * 2 * WP * 128 && BN * 128 >= 2 * WP * 128,
+                      "split class-tower tail: 4 x 2 waves, three tiles per window buffer, one per slab buffer");
+        constexpr int kTile = 2 * WP * 128; // bytes of one wave's tile: rows blk * WP + p
+        auto tile_of = [&](int w) __attribute__((always_inline)) -> char * {
+            return w < 3 ? halo0 + w * kTile : (w < 6 ? halo1 + (w - 3) * kTile : (w == 6 ? wbuf0 : wbuf1));
+        };
+        const _Float16 *w2 = reinterpret_cast<const _Float16 *>(a.tail_w);
+        const int arow = (lr >> 2) * 8 + (lr & 3); // + 4i: the lane ends up owning couts lg*8 .. lg*8+7 of the 32 stored ones
+        half8 wh2[4][2], wl2[4][2];                // A fragments straight from global memory (16 KB of weights, L2 resident); requested first, used last
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const _Float16 *wr = w2 + (long long)(arow + 4 * i) * a.tail_kpad + kb * 64 + lg * 8;
+                wh2[kb][i] = *reinterpret_cast<const half8 *>(wr);
+                wl2[kb][i] = *reinterpret_cast<const half8 *>(wr + 32);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (also the weight fragments above: a few hundred cycles, once per block)
+        __builtin_amdgcn_s_barrier();                     // every wave's requests have landed, every wave is past its last fragment read
+        asm volatile("" ::: "memory");
+        {
+            char *mine = tile_of(wave) + (lg >> 1) * (WP * 128); // this lane's 16 couts lie in block lg / 2 of the wave's two, channels 16 (lg & 1) .. + 15 of it
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = j * 16 + lr;
+                float v[NV];
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                if (a.act) wtk_silu_scaled_run<NV>(v);
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    half8 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = v[c2 * 8 + e];
+                        const _Float16 hh = (_Float16)x;
+                        hv[e] = hh;
+                        lv[e] = (_Float16)((x - (float)hh) * kSplitScale);
+                    }
+                    const int c = 2 * (lg & 1) + c2; // chunk of the hi halves; the lo halves: + 4
+                    *reinterpret_cast<half8 *>(mine + p * 128 + ((c ^ (p & 7)) << 4)) = hv;
+                    *reinterpret_cast<half8 *>(mine + p * 128 + (((c + 4) ^ (p & 7)) << 4)) = lv;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int TPH = TP / 2; // pixel tiles of the group this wave finishes
+        floatx4 acc2[2][TPH], acc2l[2][TPH];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const floatx4 b4 = (floatx4){a.tail_bias[lg * 8 + i * 4 + 0], a.tail_bias[lg * 8 + i * 4 + 1], a.tail_bias[lg * 8 + i * 4 + 2], a.tail_bias[lg * 8 + i * 4 + 3]};
+#pragma unroll
+            for (int j = 0; j < TPH; ++j) acc2[i][j] = b4, acc2l[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const char *src = tile_of(wave_p * 2 + (kb >> 1)) + (kb & 1) * (WP * 128); // channels 0..63 of the group from the low-channel wave, 64..127 from the other
+#pragma unroll
+            for (int j = 0; j < TPH; ++j) {
+                const int p = (wave_c * TPH + j) * 16 + lr;
+                const half8 ph = *reinterpret_cast<const half8 *>(src + p * 128 + ((lg ^ (p & 7)) << 4));
+                const half8 pl = *reinterpret_cast<const half8 *>(src + p * 128 + (((lg + 4) ^ (p & 7)) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh2[kb][i], ph, acc2[i][j], 0, 0, 0);
+                    acc2l[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl2[kb][i], ph, acc2l[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc2l[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh2[kb][i], pl, acc2l[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TPH; ++j) {
+            const long long pix = lane_fetch((wave_c * TPH + j) * 16 + lr, pix_e);
+            if (pix < 0) continue;
+            float v2[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r] + acc2l[i][j][r] * kSplitInv;
+            if (lg * 8 < a.tail_cout) // padded couts are never stored; the class logits are an fp32 tensor (launch check)
+                store_run_h<8>(reinterpret_cast<float *>(a.tail_out) + pix * a.tail_ld + a.tail_coff + lg * 8, v2);
+        }
+        return;
+    } else if constexpr (TAIL && SPLIT) {
         // ---- split-fp16 form of the 64-cout tail (f16x3 handles, Detect box towers): the wave's SiLU'd values go to LDS as split rows — one 128-byte
         // row [hi32 | lo32] per pixel and block of 32 channels, block 0 in the first window buffer, block 1 in the second (both free after the last tap's
         // barrier), wave-local — and are multiplied by the split 1x1 weights as conv_igemm_kernel's split form does: two K steps (the blocks), per step
@@ -1746,8 +1843,11 @@ int split_halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 
 hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
     const int bn = split_halo_cout_tile(a.Cout);
     if (a.Cin % 64 != 0 || a.CoutPad % bn != 0 || a.Cout != a.CoutPad || a.slabs == 2) return hipErrorInvalidValue;
-    // fused 1x1 tail: 64 -> 64 couts only (box towers), split weights [64][tail_kpad = 128 pseudo-channels]
-    if (a.tail_w && (a.Cout != 64 || a.res || a.out2 || !a.tail_bias || !a.tail_out || a.tail_kpad != 128 || a.tail_cout != 64 || (a.tail_f32 ? (a.tail_ld % 4 || a.tail_coff % 4) : (a.tail_ld % 64 || a.tail_coff % 64))))
+    // fused 1x1 tail: 64 -> 64 couts (box towers), split weights [64][tail_kpad = 128 pseudo-channels]; 128 -> <= 32 stored couts with fp32 output
+    // (class towers), split weights [32][tail_kpad = 256 pseudo-channels]
+    if (a.tail_w && a.Cout == 128) {
+        if (a.res || a.out2 || !a.tail_bias || !a.tail_out || a.tail_kpad != 256 || a.tail_cout < 1 || a.tail_cout > 32 || !a.tail_f32 || a.tail_ld % 4 || a.tail_coff % 4) return hipErrorInvalidValue;
+    } else if (a.tail_w && (a.Cout != 64 || a.res || a.out2 || !a.tail_bias || !a.tail_out || a.tail_kpad != 128 || a.tail_cout != 64 || (a.tail_f32 ? (a.tail_ld % 4 || a.tail_coff % 4) : (a.tail_ld % 64 || a.tail_coff % 64))))
         return hipErrorInvalidValue;
     if (a.in_ld % 64 || a.in_coff % 64 || a.out_ld % 64 || a.out_coff % 64 || a.Kpad != 9 * a.Cin) return hipErrorInvalidValue;
     if (a.pitch != (a.strips == 1 ? a.S + 1 : a.S + 2) || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W || (a.strips == 1 && a.S != a.W))
@@ -1756,6 +1856,7 @@ hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
     if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % 64 || a.res_coff % 64)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % 64 || a.out2_coff % 64)) return hipErrorInvalidValue;
+    if (bn == 128 && a.tail_w) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);
     if (bn == 128) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
     if (a.tail_w) return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);
     return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);

@@ -536,6 +536,7 @@ struct wtk_yolo {
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
     int use_tail = 1; // WTK_NO_FUSED_TAIL=1: Detect box.2 as its own launch (A/B switch)
+    int use_tail_cls_split = 1; // WTK_NO_SPLIT_CLS_TAIL=1: f16x3 handles launch the class towers' last 1x1 on its own (A/B switch; fp16 handles: WTK_NO_FUSED_TAIL)
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
@@ -569,9 +570,18 @@ struct wtk_yolo {
         float conf;
         void *o_xywh, *o_conf, *o_anchor;
         hipGraphExec_t exec;
+        // views form (wtk_yolo_predict_views): the view table's device addresses and the view shape are part of the key
+        const void *idx = nullptr, *pos = nullptr;
+        int vw = 0, vh = 0, nf = 0;
+        bool same_args(const GraphEntry &o) const {
+            return frames == o.frames && B == o.B && H == o.H && W == o.W && C == o.C && conf == o.conf && o_xywh == o.o_xywh && o_conf == o.o_conf &&
+                   o_anchor == o.o_anchor && idx == o.idx && pos == o.pos && vw == o.vw && vh == o.vh && nf == o.nf;
+        }
     };
     std::vector<GraphEntry> graphs;
+    std::vector<GraphEntry> seen_once; // caller-buffer argument sets met once (exec == nullptr): captured when they come back
     int graph_max_batch = 16; // WTK_GRAPH_MAX_BATCH; 0 disables
+    int graph_views = 0;      // WTK_GRAPH_VIEWS=1: wtk_yolo_predict_views replays captures too (measured in round 4: no gain, so off by default)
     hipStream_t host_stream = nullptr; // stream of the *_host entry points (graph capture needs a non-null stream)
     int ev_created = 0;
     double prof_ms[kProfKernels] = {};
@@ -931,6 +941,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
+    if (const char *e = std::getenv("WTK_NO_SPLIT_CLS_TAIL")) h->use_tail_cls_split = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
@@ -942,6 +953,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         h->num_cus = prop.multiProcessorCount;
     }
     if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
+    if (const char *e = std::getenv("WTK_GRAPH_VIEWS")) h->graph_views = e[0] == '1';
 
     Planner P{h, specs, d->convs};
     const int *c = dims.c;
@@ -1089,7 +1101,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             }
             // class tower: 3x3 (128 -> 128) then 1x1 (128 -> nc, stored as cls_ld = 8, 16, 24 or 32 channels)
             Op &c1 = h->ops[first_op + 2], &c2 = h->ops[first_op + 4];
-            if (h->is_f16 && c1.halo == 1 && c1.cout == 128 && c1.cout_pad == 128 && c2.k == 1 && c2.cin == 128 && c2.cout <= 32 && c2.cout_pad == 32 &&
+            if ((h->is_f16 || (h->split && h->use_tail_cls_split)) && c1.halo == 1 && c1.cout == 128 && c1.cout_pad == 128 && c2.k == 1 && c2.cin == 128 && c2.cout <= 32 && c2.cout_pad == 32 &&
                 !c2.act && c2.in_buf == c1.out_buf && c2.res_buf < 0 && c2.out2_buf < 0 && c1.res_buf < 0 && c1.out2_buf < 0 && h->halo_slabs == 3 &&
                 c2.cout == h->cls_ld) {
                 c1.tail_op = (int)first_op + 4;
@@ -1679,6 +1691,38 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     return 0;
 }
 
+// Replay the captured forward pass of this argument set, or capture it now (the whole launch sequence incl. the side streams).
+static int graph_replay_or_capture(wtk_yolo *h, wtk_yolo::GraphEntry key, hipStream_t st, const ViewSrc *vs) {
+    for (auto &g : h->graphs)
+        if (g.same_args(key)) {
+            HIP_TRY(hipGraphLaunch(g.exec, st));
+            return 0;
+        }
+    hipGraph_t graph = nullptr;
+    if (h->use_side && h->side_streams > 0 && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
+    std::unique_lock<std::recursive_mutex> capture_lock(g_side_mu); // no other thread may touch the shared side streams while they are captured
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = yolo_enqueue(h, reinterpret_cast<const uint8_t *>(key.frames), key.B, key.H, key.W, key.C, key.conf, reinterpret_cast<float *>(key.o_xywh),
+                                reinterpret_cast<float *>(key.o_conf), reinterpret_cast<int32_t *>(key.o_anchor), st, vs);
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    capture_lock.unlock();
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return 1;
+    }
+    if (ec != hipSuccess) return fail_hip("hipStreamEndCapture", ec);
+    const hipError_t ei = hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail_hip("hipGraphInstantiate", ei);
+    if (h->graphs.size() >= 16) { // bounded cache: callers that rotate buffers would otherwise grow it without limit
+        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back(key);
+    HIP_TRY(hipGraphLaunch(key.exec, st));
+    return 0;
+}
+
 extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
                                 int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
     (void)iou; // with max_det == 1 the IoU threshold cannot change the survivor
@@ -1701,35 +1745,8 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
     const bool use_graph = own_buffers && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
     if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
-    for (auto &g : h->graphs)
-        if (g.frames == frames_dev && g.B == B && g.H == H && g.W == W && g.C == C && g.conf == conf && g.o_xywh == out_xywh &&
-            g.o_conf == out_conf && g.o_anchor == out_anchor) {
-            HIP_TRY(hipGraphLaunch(g.exec, st));
-            return 0;
-        }
-    hipGraph_t graph = nullptr;
-    if (h->use_side && h->side_streams > 0 && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
-    std::unique_lock<std::recursive_mutex> capture_lock(g_side_mu); // no other thread may touch the shared side streams while they are captured
-    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
-    const hipError_t ec = hipStreamEndCapture(st, &graph);
-    capture_lock.unlock();
-    if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return 1;
-    }
-    if (ec != hipSuccess) return fail_hip("hipStreamEndCapture", ec);
-    wtk_yolo::GraphEntry e{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
-    const hipError_t ei = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) return fail_hip("hipGraphInstantiate", ei);
-    if (h->graphs.size() >= 16) { // bounded cache: callers that rotate buffers would otherwise grow it without limit
-        (void)hipGraphExecDestroy(h->graphs.front().exec);
-        h->graphs.erase(h->graphs.begin());
-    }
-    h->graphs.push_back(e);
-    HIP_TRY(hipGraphLaunch(e.exec, st));
-    return 0;
+    wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
+    return graph_replay_or_capture(h, key, st, nullptr);
 }
 
 extern "C" int wtk_yolo_predict_nms(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
@@ -1773,6 +1790,23 @@ extern "C" int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, in
         h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
     }
     const ViewSrc vs{pos_xy_dev, frame_index_dev, view_w, view_h, n_frames};
+    // The reference's operating point is this call at B = 1 and B = one cycle (9 / 15 views), once per cycle each (yolo_controller.py:95-109).  With
+    // WTK_GRAPH_VIEWS=1 a caller that comes back with the SAME device addresses (frames, view table, output rows — HipYoloController keeps them per
+    // batch size) gets the captured forward replayed; an argument set is captured the second time it is met (a caller that rotates its buffers never
+    // pays for a capture).  OFF by default: measured in round 4 (bench.py `closed_loop`, 384 x 384 views) the replay changes a B = 1 call from 1.13 to
+    // 1.12 ms and a B = 15 call from 1.38 to 1.35 ms — these calls are bound by the ~60 dependent kernels' own latencies (18 us each on grids of a few
+    // blocks), not by the host's launch rate — while a replay costs its fixed 10-16 us.
+    const bool use_graph = h->graph_views && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
+    if (use_graph) {
+        wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
+        key.idx = frame_index_dev, key.pos = pos_xy_dev, key.vw = view_w, key.vh = view_h, key.nf = n_frames;
+        bool known = false;
+        for (auto &g : h->graphs) known = known || g.same_args(key);
+        for (auto &g : h->seen_once) known = known || g.same_args(key);
+        if (known) return graph_replay_or_capture(h, key, st, &vs);
+        if (h->seen_once.size() >= 16) h->seen_once.erase(h->seen_once.begin());
+        h->seen_once.push_back(key);
+    }
     return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, &vs);
 }
 
@@ -1807,7 +1841,7 @@ extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
     if (!h || n < 0 || n > 2) return fail("wtk_yolo_set_side_streams: n must be 0, 1 or 2");
     if (h->side_streams >= 3) return fail("wtk_yolo_set_side_streams: the handle was planned with WTK_SIDE_STREAMS=3");
     DEVICE_GUARD(h);
-    if (!h->graphs.empty() && h->host_stream) HIP_TRY(hipStreamSynchronize(h->host_stream)); // captured launches carry the old stream layout
+    if (!h->graphs.empty()) HIP_TRY(hipDeviceSynchronize()); // captured launches (host stream or a caller's) carry the old stream layout
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
     h->side_streams = n;
@@ -1820,7 +1854,7 @@ extern "C" int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev) {
     h->n_dyn = n_dev;
     if (!h->graphs.empty()) { // captured launches of the host entry points carry the old pointer
         DEVICE_GUARD(h);
-        if (h->host_stream) HIP_TRY(hipStreamSynchronize(h->host_stream));
+        HIP_TRY(hipDeviceSynchronize()); // replays may be in flight on the host stream or on a caller's
     }
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
