@@ -61,7 +61,7 @@ def plan(scale="s", nc=1):
     return ops
 
 
-def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
+def adapt_plan(ops, kernel_names, size=640, batch=64, es=2, split=None):
     """Replace the layer-by-layer entries by the fused launches a trace contains (fp16, YOLOv8s):
     front = model.0 + model.1 + model.2.cv1; C2f tail = model.2.m.0.cv1/cv2 + model.2.cv2.  The fused entries carry
     (flop, algorithmic bytes) in their last field."""
@@ -87,7 +87,7 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
     # Detect towers: the last 1x1 runs in the epilogue of the 3x3 before it (TAIL instantiations of the window kernel:
     # 64-cout tile = box tower, 128-cout tile = class tower)
     tails = {"box": any("conv3x3_halo_kernel" in k and "Li64E" in k and ("Lb1ELb0EEEvNS_8HaloArgsE" in k or "Lb1ELb1EEEvNS_8HaloArgsE" in k) for k in kernel_names),  # (TAIL, SPLIT) = (1, 0) fp16 / (1, 1) f16x3
-             "cls": any("conv3x3_halo_kernel" in k and "Li128E" in k and "Lb1ELb0EEEvNS_8HaloArgsE" in k for k in kernel_names)}
+             "cls": any("conv3x3_halo_kernel" in k and "Li128E" in k and ("Lb1ELb0EEEvNS_8HaloArgsE" in k or "Lb1ELb1EEEvNS_8HaloArgsE" in k) for k in kernel_names)}
     for tower, on in tails.items():
         if not on:
             continue
@@ -104,6 +104,20 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
                 o = (nm + "+2", "fused", st, 0, 0, 0, (fl, by))
             out.append(o)
         ops = out
+    # f16x3 handles (round 4): the 192-cout Detect stems run as a 128-cout launch (class part) + a 64-cout launch (box part) where one cout tile's
+    # blocks fill the chip (wtk_api.hip: strips * blocks_per_strip >= CUs); WTK_NO_SPLIT_STEM_PAIR=1 switches it off
+    if split is None:
+        split = any("front_fused_split" in k or "c32_split" in k for k in kernel_names)  # kernels only f16x3 handles launch
+    if split and os.environ.get("WTK_NO_SPLIT_STEM_PAIR") != "1":
+        out = []
+        for o in ops:
+            nm, kd, st, co, ci, k, ex = o
+            if nm.startswith("detect.") and nm.endswith(".0(box+cls)") and batch * (size // st + 1) ** 2 // 256 >= 256 and co == 192:
+                out.append((nm.replace("(box+cls)", "(cls 128)"), kd, st, 128, ci, k, ex))
+                out.append((nm.replace("(box+cls)", "(box 64)"), kd, st, 64, ci, k, ex))
+            else:
+                out.append(o)
+        ops = out
     return ops
 
 
@@ -119,7 +133,7 @@ def main():
     rows = list(csv.DictReader(open(args.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     mine = [r for r in rows if "wtk" in r["Kernel_Name"] and "mlp_kernel" not in r["Kernel_Name"]]
-    ops = adapt_plan(plan(), [r["Kernel_Name"] for r in mine], args.size, args.batch, es)
+    ops = adapt_plan(plan(), [r["Kernel_Name"] for r in mine], args.size, args.batch, es, split=args.dtype == "f16x3")
     per = len(ops)
     n_fw = len(mine) // per
     assert n_fw > args.skip, f"{len(mine)} wtk dispatches, {per} per forward"

@@ -536,6 +536,7 @@ struct wtk_yolo {
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
     int use_tail = 1; // WTK_NO_FUSED_TAIL=1: Detect box.2 as its own launch (A/B switch)
+    int split_stem_pair = 1;    // WTK_NO_SPLIT_STEM_PAIR=1: f16x3 handles run the 192-cout Detect stems as three 64-cout tiles of one launch (A/B switch)
     int use_tail_cls_split = 1; // WTK_NO_SPLIT_CLS_TAIL=1: f16x3 handles launch the class towers' last 1x1 on its own (A/B switch; fp16 handles: WTK_NO_FUSED_TAIL)
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
@@ -942,6 +943,7 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_SPLIT_CLS_TAIL")) h->use_tail_cls_split = e[0] != '1';
+    if (const char *e = std::getenv("WTK_NO_SPLIT_STEM_PAIR")) h->split_stem_pair = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
@@ -1621,7 +1623,21 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 if (ws64) {
                 } else if (h->split && op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32_split(g, st));
-                else if (h->split)
+                else if (h->split && h->split_stem_pair && op.cout == 192 && op.cout_pad == 192 && op.tail_op < 0 && !g.res && !g.out2 && g.bm != 128 &&
+                         (long long)g.strips * g.blocks_per_strip >= h->num_cus) {
+                    // The fused Detect stems (box 64 + class 128 couts, one window) on split operands: the 192-cout tile of the fp16 kernel does not fit two
+                    // accumulator sets, and three 64-cout tiles stage every window three times at the thin wave tile (32 px x 64 couts).  Two launches
+                    // instead — couts 64..191 at the 128-cout tile, couts 0..63 at the 64-cout tile: two stagings, two thirds of the work at the wide
+                    // wave tile; the same K order per output channel, so bit-identical (WTK_NO_SPLIT_STEM_PAIR=1: three 64-cout tiles).  Only where
+                    // one cout tile's blocks already fill the chip (P3, P4).
+                    HaloArgs g1 = g, g0 = g;
+                    g1.Cout = g1.CoutPad = 128;
+                    g1.w = reinterpret_cast<const _Float16 *>(g.w) + 64LL * g.Kpad, g1.bias = g.bias + 64, g1.out_coff = g.out_coff + 2 * 64;
+                    g0.Cout = g0.CoutPad = 64;
+                    HIP_TRY(launch_conv3x3_halo_split(g1, st));
+                    HIP_TRY(launch_conv3x3_halo_split(g0, st));
+                    ++launches[kid];
+                } else if (h->split)
                     HIP_TRY(launch_conv3x3_halo_split(g, st));
                 else if (op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32(g, st));
