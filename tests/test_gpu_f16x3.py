@@ -159,28 +159,6 @@ def test_f16x3_fused_class_tail_equals_two_launches(hip_lib, monkeypatch, B, H, 
             np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("B,H,W", [(12, 1280, 1280), (40, 640, 608)])
-def test_f16x3_detect_stems_as_two_launches_equal_three_tiles(hip_lib, monkeypatch, B, H, W):
-    """Round 4: the fused Detect stems (192 couts) of an f16x3 handle as a 128-cout launch + a 64-cout launch where one cout tile's blocks fill the chip
-    (P3 and P4 at these batches) against the three 64-cout tiles of one launch (WTK_NO_SPLIT_STEM_PAIR=1): per output channel the same products in the
-    same order — every head logit and result bit-identical."""
-    w = ys.synthetic_weights("s", 1, seed=0)
-    depth, width, maxch = ys.SCALES["s"]
-    frames = np.random.default_rng(H + 7 * W).integers(0, 256, size=(B, H, W), dtype=np.uint8)
-    outs = []
-    for off in ("1", "0"):
-        monkeypatch.setenv("WTK_NO_SPLIT_STEM_PAIR", off)
-        det = hip.HipYolo(w, (H, W), B, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
-        res = det.predict_host(frames, conf=0.05)
-        outs.append((res, det.debug_head(B)))
-        det.close()
-    (ref_res, (ref_box, ref_cls)), (res, (box, cls)) = outs
-    np.testing.assert_array_equal(box, ref_box)
-    np.testing.assert_array_equal(cls, ref_cls)
-    for x, y in zip(res, ref_res):
-        np.testing.assert_array_equal(x, y)
-
-
 @pytest.mark.parametrize("size,B", [(640, 4), (1280, 2)])
 def test_f16x3_full_size_survivors_equal_oracle(hip_lib, size, B):
     """BASELINE configs 2 and 5 frame shapes (1280x1280: the window kernels cut the 160-column maps into two strips)."""

@@ -386,7 +386,42 @@ def test_widest_class_count_at_scale_s_640(hip_lib):
             assert anchor[n] >= 0 and anchor_o[n] >= 0 and score_o[n].max() - score_o[n, anchor[n]] <= 1e-4, (n, anchor[n], anchor_o[n])
     det.close()
     with pytest.raises(hip.WtkError, match="nc"):
-        _models("s", size, "fp32", nc=80, max_batch=1)
+        _models("s", size, "fp32", nc=81, max_batch=1)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "f16x3"])
+def test_stock_80_class_head_at_640(hip_lib, dtype):
+    """A stock YOLOv8s head (nc = 80; 11.157 M parameters with Conv + BN folded) loads and runs: above 32 classes the class towers' last 1x1 is a launch of its own
+    (the fused tail stores 32 couts).  Every class logit within 2e-3 of the restatement's at BASELINE's frame size, the selection bit-exact against
+    the restatement's selection logic on the same logits (max over classes, fp32 score order, lowest anchor on equal scores), and the general NMS
+    entry point names the restatement's classes."""
+    size, B, nc = 640, 2, 80
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    w = ys.synthetic_weights("s", nc, seed=0)
+    assert sum(int(np.prod(wt.shape)) + len(b) for wt, b in w.values()) == 11156528  # folded weights + biases of the 63 convs (SURVEY: 11.157 M)
+    depth, width, maxch = ys.SCALES["s"]
+    oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, nc))
+    det = hip.HipYolo(w, (size, size), B, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch)
+    frames = fr.diverse_frames(B, size, seed=32000, per_seed=1)
+    box_o, cls_o, hw = _oracle_heads(oracle, frames, size)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.01)
+    box_g, cls_g = det.debug_head(B)
+    assert cls_g.shape == (B, 8400, nc)
+    assert np.abs(cls_g - cls_o.numpy()).max() < F32_LOGIT_ATOL and np.abs(box_g - box_o.numpy()).max() < F32_LOGIT_ATOL
+    xywh_s, conf_s, anchor_s = yo.postprocess(torch.from_numpy(box_g), torch.from_numpy(cls_g), (size, size), hw, conf=0.01)
+    np.testing.assert_array_equal(anchor, anchor_s)
+    np.testing.assert_allclose(xywh, xywh_s, rtol=0, atol=F32_BOX_ATOL)
+    np.testing.assert_allclose(conf, conf_s, rtol=0, atol=1e-6)
+    # general NMS over 80 classes (class-aware offsets): kept anchors and classes equal to the restatement's on the device's own logits
+    max_det = 10
+    xy, cf, kc, an, cnt = det.decode_nms_host(box_g, cls_g, size, size, max_det, conf=0.25, iou=0.7)
+    want = _oracle_nms_rows(box_g, cls_g, (size, size), (size, size), 0.25, 0.7, max_det)
+    for n in range(B):
+        bw, sw, cw, iw = want[n]
+        assert cnt[n] == len(iw)
+        np.testing.assert_array_equal(an[n, : cnt[n]], iw)
+        np.testing.assert_array_equal(kc[n, : cnt[n]], cw)
+    det.close()
 
 
 def test_letterbox_360_to_384_like_the_reference_workflow(hip_lib):

@@ -61,7 +61,7 @@ def plan(scale="s", nc=1):
     return ops
 
 
-def adapt_plan(ops, kernel_names, size=640, batch=64, es=2, split=None):
+def adapt_plan(ops, kernel_names, size=640, batch=64, es=2):
     """Replace the layer-by-layer entries by the fused launches a trace contains (fp16, YOLOv8s):
     front = model.0 + model.1 + model.2.cv1; C2f tail = model.2.m.0.cv1/cv2 + model.2.cv2.  The fused entries carry
     (flop, algorithmic bytes) in their last field."""
@@ -104,20 +104,6 @@ def adapt_plan(ops, kernel_names, size=640, batch=64, es=2, split=None):
                 o = (nm + "+2", "fused", st, 0, 0, 0, (fl, by))
             out.append(o)
         ops = out
-    # f16x3 handles (round 4): the 192-cout Detect stems run as a 128-cout launch (class part) + a 64-cout launch (box part) where one cout tile's
-    # blocks fill the chip (wtk_api.hip: strips * blocks_per_strip >= CUs); WTK_NO_SPLIT_STEM_PAIR=1 switches it off
-    if split is None:
-        split = any("front_fused_split" in k or "c32_split" in k for k in kernel_names)  # kernels only f16x3 handles launch
-    if split and os.environ.get("WTK_NO_SPLIT_STEM_PAIR") != "1":
-        out = []
-        for o in ops:
-            nm, kd, st, co, ci, k, ex = o
-            if nm.startswith("detect.") and nm.endswith(".0(box+cls)") and batch * (size // st + 1) ** 2 // 256 >= 256 and co == 192:
-                out.append((nm.replace("(box+cls)", "(cls 128)"), kd, st, 128, ci, k, ex))
-                out.append((nm.replace("(box+cls)", "(box 64)"), kd, st, 64, ci, k, ex))
-            else:
-                out.append(o)
-        ops = out
     return ops
 
 
@@ -133,7 +119,7 @@ def main():
     rows = list(csv.DictReader(open(args.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     mine = [r for r in rows if "wtk" in r["Kernel_Name"] and "mlp_kernel" not in r["Kernel_Name"]]
-    ops = adapt_plan(plan(), [r["Kernel_Name"] for r in mine], args.size, args.batch, es, split=args.dtype == "f16x3")
+    ops = adapt_plan(plan(), [r["Kernel_Name"] for r in mine], args.size, args.batch, es)
     per = len(ops)
     n_fw = len(mine) // per
     assert n_fw > args.skip, f"{len(mine)} wtk dispatches, {per} per forward"

@@ -536,7 +536,6 @@ struct wtk_yolo {
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
     int use_tail = 1; // WTK_NO_FUSED_TAIL=1: Detect box.2 as its own launch (A/B switch)
-    int split_stem_pair = 1;    // WTK_NO_SPLIT_STEM_PAIR=1: f16x3 handles run the 192-cout Detect stems as three 64-cout tiles of one launch (A/B switch)
     int use_tail_cls_split = 1; // WTK_NO_SPLIT_CLS_TAIL=1: f16x3 handles launch the class towers' last 1x1 on its own (A/B switch; fp16 handles: WTK_NO_FUSED_TAIL)
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
@@ -904,7 +903,9 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (d->dtype != WTK_F32 && d->dtype != WTK_F16 && d->dtype != WTK_F16X3) return fail("wtk_yolo_create: dtype must be WTK_F32, WTK_F16 or WTK_F16X3");
     if (d->imgsz_h <= 0 || d->imgsz_w <= 0 || d->imgsz_h % 32 || d->imgsz_w % 32) return fail("wtk_yolo_create: imgsz must be a positive multiple of 32");
     if (d->max_batch <= 0) return fail("wtk_yolo_create: max_batch must be positive");
-    if (d->nc < 1 || d->nc > 32) return fail("wtk_yolo_create: nc must be in [1, 32]");
+    // nc <= 32: the class towers' last 1x1 runs inside the 3x3 before it (32 stored couts); 33..80 (a stock 80-class YOLOv8 head): the same conv as a
+    // launch of its own (implicit GEMM over cls_ld = nc rounded up to 8 couts).  The reference trains single_cls (yolo/yolo_train_config.yaml:27).
+    if (d->nc < 1 || d->nc > 80) return fail("wtk_yolo_create: nc must be in [1, 80]");
     if (wtk_device_count() <= d->device) return fail("wtk_yolo_create: no such HIP device (is a GPU visible?)");
     const ModelDims dims = model_dims(d->width_mult, d->depth_mult, d->max_channels, d->nc);
     const std::vector<ConvSpec> specs = conv_specs(dims);
@@ -943,7 +944,6 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_SPLIT_CLS_TAIL")) h->use_tail_cls_split = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_SPLIT_STEM_PAIR")) h->split_stem_pair = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
@@ -1623,21 +1623,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 if (ws64) {
                 } else if (h->split && op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32_split(g, st));
-                else if (h->split && h->split_stem_pair && op.cout == 192 && op.cout_pad == 192 && op.tail_op < 0 && !g.res && !g.out2 && g.bm != 128 &&
-                         (long long)g.strips * g.blocks_per_strip >= h->num_cus) {
-                    // The fused Detect stems (box 64 + class 128 couts, one window) on split operands: the 192-cout tile of the fp16 kernel does not fit two
-                    // accumulator sets, and three 64-cout tiles stage every window three times at the thin wave tile (32 px x 64 couts).  Two launches
-                    // instead — couts 64..191 at the 128-cout tile, couts 0..63 at the 64-cout tile: two stagings, two thirds of the work at the wide
-                    // wave tile; the same K order per output channel, so bit-identical (WTK_NO_SPLIT_STEM_PAIR=1: three 64-cout tiles).  Only where
-                    // one cout tile's blocks already fill the chip (P3, P4).
-                    HaloArgs g1 = g, g0 = g;
-                    g1.Cout = g1.CoutPad = 128;
-                    g1.w = reinterpret_cast<const _Float16 *>(g.w) + 64LL * g.Kpad, g1.bias = g.bias + 64, g1.out_coff = g.out_coff + 2 * 64;
-                    g0.Cout = g0.CoutPad = 64;
-                    HIP_TRY(launch_conv3x3_halo_split(g1, st));
-                    HIP_TRY(launch_conv3x3_halo_split(g0, st));
-                    ++launches[kid];
-                } else if (h->split)
+                else if (h->split)
                     HIP_TRY(launch_conv3x3_halo_split(g, st));
                 else if (op.halo == 2)
                     HIP_TRY(launch_conv3x3_c32(g, st));
