@@ -112,7 +112,7 @@ typedef struct wtk_yolo_desc {
     int32_t imgsz_h;    /* network input height (multiple of 32) */
     int32_t imgsz_w;    /* network input width  (multiple of 32) */
     int32_t max_batch;  /* frames per forward pass the workspace is sized for */
-    int32_t nc;         /* number of classes (1 for the worm detector, yolo_train_config.yaml:27) */
+    int32_t nc;         /* number of classes, 1 .. 80 (1 for the worm detector, yolo_train_config.yaml:27; 80 = a stock YOLOv8 head) */
     float width_mult;   /* 0.50 for YOLOv8s */
     float depth_mult;   /* 0.33 for YOLOv8s */
     int32_t max_channels; /* 1024 for YOLOv8s */
