@@ -497,6 +497,15 @@ def test_closed_loop_sim_with_yolo_controller_matches_oracle_controller(hip_lib,
         simmod.Simulator.camera_view = orig_view
     assert not calls, "the device-resident controller must never ask the simulator for a host crop"
     assert m_d == m_g and rows_d == rows_g
+    # the same loop with the views entry point replaying captured hipGraphs (WTK_GRAPH_VIEWS=1, read when the handle is created: the controller
+    # returns with the same device addresses per batch size, so every call after the second of a kind is a replay): identical rows
+    os.environ["WTK_GRAPH_VIEWS"] = "1"
+    try:
+        cfg_g = YoloConfig(model_path=path, device="cuda", pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="fp32", scale="n", max_batch=16)
+        m_r, rows_r = run(lambda tc: HipYoloController(tc, cfg_g, device_frames=dev_frames))
+    finally:
+        del os.environ["WTK_GRAPH_VIEWS"]
+    assert m_r == m_g and rows_r == rows_g
     assert len(rows_g) == len(rows_o) == 36  # 4 full cycles; the trailing partial cycle is never logged
     for a, b in zip(rows_g, rows_o):
         assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
