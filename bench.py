@@ -516,7 +516,12 @@ def main():
         m = (len(frames) // 64) * 64
         rows = {}
         for d in (dt, "fp32"):
-            det = mk(d, 64)
+            if d == "hybrid":  # the look-twice object on the run's margin (immediate form: rows are final when the call returns)
+                from wtracker_amd.hybrid import HybridDetector
+
+                det = HybridDetector(mk("fp16", 64), mk("f16x3", 64), margin=args.hybrid_margin, k=64)
+            else:
+                det = mk(d, 64)
             x, c, a = (torch.empty((m, 4), dtype=torch.float32, device=dev), torch.empty((m,), dtype=torch.float32, device=dev),
                        torch.empty((m,), dtype=torch.int32, device=dev))
             for i in range(0, m, 64):
