@@ -330,11 +330,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_split_kernel(const HaloArg
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = wtk_split_value(acc[i][j][r], acc1[i][j][r]);
             if (a.act) wtk_silu_scaled_run<NV>(v);
             if (res) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] += (float)rcur[j][0][e] + (float)rcur[j][1][e] * kSplitInv;
+                for (int e = 0; e < NV; ++e) v[e] += wtk_split_value((float)rcur[j][0][e], (float)rcur[j][1][e]);
             }
             wtk_split_store<NV>(out + pix * a.out_ld + a.out_coff, cb, v);
         }

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = wtk_split_value(acc[i][j][r], acc1[i][j][r]);
                 if (a.act) wtk_silu_scaled_run<NV>(v);
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r] + acc2l[i][j][r] * kSplitInv;
+                for (int r = 0; r < 4; ++r) v2[i * 4 + r] = wtk_split_value(acc2[i][j][r], acc2l[i][j][r]);
             if (lg * 8 < a.tail_cout) // padded couts are never stored; the class logits are an fp32 tensor (launch check)
                 store_run_h<8>(reinterpret_cast<float *>(a.tail_out) + pix * a.tail_ld + a.tail_coff + lg * 8, v2);
         }
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = wtk_split_value(acc[i][j][r], acc1[i][j][r]);
                 if (a.act) wtk_silu_scaled_run<NV>(v);
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v2[i * 4 + r] = acc2[i][j][r] + acc2l[i][j][r] * kSplitInv;
+                for (int r = 0; r < 4; ++r) v2[i * 4 + r] = wtk_split_value(acc2[i][j][r], acc2l[i][j][r]);
             if (a.tail_f32)
                 store_run_h<16>(reinterpret_cast<float *>(a.tail_out) + pix * a.tail_ld + a.tail_coff + lg * 16, v2); // head logits stay fp32
             else
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if constexpr (SPLIT)
-                    v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                    v[i * 4 + r] = wtk_split_value(acc[i][j][r], acc1[i][j][r]);
                 else
                     v[i * 4 + r] = acc[i][j][r];
             }
@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(const HaloArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if constexpr (SPLIT)
-                        v[i * 4 + r] = acc[i][j][r] + acc1[i][j][r] * kSplitInv;
+                        v[i * 4 + r] = wtk_split_value(acc[i][j][r], acc1[i][j][r]);
                     else
                         v[i * 4 + r] = acc[i][j][r];
                 }

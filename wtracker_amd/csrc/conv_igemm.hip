@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if constexpr (SPLIT)
-                            v[t * 4 + r] = acc[t][j][r] + acc1[t][j][r] * kSplitInv; // bias already inside acc
+                            v[t * 4 + r] = wtk_split_value(acc[t][j][r], acc1[t][j][r]); // bias already inside acc
                         else
                             v[t * 4 + r] = acc[t][j][r]; // bias already inside
                     }

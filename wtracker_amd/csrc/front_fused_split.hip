@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if constexpr (SS)
-                            t[i * 4 + r] = acc[it][i][r] + ffs_pin(acc1[it][i][r] * kSplitInv);
+                            t[i * 4 + r] = wtk_split_value(acc[it][i][r], acc1[it][i][r]);
                         else
                             t[i * 4 + r] = acc[it][i][r];
                     }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[i * 4 + r] = acc[i][r] + ffs_pin(acc1[i][r] * kSplitInv);
+                for (int r = 0; r < 4; ++r) t[i * 4 + r] = wtk_split_value(acc[i][r], acc1[i][r]);
             wtk_silu_scaled_run<8, !WTK_FFS_PACKED>(t);
             half8 hv, lv;
             split8(t, hv, lv);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void front_fused_split_kernel(const FrontAr
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[i * 4 + r] = acc[i][r] + ffs_pin(acc1[i][r] * kSplitInv);
+                for (int r = 0; r < 4; ++r) t[i * 4 + r] = wtk_split_value(acc[i][r], acc1[i][r]);
             wtk_silu_scaled_run<8, !WTK_FFS_PACKED>(t);
             split8(t, pend[0], pend[1]);
             const int oy = oy0 + orow, ox = ox0 + lr;

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = acc[i][j][r]; // bias already inside
-                if constexpr (SPLIT) s += acc1[i][j][r] * kSplitInv;
+                if constexpr (SPLIT) s = wtk_split_value(s, acc1[i][j][r]);
                 v[i * 4 + r] = wtk_silu_scaled(s);
             }
         if constexpr (SPLIT) { // one pixel = 2 * Cout halves
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512) void sppf_pool_kernel(const PoolArgs a) {
             const half4_p hv = *reinterpret_cast<const half4_p *>(p), lv = *reinterpret_cast<const half4_p *>(p + 32);
             V v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (float)hv[e] + (float)lv[e] * kSplitInv;
+            for (int e = 0; e < 4; ++e) v[e] = wtk_split_value((float)hv[e], (float)lv[e]);
             A[i] = v;
         } else {
             A[i] = *reinterpret_cast<const V *>(base + (long long)px * ld + g * CE);

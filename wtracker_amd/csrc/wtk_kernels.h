@@ -109,6 +109,10 @@ template <int NV, bool SCALAR = false> __device__ __forceinline__ void wtk_silu_
 // Range: |x| must stay below the fp16 maximum (65504), as in the fp16 mode.
 // ---------------------------------------------------------------------------------------------
 constexpr float kSplitScale = 2048.0f, kSplitInv = 1.0f / 2048.0f;
+// value of a split pair / of the two accumulators of a split product: hi + lo * 2^-11 as ONE fused multiply-add.  The product is exact (a power of
+// two), so the single rounding of the fma is the rounding of the separate multiply + add this replaces — the same bits, one VALU op less per value
+// in epilogues that are VALU bound (-ffp-contract=off keeps the compiler from fusing on its own, hence the explicit builtin)
+__device__ __forceinline__ float wtk_split_value(float hi, float lo) { return __builtin_fmaf(lo, kSplitInv, hi); }
 typedef _Float16 wtk_h8 __attribute__((ext_vector_type(8)));
 // store NV (8 or 16) consecutive channels starting at real channel c (multiple of NV) of one pixel; `pix` = the pixel's pseudo-channel 0
 template <int NV> __device__ __forceinline__ void wtk_split_store(_Float16 *pix, int c, const float (&v)[NV]) {
@@ -134,7 +138,7 @@ template <int NV> __device__ __forceinline__ void wtk_split_load(const _Float16 
     for (int i = 0; i < NV; i += 8) {
         const wtk_h8 hv = *reinterpret_cast<const wtk_h8 *>(p + i), lv = *reinterpret_cast<const wtk_h8 *>(p + 32 + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[i + j] = (float)hv[j] + (float)lv[j] * kSplitInv;
+        for (int j = 0; j < 8; ++j) v[i + j] = wtk_split_value((float)hv[j], (float)lv[j]);
     }
 }
 
