@@ -622,6 +622,14 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
     issue_stage(smem0);
     if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads(); // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+#ifdef WTK_IGEMM_STAMPS // diagnostic builds (tools/igemm_stamps_split.hip): per-wave cycle totals of a K step's request issue, multiply (+ epilogue), vmcnt wait, barrier wait
+    unsigned long long st_sum[4] = {0, 0, 0, 0};
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#define WTK_ST(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i] += t_ - st_prev; st_prev = t_; }
+    unsigned long long st_prev = st_c0;
+#else
+#define WTK_ST(i)
+#endif
     for (int s = 0; s < total_stages; s += 2) {
 #if WTK_IGEMM_ORDER == 1
         compute_half(smem0, 0);
@@ -629,6 +637,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem0, 1);
 #else
         if (s + 1 < total_stages) issue_stage(smem1); // smem1 was last read before the previous barrier
+        WTK_ST(0)
         if constexpr (SPLIT) {
             compute_split(smem0);
         } else {
@@ -637,8 +646,14 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         }
 #endif
         after_compute(smem0);
+#ifdef WTK_IGEMM_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        WTK_ST(1)
         if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WTK_ST(2)
         __syncthreads();
+        WTK_ST(3)
         if (s + 1 >= total_stages) break;
 #if WTK_IGEMM_ORDER == 1
         compute_half(smem1, 0);
@@ -646,6 +661,7 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         compute_half(smem1, 1);
 #else
         if (s + 2 < total_stages) issue_stage(smem0);
+        WTK_ST(0)
         if constexpr (SPLIT) {
             compute_split(smem1);
         } else {
@@ -654,9 +670,25 @@ __global__ __launch_bounds__(64 * WAVES_P * WAVES_C, (2 * (BM + BN) * 128 <= 52 
         }
 #endif
         after_compute(smem1);
+#ifdef WTK_IGEMM_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        WTK_ST(1)
         if constexpr (BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WTK_ST(2)
         __syncthreads();
+        WTK_ST(3)
     }
+#ifdef WTK_IGEMM_STAMPS
+    if (lane == 0 && a.dbg_stamps) {
+        unsigned long long *o = a.dbg_stamps + ((long long)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 4; ++i) o[i] = st_sum[i];
+        o[4] = (unsigned long long)total_stages;
+        o[5] = __builtin_amdgcn_s_memtime() - st_c0;
+        o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
+#undef WTK_ST
 }
 
 int conv_cfg_bm(int cfg) { return (cfg == CFG_128x128 || cfg == CFG_128x64) ? 128 : 256; }

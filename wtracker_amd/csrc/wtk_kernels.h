@@ -184,6 +184,9 @@ struct ConvArgs {
     void *tail_out;
     int tail_kpad, tail_ld, tail_coff, tail_act;
     const int *n_dyn; // nullable: device-side image count <= N; pixel tiles that start beyond its last image are never visited
+#ifdef WTK_IGEMM_STAMPS
+    unsigned long long *dbg_stamps; // diagnostic builds only: [grid][waves][8] cycle sums
+#endif
     int out_f32; // fp16 kernels only: `out` is an fp32 tensor (the six Detect output convs: head logits are never rounded to fp16)
     // split mode (launch_conv_split): in / in2 / res / out / out2 are split-fp16 tensors; in_ld, in_coff, Cin, K, Kpad, in2_*, res_*, out_ld,
     // out_coff are given in PSEUDO-channels (2 x the real ones); Cout / CoutPad stay real (an fp32 `out` keeps real out_ld / out_coff)
@@ -200,6 +203,9 @@ hipError_t conv_init_attributes();
 // fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
 hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream);
+// 1x1 / stride-1 convs as two alternating four-wave groups per workgroup (conv1x1_pp.hip); split != 0: split-fp16 operands (pseudo-channel arguments)
+bool conv1x1_pp_eligible(const ConvArgs &a, int split);
+hipError_t launch_conv1x1_pp(ConvArgs a, int split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input window (conv3x3_halo.hip).
