@@ -159,31 +159,6 @@ def test_f16x3_fused_class_tail_equals_two_launches(hip_lib, monkeypatch, B, H, 
             np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("B,H,W", [(3, 128, 128), (2, 352, 224), (8, 640, 640), (1, 1280, 736)])
-def test_f16x3_alternating_group_1x1_kernel_equals_implicit_gemm(hip_lib, monkeypatch, B, H, W):
-    """Round 4: the 1x1 layers of an f16x3 handle through conv1x1_pp_kernel (two four-wave groups of one workgroup half a K step apart: one multiplies
-    while its SIMD partner issues LDS-DMA requests / runs its epilogue) against the two independent blocks of conv_igemm_kernel (WTK_NO_PP_1X1=1): the same
-    products in the same order — every head logit and result bit-identical; ragged pixel tiles, one and several cout tiles, odd tile counts (a group
-    that idles through its partner's last tiles); two runs of the new kernel catch a missing wait."""
-    w = ys.synthetic_weights("s", 1, seed=0)
-    depth, width, maxch = ys.SCALES["s"]
-    frames = np.random.default_rng(H + 11 * W).integers(0, 256, size=(B, H, W), dtype=np.uint8)
-    outs = []
-    for off in ("1", "0", "0"):
-        monkeypatch.setenv("WTK_NO_PP_1X1", off)
-        det = hip.HipYolo(w, (H, W), B, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch)
-        res = det.predict_host(frames, conf=0.05)
-        outs.append((res, det.debug_head(B)))
-        det.close()
-    ref_res, (ref_box, ref_cls) = outs[0]
-    assert np.abs(ref_box).max() > 0
-    for res, (box, cls) in outs[1:]:
-        np.testing.assert_array_equal(box, ref_box)
-        np.testing.assert_array_equal(cls, ref_cls)
-        for x, y in zip(res, ref_res):
-            np.testing.assert_array_equal(x, y)
-
-
 @pytest.mark.parametrize("size,B", [(640, 4), (1280, 2)])
 def test_f16x3_full_size_survivors_equal_oracle(hip_lib, size, B):
     """BASELINE configs 2 and 5 frame shapes (1280x1280: the window kernels cut the 160-column maps into two strips)."""

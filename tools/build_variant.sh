@@ -8,7 +8,7 @@ D=/tmp/wtk_variant_$NAME
 rm -rf $D && mkdir -p $D/wtracker_amd $D/include && cp -r wtracker_amd/csrc $D/wtracker_amd/csrc && cp include/wtk_hip.h $D/include/
 cd $D/wtracker_amd/csrc && rm -f *.o
 objs=""
-for f in wtk_api conv_igemm conv1x1_wide conv1x1_pp conv3x3_halo conv3x3_c32 front_fused front_fused_split c2f_fused stem_pool head mlp track_ops comm; do
+for f in wtk_api conv_igemm conv1x1_wide conv3x3_halo conv3x3_c32 front_fused front_fused_split c2f_fused stem_pool head mlp track_ops comm; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wall -Wno-unused-function $FLAGS -c $f.hip -o $f.o &
   objs="$objs $f.o"
 done

@@ -8,7 +8,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwtk_hip.so")
-SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv1x1_wide.hip", "conv1x1_pp.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "front_fused_split.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
+SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "front_fused_split.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
 HEADERS = ["wtk_kernels.h", os.path.join("..", "..", "include", "wtk_hip.h")]
 
 

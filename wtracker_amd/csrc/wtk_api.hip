@@ -536,7 +536,6 @@ struct wtk_yolo {
     int use_halo = 1;
     int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
     int use_tail = 1; // WTK_NO_FUSED_TAIL=1: Detect box.2 as its own launch (A/B switch)
-    int use_pp = 1; // WTK_NO_PP_1X1=1: 1x1 convs through conv_igemm_kernel instead of conv1x1_pp_kernel (A/B switch, bit-identity test)
     int use_tail_cls_split = 1; // WTK_NO_SPLIT_CLS_TAIL=1: f16x3 handles launch the class towers' last 1x1 on its own (A/B switch; fp16 handles: WTK_NO_FUSED_TAIL)
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
@@ -945,7 +944,6 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
     if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_SPLIT_CLS_TAIL")) h->use_tail_cls_split = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_PP_1X1")) h->use_pp = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
     if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
@@ -1562,10 +1560,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 g.zeros = h->zero_page;
                 HIP_TRY(launch_conv3x3_s2_split(g, st));
             } else if (h->split && !op.halo) {
-                if (h->use_pp && op.cfg == CFG_128x128 && conv1x1_pp_eligible(a, 1))
-                    HIP_TRY(launch_conv1x1_pp(a, 1, st)); // two alternating four-wave groups per workgroup (conv1x1_pp.hip)
-                else
-                    HIP_TRY(launch_conv_split(a, op.cfg, st));
+                HIP_TRY(launch_conv_split(a, op.cfg, st));
             } else if (op.halo) {
                 HaloArgs g;
                 std::memset(&g, 0, sizeof(g));

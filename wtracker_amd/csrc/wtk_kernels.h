@@ -203,9 +203,6 @@ hipError_t conv_init_attributes();
 // fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
 hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream);
-// 1x1 / stride-1 convs as two alternating four-wave groups per workgroup (conv1x1_pp.hip); split != 0: split-fp16 operands (pseudo-channel arguments)
-bool conv1x1_pp_eligible(const ConvArgs &a, int split);
-hipError_t launch_conv1x1_pp(ConvArgs a, int split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-resident input window (conv3x3_halo.hip).
