@@ -53,17 +53,28 @@ def test_bench_n_gt_1_branch_with_two_gloo_ranks(hip_lib):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][1][-3000:]}"
     assert not torch.cuda.is_initialized()
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")], "only rank 0 prints the line"
-    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    raw = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(raw) == 1 and outs[0][0].rstrip().endswith(raw[0]), "ONE json line, and it is the last thing on stdout"
+    assert len(raw[0]) < 4096, len(raw[0])  # the driver keeps a bounded tail of stdout (BENCH_r04: a 25 KB line did not parse)
+    line = json.loads(raw[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "windows", "headline_exactness_verified", "value_f16x3", "detail"):
+        assert k in line, k
+    assert line["roofline"]["peak_basis"].startswith("fp16 dense") and 0 < line["roofline"]["frac"] < 1
+    detail = json.load(open(os.path.join(ROOT, line["detail"])))  # the full object: per-kernel lines, per-mode objects
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-6) and detail["roofline"]["kernels"]
     assert line["n_gpus"] == 2 and line["dtype"] == "f16x3" and line["scaling"] == "weak" and line["steps"] == steps
     d = line["dist"]
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["checksum_equal_on_all_ranks"] is True and d["track_rows"] > 0
     w = line["windows"]
     assert w["n"] == 1 and w["steps_each"] == steps
-    assert abs(line["value"] - world * 64 * steps / (w["median_ms"] * 1e-3)) <= 1e-6 * line["value"]  # whole-job frames of the window / its time
-    assert abs(line["ms_per_step"] - w["median_ms"] / steps) <= 1e-9 * w["median_ms"]
+    wd = detail["windows"]
+    assert abs(detail["value"] - world * 64 * steps / (wd["median_ms"] * 1e-3)) <= 1e-6 * detail["value"]  # whole-job frames of the window / its time
+    assert abs(detail["ms_per_step"] - wd["median_ms"] / steps) <= 1e-9 * wd["median_ms"]
+    assert abs(line["ms_per_step"] - w["median_ms"] / steps) <= 1e-3 * line["ms_per_step"]  # (the line carries rounded figures)
     chk = line["headline_check"]
     assert chk["frames"] == world * 64 and chk["index_mismatches"] == 0 and chk["verified"] is True and line["headline_exactness_verified"] is True
-    assert line["config"]["global_batch"] == 128 and "cpu_baseline" not in line and "closed_loop" not in line
+    assert line["config"]["global_batch"] == 128 and "cpu_baseline" not in line and "closed_loop" not in detail
 
 
 def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
