@@ -192,31 +192,20 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
            "frames": f"{ec.num_frames} synthetic {size}x{size} uint8 gray frames resident in HBM, camera view 360x360 -> imgsz 384, conf {conf}",
            "timing_ms": [200, 40, 50], "cycle_frames": 15, "cycles": cycles, "calls_per_cycle": "one B=15 _cycle_predict_all + one B=1 provide_movement_vector"}
     ref_moves = None
-    prev_graph = os.environ.get("WTK_GRAPH_VIEWS")
-    for dtype in ("f16x3", "fp32"):
-        for graph in (True, False):
-            os.environ["WTK_GRAPH_VIEWS"] = "1" if graph else "0"  # read when a handle is created; the library's default is 0 (eager launches)
-            cfg = YoloConfig(model_path=tmp.name, device=f"cuda:{device}", pred_kwargs={"imgsz": 384, "conf": conf}, dtype=dtype, scale=scale, max_batch=16)
-            drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))  # warm-up pass: handle creation, captures
-            res, moves, _ = drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))
-            for det in cfg.model._dets.values():
-                det.close()
-            cfg.model = None
-            res["moves"] = len(moves)
-            if ref_moves is None:
-                ref_moves = moves
-            res["moves_equal_first_mode"] = moves == ref_moves
-            out[f"{dtype}_graph" if graph else f"{dtype}_eager"] = res
-        g, e = out[f"{dtype}_graph"], out[f"{dtype}_eager"]
-        out[f"{dtype}_graph_gain"] = {"frames_per_s": g["frames_per_s"] / e["frames_per_s"], "B1_call_ms_saved": e["ms_single_frame_call_B1"] - g["ms_single_frame_call_B1"],
-                                      "B15_call_ms_saved": e["ms_cycle_batch_call_B15"] - g["ms_cycle_batch_call_B15"]}
-    if prev_graph is None:
-        os.environ.pop("WTK_GRAPH_VIEWS", None)
-    else:
-        os.environ["WTK_GRAPH_VIEWS"] = prev_graph
-    out["graph_path"] = ("*_graph = WTK_GRAPH_VIEWS=1: wtk_yolo_predict_views replays a captured hipGraph for a call that returns with the same device addresses "
-                         "(HipYoloController keeps its view table and output rows per batch size); *_eager = the library's default.  The calls are bound by the ~60 "
-                         "dependent kernels' own latencies on grids of a few blocks, not by the host's launch rate, so the replay buys nothing (see *_graph_gain)")
+    for dtype, plan in (("f16x3", "latency"), ("fp32", "latency"), ("f16x3", "throughput")):
+        cfg = YoloConfig(model_path=tmp.name, device=f"cuda:{device}", pred_kwargs={"imgsz": 384, "conf": conf}, dtype=dtype, scale=scale, max_batch=16, plan=plan)
+        drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))  # warm-up pass: handle creation, captures
+        res, moves, _ = drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))
+        for det in cfg.model._dets.values():
+            det.close()
+        cfg.model = None
+        res["moves"] = len(moves)
+        if ref_moves is None:
+            ref_moves = moves
+        res["moves_equal_first_mode"] = moves == ref_moves
+        out[f"{dtype}_{plan}"] = res
+    out["plans"] = ("*_latency = the plan HipYoloController's handles get for calls of <= 16 frames (YoloConfig.plan = 'auto'): split-K convs (conv_sk.hip) and a replayed "
+                    "hipGraph per (batch size, buffers); f16x3_throughput = the same calls on the large-batch kernels (what every call ran on before round 5)")
     # the CPU restatement's controller on the host cores, same frames and driver
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
@@ -285,7 +274,7 @@ def compact_line(detail: dict) -> dict:
     if hc:
         line["headline_check"] = {k: _r(hc[k]) for k in ("frames", "index_mismatches", "box_abs_diff_max_px", "verified")}
     for k, v in detail.items():
-        if k.startswith("value_") or k.startswith("latency_"):
+        if k.startswith("value_") or k.startswith("latency_") or k == "closed_loop_f16x3_frames_per_s":
             line[k] = _r(v)
     if "dist" in detail:
         d = detail["dist"]
@@ -314,6 +303,60 @@ def emit(detail: dict) -> str:
         s = json.dumps(line, allow_nan=False)
     assert len(s) < LINE_LIMIT, len(s)
     return s
+
+
+def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
+    """The reference's two detector calls per cycle — one batch of cycle_frame_num = 15 frames and ONE frame (yolo_controller.py:96-98,108-109), imgsz 384
+    (initialize_experiment.ipynb cell 9) — and BASELINE config 2 (640 x 640, B = 1), on a latency-plan handle (wtk_yolo_create_planned: split-K convs +
+    replayed hipGraph) and, beside it, on a throughput-plan handle of the same model.  Per shape:
+      device_ms  HIP events on the call's stream around 40 back-to-back calls / 40 (frames resident in HBM: what the device needs per call)
+      host_ms    median wall time of one call + stream synchronisation seen from the host (launch / replay cost included, no PCIe traffic)
+      pcie_ms    median of wtk_yolo_predict_host: upload of the frames, the call, download of the rows (what a host-frame controller call costs)."""
+    from wtracker_amd import frames as fr
+    from wtracker_amd import hip
+    from wtracker_amd import yolo_spec as ys
+
+    depth, width, maxch = ys.SCALES[scale]
+    dev = torch.device("cuda", device)
+    st = torch.cuda.Stream(device=dev)
+    rows = []
+    for dtype in ("f16x3", "fp32"):
+        for plan in ("latency", "throughput"):
+            for size, B in ((384, 1), (384, 15), (640, 1)):
+                det = hip.HipYolo(weights, (size, size), 16, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=device, plan=plan)
+                f_np = fr.diverse_frames(16, size, seed=4242)[:B]
+                f = torch.from_numpy(f_np).to(dev)
+                x = torch.empty((B, 4), dtype=torch.float32, device=dev)
+                c = torch.empty((B,), dtype=torch.float32, device=dev)
+                a = torch.empty((B,), dtype=torch.int32, device=dev)
+                call = lambda: det.predict(f, B, size, size, 1, x, c, a, conf=conf, stream=st.cuda_stream)
+                for _ in range(5):  # eager, capture, replays
+                    call()
+                st.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = 40
+                e0.record(st)
+                for _ in range(n):
+                    call()
+                e1.record(st)
+                st.synchronize()
+                device_ms = e0.elapsed_time(e1) / n
+                host = []
+                for _ in range(30):
+                    t0 = time.perf_counter()
+                    call()
+                    st.synchronize()
+                    host.append(time.perf_counter() - t0)
+                pcie = []
+                for _ in range(15):
+                    t0 = time.perf_counter()
+                    det.predict_host(f_np, conf=conf)
+                    pcie.append(time.perf_counter() - t0)
+                gflop = 2.0 * det.macs_per_frame * B / 1e9
+                rows.append({"dtype": dtype, "plan": det.plan, "size": size, "batch": B, "device_ms": device_ms, "host_ms": float(np.median(host)) * 1e3,
+                             "pcie_ms": float(np.median(pcie[3:])) * 1e3, "gflop": gflop, "achieved_tflops": gflop / device_ms, "frac_of_peak": gflop / device_ms / PEAK_TFLOPS[dtype]})
+                det.close()
+    return {"what": latency_leg.__doc__.split("Per shape:")[0].strip().replace("\n", " "), "rows": rows}
 
 
 class Workload:
@@ -364,6 +407,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="measure the headline mode only (no per-mode sub-objects)")
     ap.add_argument("--no-hybrid", action="store_true", help="skip the hybrid sub-object (and its calibration pass)")
     ap.add_argument("--no-check", action="store_true", help="skip headline_check (profiling passes: nothing but the timed workload's kernels in the trace)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the latency sub-object (B = 1 / 15 at 384^2, B = 1 at 640^2: the reference's calls and BASELINE config 2)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed_loop sub-object (the reference's real operating point: 360 -> 384 views, 15-frame cycles)")
     ap.add_argument("--conf", type=float, default=0.1)
     ap.add_argument("--defer", type=int, default=HYBRID_DEFER, help="hybrid: batches of a lane whose weak rows share one full-precision pass (1 = second look inside every step)")
@@ -706,6 +750,9 @@ def main():
     closed = None
     if world == 1 and not args.no_closed_loop and not args.no_fp32:
         closed = closed_loop(weights, scale, nc, local_rank, args.conf)
+    lat = None
+    if world == 1 and not args.no_latency and not args.no_fp32 and args.size == 640:
+        lat = latency_leg(weights, scale, nc, local_rank, args.conf)
 
     out = {
         "metric": f"frames/sec YOLOv8s+ResMLP sim loop @{args.size}x{args.size}",
@@ -738,6 +785,12 @@ def main():
     out["end_to_end"] = head["end_to_end"]
     if closed is not None:
         out["closed_loop"] = closed
+        out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_latency"]["frames_per_s"]
+    if lat is not None:
+        out["latency"] = lat
+        for r in lat["rows"]:  # two scalars per reference-precision mode in the main line: the reference's two calls
+            if r["plan"] == "latency" and r["size"] == 384:
+                out[f"latency_b{r['batch']}_384_{r['dtype']}_ms"] = r["device_ms"]
     # flat per-mode keys (a record that keeps only top-level scalars still carries every mode and its exactness)
     for dt, m in modes.items():
         out[f"value_{dt}"] = m["value"]

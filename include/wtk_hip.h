@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define WTK_ABI_VERSION 6 /* 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted; 5: + wtk_recheck_enqueue / _scatter; 6: + wtk_hybrid_* (additive: every earlier entry point is unchanged) */
+#define WTK_ABI_VERSION 7 /* 7: + wtk_yolo_create_planned / wtk_yolo_plan, wtk_yolo_status (additive); 2: + wtk_yolo_predict_views / _nms, wtk_track_*, wtk_comm_*; 3: + WTK_F16X3, wtk_recheck_*; 4: + wtk_recheck_select_counted; 5: + wtk_recheck_enqueue / _scatter; 6: + wtk_hybrid_* (additive: every earlier entry point is unchanged) */
 
 typedef enum wtk_dtype {
     WTK_F32 = 0, /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity mode   */
@@ -129,6 +129,21 @@ int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t max_channels,
 
 int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *desc);
 void wtk_yolo_destroy(wtk_yolo *h);
+/* The same with the launch plan named by the caller.  A handle is planned ONCE, for one of two regimes:
+ *   WTK_PLAN_THROUGHPUT  large batches (BASELINE configs 3-5): window / implicit-GEMM kernels with big tiles, fused Detect tails;
+ *   WTK_PLAN_LATENCY     the reference's own operating point — one call of cycle_frame_num (9 / 15) frames and one single-frame
+ *                        call per cycle at imgsz 384 (yolo_controller.py:96-98,108-109; initialize_experiment.ipynb: imgsz 384):
+ *                        every conv is cut along K as well (split-K implicit GEMM + a slab-combining pass), so that a layer of a
+ *                        few thousand pixels still runs on every CU, and calls with a repeating argument set replay a captured
+ *                        hipGraph.  WTK_F32 and WTK_F16X3 only (WTK_F16 handles stay on the throughput plan).
+ *   WTK_PLAN_AUTO        (= wtk_yolo_create) latency when max_batch <= 16 and the dtype allows it, else throughput; the environment
+ *                        variable WTK_LATENCY_PLAN=0 / 1 overrides AUTO only.
+ * The plan never changes per call: within a handle a frame's logits do not depend on the batch it arrives in.  Both plans meet the
+ * same tolerances against the fp32 restatement; they are not bit-identical to each other (K is summed in a different order). */
+typedef enum wtk_plan { WTK_PLAN_AUTO = 0, WTK_PLAN_THROUGHPUT = 1, WTK_PLAN_LATENCY = 2 } wtk_plan;
+int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *desc, int32_t plan);
+/* The plan a handle runs on: WTK_PLAN_THROUGHPUT or WTK_PLAN_LATENCY (-1 on a null handle). */
+int wtk_yolo_plan(wtk_yolo *h);
 
 /* frames: DEVICE pointer, uint8, [B][H][W][C] with C = 1 (gray; replicated to 3 channels as
  * yolo_controller.py:68-69 does) or C = 3 (BGR).  H x W is letterboxed to imgsz_h x imgsz_w
@@ -160,6 +175,18 @@ int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B, float *out
 int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host /*[B][A][64]*/,
                          const float *cls_host /*[B][A][nc]*/, int32_t B, int32_t H, int32_t W,
                          float conf, float *out_xywh, float *out_conf, int32_t *out_anchor);
+/* Range guard of the fp16-storage modes (WTK_F16, WTK_F16X3: activations and weights live as fp16 values / pairs, |x| < 65 504 in the library's
+ * log2(e)-scaled activation domain).  The reference runs a trained, BatchNorm-folded checkpoint in fp32 (yolo_controller.py:42-45,
+ * yolo/yolo_train_config.yaml:51) — weights this library has never seen — so both ends are checked:
+ *   at wtk_yolo_create   a packed weight beyond the fp16 range is REFUSED (the message names the conv).  Small weights need no guard: below the fp16
+ *                        normal range the hi half is a subnormal (spacing 2^-24) and the lo half carries the rest times 2^11, so the pair still
+ *                        holds the weight to an ABSOLUTE error of ~2^-36 — far below the rounding of the products it takes part in;
+ *   at run time          every max_det = 1 / NMS call reads every class logit: an activation that overflowed anywhere in the network reaches the
+ *                        head as inf / NaN in its receptive field, and the head kernels then raise WTK_STATUS_NONFINITE (sticky).
+ * wtk_yolo_status: the flags as of the work the caller has synchronised with (no device call: the word lives in pinned host memory);
+ * clear != 0 resets the sticky bits.  A WTK_F32 handle reports NONFINITE only for inf / NaN that fp32 itself produces. */
+#define WTK_STATUS_NONFINITE 1
+int wtk_yolo_status(wtk_yolo *h, int32_t *flags, int32_t clear);
 /* Algorithmic work of one forward pass: conv MACs per frame and the number of anchors. */
 int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors);
 /* Average device time (ms) per launch of each kernel class over the frames processed since

@@ -25,7 +25,7 @@ def test_header_and_binding_list_agree():
 def test_library_exports_every_declared_symbol(hip_lib):
     for name in header_symbols():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.wtk_abi_version() == 6
+    assert hip_lib.wtk_abi_version() == 7
     assert hip_lib.wtk_last_error() is not None
     assert hip_lib.wtk_device_count() >= 0
 

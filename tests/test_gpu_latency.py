@@ -1,0 +1,275 @@
+"""GPU parity of the LATENCY plan (conv_sk.hip: split-K implicit GEMM + slab-combining pass; wtk_yolo_create_planned) — the plan a handle of
+max_batch <= 16 gets, i.e. the reference's own operating point: one call of cycle_frame_num frames and one single-frame call per cycle at
+imgsz 384 (yolo_controller.py:96-98,108-109).  Checker: the fp32 CPU restatement (oracle/yolo_oracle.py; parity unpinned: no ultralytics here).
+
+Bars (written here): head logits within 2e-3, boxes within 2e-2 px, survivor index equal — on 256 frames, at B = 1 and B = 15;
+and a frame's logits must not depend on the batch it arrives in (bit for bit, within the plan)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo_oracle as yo
+from wtracker_amd import frames as fr
+from wtracker_amd import hip
+from wtracker_amd import yolo_spec as ys
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_ATOL = 2e-3
+BOX_ATOL = 2e-2
+
+
+def _handle(size, dtype, max_batch=16, plan="latency", nc=1, seed=0, scale="s"):
+    w = ys.synthetic_weights(scale, nc, seed=seed)
+    depth, width, maxch = ys.SCALES[scale]
+    det = hip.HipYolo(w, (size, size), max_batch, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, plan=plan)
+    return w, det, yo.YoloOracle(w, ys.model_dims(width, depth, maxch, nc))
+
+
+def _oracle(oracle, frames, size, conf=0.1):
+    with torch.no_grad():
+        x, hw = yo.preprocess(list(frames), size)
+        box, cls = oracle.forward(x)
+    return box.numpy(), cls.numpy(), yo.postprocess(box, cls, (size, size), hw, conf=conf)
+
+
+def test_auto_rule_and_explicit_plans(hip_lib, monkeypatch):
+    w = ys.synthetic_weights("s", 1, seed=0)
+    mk = lambda **kw: hip.HipYolo(w, (128, 128), **kw)
+    monkeypatch.delenv("WTK_LATENCY_PLAN", raising=False)
+    for dtype, mb, want in (("fp32", 16, "latency"), ("f16x3", 1, "latency"), ("f16x3", 17, "throughput"), ("fp16", 8, "throughput")):
+        d = mk(max_batch=mb, dtype=dtype)
+        assert d.plan == want, (dtype, mb, d.plan)
+        d.close()
+    monkeypatch.setenv("WTK_LATENCY_PLAN", "0")  # the variable overrides AUTO ...
+    d = mk(max_batch=8, dtype="fp32")
+    assert d.plan == "throughput"
+    d.close()
+    d = mk(max_batch=8, dtype="fp32", plan="latency")  # ... and an explicit plan beats the variable
+    assert d.plan == "latency"
+    d.close()
+    d = mk(max_batch=64, dtype="f16x3", plan="latency")
+    assert d.plan == "latency"
+    d.close()
+    with pytest.raises(hip.WtkError, match="latency plan"):
+        mk(max_batch=8, dtype="fp16", plan="latency")
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+@pytest.mark.parametrize("size,B", [(384, 1), (384, 5), (640, 1), (128, 3)])
+def test_latency_plan_logits_boxes_and_survivors_match_the_restatement(hip_lib, dtype, size, B):
+    _, det, oracle = _handle(size, dtype)
+    assert det.plan == "latency"
+    frames = fr.diverse_frames(max(B, 4), size, seed=500 + size)[:B]
+    box_o, cls_o, (xywh_o, conf_o, anchor_o) = _oracle(oracle, frames, size)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+    box_g, cls_g = det.debug_head(B)
+    np.testing.assert_allclose(cls_g, cls_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(box_g, box_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=BOX_ATOL)
+    np.testing.assert_allclose(conf, conf_o, rtol=0, atol=1e-4)
+    det.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_a_frames_logits_do_not_depend_on_its_batch(hip_lib, dtype):
+    """The K slicing is a function of the layer alone and the tile shape never enters the arithmetic: the same frame alone, in a batch of 4 and
+    in a batch of 15 gives the same head logits bit for bit (what lets provide_movement_vector's single-frame call and _cycle_predict_all's
+    cycle batch agree on a frame they both see, yolo_controller.py:96-109)."""
+    size = 384
+    _, det, _ = _handle(size, dtype)
+    frames = fr.diverse_frames(16, size, seed=77)[:15]
+    x15, c15, a15 = det.predict_host(frames, conf=0.1)
+    b15, k15 = det.debug_head(15)
+    for i0, n in ((0, 1), (7, 1), (14, 1), (4, 4), (11, 4)):
+        x, c, a = det.predict_host(frames[i0 : i0 + n], conf=0.1)
+        b, k = det.debug_head(n)
+        np.testing.assert_array_equal(k, k15[i0 : i0 + n])
+        np.testing.assert_array_equal(b, b15[i0 : i0 + n])
+        np.testing.assert_array_equal(a, a15[i0 : i0 + n])
+        np.testing.assert_array_equal(x, x15[i0 : i0 + n])
+    det.close()
+
+
+def test_survivor_index_on_256_frames_at_b15_and_b1(hip_lib):
+    """256 frames of 64 seeded tracks at 384^2 through the f16x3 latency handle in calls of 15 (the cycle batch; the last call has one frame) and the
+    first 32 again one at a time: every survivor index equals the fp32 restatement's, boxes within 2e-2 px."""
+    size, n = 384, 256
+    _, det, oracle = _handle(size, "f16x3")
+    frames = fr.diverse_frames(n, size, seed=9000)
+    res = [det.predict_host(frames[i : i + 15], conf=0.1) for i in range(0, n, 15)]
+    xywh, conf, anchor = (np.concatenate([r[k] for r in res]) for k in range(3))
+    xo, ao = [], []
+    for i in range(0, n, 32):
+        _, _, (x, _, a) = _oracle(oracle, frames[i : i + 32], size)
+        xo.append(x), ao.append(a)
+    xywh_o, anchor_o = np.concatenate(xo), np.concatenate(ao)
+    assert (anchor_o >= 0).sum() >= n // 2  # the threshold is exercised on both sides
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=BOX_ATOL)
+    for i in range(32):
+        x1, _, a1 = det.predict_host(frames[i : i + 1], conf=0.1)
+        assert a1[0] == anchor[i]
+        np.testing.assert_array_equal(x1[0], xywh[i])
+    det.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_latency_and_throughput_plans_agree_within_the_stated_tolerance(hip_lib, dtype):
+    """Two plans of the same model: K is summed in a different order, so not bit-identical — logits within the restatement tolerance of each
+    other, survivors equal on 30 frames."""
+    size, n = 384, 30
+    w, lat, _ = _handle(size, dtype)
+    depth, width, maxch = ys.SCALES["s"]
+    thr = hip.HipYolo(w, (size, size), 16, dtype=dtype, width=width, depth=depth, max_channels=maxch, plan="throughput")
+    assert thr.plan == "throughput"
+    frames = fr.diverse_frames(32, size, seed=31)[:n]
+    for i in range(0, n, 15):
+        xl, cl, al = lat.predict_host(frames[i : i + 15], conf=0.1)
+        bl, kl = lat.debug_head(15)
+        xt, ct, at = thr.predict_host(frames[i : i + 15], conf=0.1)
+        bt, kt = thr.debug_head(15)
+        np.testing.assert_allclose(kl, kt, rtol=1e-3, atol=LOGIT_ATOL)
+        np.testing.assert_allclose(bl, bt, rtol=1e-3, atol=LOGIT_ATOL)
+        np.testing.assert_array_equal(al, at)
+        np.testing.assert_allclose(xl, xt, rtol=0, atol=BOX_ATOL)
+    lat.close(), thr.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_in_kernel_slab_combination_equals_the_two_launch_form(hip_lib, dtype, monkeypatch):
+    """The slabs of a split layer are combined by the block of the tile that arrives last (write-through stores, ticket, sc1 loads: conv_sk.hip) — a
+    cross-CU hand-off inside one launch.  WTK_SK_FINISH=1 builds the same handle with the combination as a second launch (ordinary kernel-boundary
+    visibility).  Both add the slabs in slice order, so every logit must be equal bit for bit; a stale or torn slab read would show here.  Repeated
+    with changing frames and batch sizes so that slab addresses are re-used while other work is in flight."""
+    size = 384
+    w, a, _ = _handle(size, dtype)
+    monkeypatch.setenv("WTK_SK_FINISH", "1")
+    depth, width, maxch = ys.SCALES["s"]
+    b = hip.HipYolo(w, (size, size), 16, dtype=dtype, width=width, depth=depth, max_channels=maxch, plan="latency")
+    monkeypatch.delenv("WTK_SK_FINISH")
+    pool = fr.diverse_frames(64, size, seed=123)
+    rng = np.random.default_rng(0)
+    for it in range(24):
+        n = (15, 1, 4, 9)[it % 4]
+        sel = pool[rng.integers(0, 64, size=n)]
+        xa, ca, aa = a.predict_host(sel, conf=0.1)
+        ba, ka = a.debug_head(n)
+        xb, cb, ab = b.predict_host(sel, conf=0.1)
+        bb, kb = b.debug_head(n)
+        np.testing.assert_array_equal(ka, kb, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(ba, bb, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(aa, ab)
+        np.testing.assert_array_equal(xa, xb)
+    a.close(), b.close()
+
+
+def test_replayed_capture_for_caller_buffers_equals_eager(hip_lib):
+    """A latency handle replays a captured hipGraph for caller buffers from the third call with the same argument set on (seen once -> captured ->
+    replayed); the rows must be the eager rows, and new frame CONTENT in the same buffer must be honoured by the replay."""
+    size, B = 384, 15
+    _, det, _ = _handle(size, "f16x3")
+    dev = torch.device("cuda", 0)
+    fa = torch.from_numpy(fr.diverse_frames(16, size, seed=1)[:B]).to(dev)
+    fb = torch.from_numpy(fr.diverse_frames(16, size, seed=2)[:B]).to(dev)
+    buf = torch.empty_like(fa)
+    out = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    an = torch.empty((B,), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    rows = []
+    with torch.cuda.stream(st):
+        for src in (fa, fa, fa, fb, fa):
+            buf.copy_(src)
+            det.predict(buf, B, size, size, 1, out, None, an, conf=0.1, stream=st.cuda_stream)
+            st.synchronize()
+            rows.append((out.cpu().numpy().copy(), an.cpu().numpy().copy()))
+    for k in (1, 2, 4):
+        np.testing.assert_array_equal(rows[k][0], rows[0][0])
+        np.testing.assert_array_equal(rows[k][1], rows[0][1])
+    xb, _, ab = det.predict_host(fb.cpu().numpy(), conf=0.1)
+    np.testing.assert_array_equal(rows[3][1], ab)
+    np.testing.assert_array_equal(rows[3][0], xb)
+    assert not np.array_equal(rows[3][1], rows[0][1])
+    det.close()
+
+
+def test_dynamic_batch_on_a_latency_handle(hip_lib):
+    size, B = 128, 8
+    _, det, _ = _handle(size, "f16x3")
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(fr.diverse_frames(8, size, seed=5)).to(dev)
+    out = torch.full((B, 4), -1.0, dtype=torch.float32, device=dev)
+    an = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    det.predict(frames, B, size, size, 1, out, None, an, conf=0.1)
+    torch.cuda.synchronize()
+    full = an.cpu().numpy().copy()
+    n_dev = torch.tensor([3], dtype=torch.int32, device=dev)
+    det.set_dynamic_batch(n_dev)
+    det.predict(frames, B, size, size, 1, out, None, an, conf=0.1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(an.cpu().numpy()[:3], full[:3])
+    det.set_dynamic_batch(None)
+    det.close()
+
+
+# ---- range guard of the fp16-storage modes (include/wtk_hip.h: wtk_yolo_status)
+def _scaled_weights(name, factor, seed=0):
+    w = {k: (a.copy(), b.copy()) for k, (a, b) in ys.synthetic_weights("s", 1, seed=seed).items()}
+    w[name] = (w[name][0] * np.float32(factor), w[name][1])
+    return w
+
+
+@pytest.mark.parametrize("plan", ["latency", "throughput"])
+def test_activation_overflow_raises_the_sticky_flag_in_fp16_modes_and_not_in_fp32(hip_lib, plan):
+    """One conv's weights x 3e4: its outputs (O(1 .. 10) before) leave the fp16 range.  fp16 / f16x3 handles must raise WTK_STATUS_NONFINITE on the first
+    call and keep it until cleared; the fp32 handle computes the (large but finite) values and stays clean."""
+    size, B = 128, 2
+    w = _scaled_weights("model.6.cv2", 3e4)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = fr.diverse_frames(4, size, seed=3)[:B]
+    for dtype in ("f16x3", "fp16", "fp32"):
+        if dtype == "fp16" and plan == "latency":
+            continue
+        det = hip.HipYolo(w, (size, size), 4, dtype=dtype, width=width, depth=depth, max_channels=maxch, plan=plan)
+        assert det.status() == 0
+        det.predict_host(frames, conf=0.1)
+        if dtype == "fp32":
+            assert det.status() == 0, dtype
+        else:
+            assert det.status() & hip.STATUS_NONFINITE, dtype
+            assert det.status(clear=True) & hip.STATUS_NONFINITE  # sticky until cleared
+            assert det.status() == 0
+        det.close()
+    clean = hip.HipYolo(ys.synthetic_weights("s", 1, seed=0), (size, size), 4, dtype="f16x3", width=width, depth=depth, max_channels=maxch, plan=plan)
+    clean.predict_host(frames, conf=0.1)
+    assert clean.status() == 0
+    clean.close()
+
+
+def test_weights_outside_the_fp16_range_are_refused_at_create(hip_lib):
+    depth, width, maxch = ys.SCALES["s"]
+    w = _scaled_weights("model.22.cv2.0.2", 1e6)  # a linear Detect output conv: |w| ~ 1e5 after the fold
+    for dtype in ("f16x3", "fp16"):
+        with pytest.raises(hip.WtkError, match="outside the fp16 range"):
+            hip.HipYolo(w, (128, 128), 2, dtype=dtype, width=width, depth=depth, max_channels=maxch)
+    det = hip.HipYolo(w, (128, 128), 2, dtype="fp32", width=width, depth=depth, max_channels=maxch)  # the reference's precision takes them
+    det.close()
+
+
+def test_controller_raises_on_overflow(hip_lib, tmp_path):
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig
+
+    path = str(tmp_path / "big.wtk")
+    ys.save_weights(path, _scaled_weights("model.6.cv2", 3e4), "s", 1)
+    ec = ExperimentConfig("x", 20, 60, (256, 256), 90, (128, 128))
+    tc = TimingConfig(ec, 100, 40, 50, (1.4, 1.4), (0.32, 0.32))
+    frames = list(fr.diverse_frames(4, 128, seed=3)[:2])
+    ctrl = HipYoloController(tc, YoloConfig(model_path=path, pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="f16x3", max_batch=4))
+    with pytest.raises(hip.WtkError, match="fp16 range"):
+        ctrl.predict(frames)
+    ok = HipYoloController(tc, YoloConfig(model_path=path, pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="fp32", max_batch=4))
+    assert ok.predict(frames).shape == (2, 4)

@@ -25,12 +25,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--lanes", type=int, default=1)
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel-class profile of one forward")
+    ap.add_argument("--plan", default="auto", choices=["auto", "throughput", "latency"])
     ap.add_argument("--dyn", type=int, default=-1, help="device-side dynamic batch count (wtk_yolo_set_dynamic_batch); -1: static")
     args = ap.parse_args()
     B, S = args.batch, args.size
     w = ys.synthetic_weights("s", 1, seed=0)
     depth, width, maxch = ys.SCALES["s"]
-    dets = [hip.HipYolo(w, (S, S), B, dtype=args.dtype, nc=1, width=width, depth=depth, max_channels=maxch) for _ in range(args.lanes)]
+    dets = [hip.HipYolo(w, (S, S), B, dtype=args.dtype, nc=1, width=width, depth=depth, max_channels=maxch, plan=args.plan) for _ in range(args.lanes)]
     frames, _ = fr.synthetic_frames(B, S, seed=0)
     dev = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
     outs = [torch.empty((B, 4), dtype=torch.float32, device="cuda") for _ in dets]
@@ -52,7 +53,7 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f"{args.dtype} B={B} dyn={args.dyn} {S}x{S} lanes={args.lanes}: {dt * 1e3:.3f} ms per step, {B * args.lanes / dt:,.0f} frames/s", flush=True)
+    print(f"{args.dtype} plan={dets[0].plan} B={B} dyn={args.dyn} {S}x{S} lanes={args.lanes}: {dt * 1e3:.3f} ms per step, {B * args.lanes / dt:,.0f} frames/s", flush=True)
     if args.kernels:
         dets[0].set_profiling(True)
         dets[0].predict(dev.data_ptr(), B, S, S, 1, outs[0].data_ptr(), conf=0.1, stream=0)

@@ -8,7 +8,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwtk_hip.so")
-SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "front_fused_split.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
+SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv_sk.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "front_fused_split.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
 HEADERS = ["wtk_kernels.h", os.path.join("..", "..", "include", "wtk_hip.h")]
 
 
@@ -19,8 +19,23 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+STAMP = os.path.join(CSRC, ".flags")
+
+
+def _flags() -> list:
+    """The compile flags of this process: BASE_FLAGS + WTK_EXTRA_HIPCC_FLAGS (diagnostic builds: -DWTK_*_STAMPS interval stamps, results unchanged)."""
+    return BASE_FLAGS + os.environ.get("WTK_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def _stamp_matches() -> bool:
+    return os.path.exists(STAMP) and open(STAMP).read() == " ".join(_flags())
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """Stale when the library is missing, older than a source / header, or was built with OTHER flags than this process asks for (the stamp is
+    written after a successful link only: a diagnostic library, or objects left behind by a build that failed half way, never pass for current)."""
+    if not os.path.exists(LIB_PATH) or not _stamp_matches():
         return True
     t = os.path.getmtime(LIB_PATH)
     for f in SOURCES + HEADERS:
@@ -47,16 +62,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
     objs = []
-    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
-    extra = os.environ.get("WTK_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds (-DWTK_*_STAMPS): interval stamps, results unchanged
-    if any(f.startswith("-DWTK_TIMING") for f in extra) and os.environ.get("WTK_DIAGNOSTIC_BUILD") != "1":
-        # timing-ablation macros make kernels skip work: such a library returns wrong boxes and must never be built by accident
+    flags = _flags()
+    if any(f.startswith("-DWTK_TIMING") for f in flags) and os.environ.get("WTK_DIAGNOSTIC_BUILD") != "1":
+        # timing-ablation macros (tools/patches) make kernels skip work: such a library returns wrong boxes and must never be built by accident
         raise RuntimeError("WTK_EXTRA_HIPCC_FLAGS contains a -DWTK_TIMING* macro (results would be garbage); set WTK_DIAGNOSTIC_BUILD=1 to build it anyway")
-    flags += extra
-    # one object per translation unit, recompiled only when its source, a shared header or the flag set changed
-    stamp = os.path.join(CSRC, ".flags")
+    # one object per translation unit, recompiled only when its source, a shared header or the flag set changed.  The stamp is REMOVED before the
+    # first object is overwritten and written again only after the link: objects of a build that failed half way (some with the new flags — a
+    # -DWTK_*_STAMPS macro changes struct layouts — some with the old) can never be linked together under a stamp that says they match.
+    stamp = STAMP
     flag_key = " ".join(flags)
-    same_flags = os.path.exists(stamp) and open(stamp).read() == flag_key
+    same_flags = _stamp_matches()
+    if os.path.exists(stamp):
+        os.remove(stamp)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS)
     procs = []
     for src in SOURCES:

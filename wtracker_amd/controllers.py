@@ -12,6 +12,7 @@ Mirrors (same constructor arguments, method names, return conventions, error beh
 """
 from __future__ import annotations
 
+import os
 from collections import deque
 from dataclasses import dataclass, field
 from typing import Any, Collection, Optional
@@ -315,6 +316,11 @@ class YoloConfig:
     recheck_dtype: str = "auto"
     scale: str = "s"
     max_batch: int = 64
+    # launch plan of the detector handles (include/wtk_hip.h: wtk_yolo_create_planned).  "auto": calls of up to LATENCY_MAX_BATCH frames — the reference's
+    # own calls: one cycle batch (9 / 15 frames) and one single frame per cycle, yolo_controller.py:96-98,108-109 — go to ONE handle on the latency plan
+    # (split-K convs, replayed captures; a frame's result does not depend on which of the two calls sees it), larger batches to a throughput-plan handle;
+    # "throughput" / "latency": every call on that plan.  fp16 handles always run the throughput plan.
+    plan: str = "auto"
     model: Any = field(default=None, init=False, repr=False)
 
     def __getstate__(self) -> dict:
@@ -338,6 +344,15 @@ class YoloConfig:
         return self.model
 
 
+def _raise_on_overflow(det: hip.HipYolo) -> None:
+    """The fp16-storage modes need |activation| < 65 504 (include/wtk_hip.h: wtk_yolo_status).  A trained, BatchNorm-folded checkpoint
+    (yolo_controller.py:42-45 loads one) whose activations leave that range would otherwise give NaN rows or wrong survivors silently: the head
+    kernels raise a sticky flag when a head logit is inf / NaN, and the controller turns it into an error that names the way out."""
+    if det.status(clear=True) & hip.STATUS_NONFINITE:
+        raise hip.WtkError(f"non-finite head logits in dtype '{det.dtype}': an activation of this model left the fp16 range (65 504); "
+                           "use YoloConfig(dtype='fp32')" if det.dtype != "fp32" else "non-finite head logits: the model's weights or the input produce inf / NaN")
+
+
 class _YoloModel:
     """Weights + one device detector per network input shape (created on first use)."""
 
@@ -346,18 +361,24 @@ class _YoloModel:
         self.weights, self.nc = yolo_spec.load_weights(cfg.model_path)
         self._dets: dict = {}
 
+    LATENCY_MAX_BATCH = 16
+
     def detector(self, net_hw: tuple, batch: int, dtype: Optional[str] = None) -> hip.HipYolo:
         dtype = dtype or self.cfg.dtype
         if dtype == "auto":  # the reference's precision at the best rate this scale has
             dtype = "f16x3" if yolo_spec.split_capable(self.cfg.scale, self.nc) else "fp32"
-        key = (net_hw, dtype)
+        plan = self.cfg.plan
+        if plan == "auto" or dtype in ("fp16", "f16", "float16"):
+            plan = "latency" if batch <= self.LATENCY_MAX_BATCH and dtype not in ("fp16", "f16", "float16") and os.environ.get("WTK_LATENCY_PLAN") != "0" else "throughput"
+        key = (net_hw, dtype, plan)
         det = self._dets.get(key)
         if det is None or det.max_batch < batch:
             if det is not None:
                 det.close()
             width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
-            det = hip.HipYolo(self.weights, net_hw, max(batch, self.cfg.max_batch), dtype=dtype, nc=self.nc,
-                              width=width, depth=depth, max_channels=maxch, device=self.cfg.device_index())
+            cap = max(batch, self.LATENCY_MAX_BATCH if plan == "latency" else self.cfg.max_batch)
+            det = hip.HipYolo(self.weights, net_hw, cap, dtype=dtype, nc=self.nc, width=width, depth=depth, max_channels=maxch,
+                              device=self.cfg.device_index(), plan=plan)
             self._dets[key] = det
         return det
 
@@ -416,6 +437,7 @@ class HipYoloController(SimController):
         net_hw = yolo_spec.letterbox_shape(H, W, imgsz)
         det = self._model.detector(net_hw, batch.shape[0])
         xywh, _, anchor = det.predict_host(batch, conf=conf, iou=iou, max_det=1)
+        _raise_on_overflow(det)
         self.last_rechecked = 0
         if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
             weak = np.nonzero(det.last_margins(batch.shape[0]) < self.yolo_config.recheck_margin)[0]
@@ -451,7 +473,9 @@ class HipYoloController(SimController):
         # launch bound), which needs a stream of the controller's own: the legacy default stream cannot be captured.
         if self._view_stream is None:
             self._view_stream = torch.cuda.Stream(device=dev)
-            self._view_stream.wait_stream(torch.cuda.current_stream(dev))  # whatever produced `device_frames`
+        # EVERY call is ordered behind the caller's current stream (an event wait, microseconds): a caller that refills or extends `device_frames` in
+        # place between cycles has its writes on that stream, and the crop / letterbox kernel must not read frames that are still being written
+        self._view_stream.wait_stream(torch.cuda.current_stream(dev))
         bufs = self._view_bufs.get(n)
         if bufs is None:
             bufs = self._view_bufs[n] = dict(meta=torch.empty((3 * n,), dtype=torch.int32, device=dev), host=torch.empty((3 * n,), dtype=torch.int32).pin_memory(),
@@ -470,6 +494,7 @@ class HipYoloController(SimController):
                               stream=self._view_stream.cuda_stream)
             self._view_stream.synchronize()
         xywh, anchor = out.cpu().numpy(), an.cpu().numpy()
+        _raise_on_overflow(det)
         self.last_rechecked = 0
         if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
             weak = np.nonzero(det.last_margins(n) < self.yolo_config.recheck_margin)[0]

@@ -1,0 +1,528 @@
+// Split-K implicit-GEMM convolution for the SMALL-BATCH (latency) plan of a detector handle (gfx950).
+//
+// Why it exists.  The reference calls the detector twice per cycle: one batch of cycle_frame_num frames (9 / 15) and ONE frame
+// (yolo_controller.py:96-98, 108-109), at imgsz 384.  At that size the throughput kernels (conv_igemm / conv3x3_halo / conv3x3_s2)
+// run every layer on a handful of blocks, each of which walks the whole K of its tile one staged step at a time: a step costs a full
+// memory latency when nothing else is resident on the CU, so a layer takes 10-45 us whatever its arithmetic (profiles/r05_notes.md:
+// B = 1 at 384^2, B = 15 at 384^2 and B = 1 at 640^2 take the same time per layer).  Here a layer is cut along K as well:
+//   block = (pixel tile, cout tile, K slice of <= 8 steps);  a step = one 128-byte operand row = 32 channels of one tap
+// and a block requests its slice's operands through an NS-deep LDS ring with NS - 1 stages in flight from the first instruction
+// (for a slice of <= NS - 1 steps: everything at once, ONE latency), multiplies, and leaves either the finished tile (S = 1) or an
+// fp32 partial tile in its slice's slab.  The slabs of a tile are combined by the block of that tile that ARRIVES LAST (one ticket per tile: write-through
+// `sc1` slab stores, every wave's vmcnt(0), block barrier, one agent-scope atomic add by one lane; the block whose add returns S - 1 reads all S slabs
+// with `sc1` loads — MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads", first row — adds them in slice order and applies bias / SiLU / residual /
+// store; it also re-arms the ticket).  sk_finish_kernel is the same combination as a second launch (WTK_SK_FINISH=1): a dependent launch costs
+// ~4.7 us here, which is what a small layer's whole convolution costs.  Both forms add the slabs in the same order: bit-identical.
+//
+// Determinism and batch invariance.  The slicing of K is a function of the LAYER alone (conv_sk_slices), every output value is
+// the sum of its slices' MFMA chains in slice order, and the tile shape (chosen from the batch) does not enter the arithmetic:
+// a frame gets the same logits at B = 1 and at B = 15.  No atomics.
+//
+// Operand layout: the igemm kernel's (conv_igemm.hip): NHWC activations as channel-slice views, weights [CoutPad][K] with K = (tap, channel);
+// a step's two operand tiles are staged by LDS-DMA (buffer_load ... lds from inline asm, source-side XOR swizzle) and read back as
+// conflict-free ds_read_b128 MFMA fragments.  Two storage modes share all of it because both spend 4 bytes per value:
+//   SPLIT  split-fp16 pairs [hi32 | lo32] per 32 channels, three v_mfma_f32_16x16x32_f16 per product (wtk_kernels.h, kSplitScale)
+//   fp32   32 floats per row, exact v_mfma_f32_16x16x4_f32
+#include "wtk_kernels.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace wtk {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ rsrc_t sk_rsrc(const void *base) {
+    const unsigned long long b = (unsigned long long)base;
+    rsrc_t r;
+    r.x = (int)(unsigned)(b & 0xffffffffu);
+    r.y = (int)(unsigned)((b >> 32) & 0xffffu);
+    r.z = (int)0xffffff00u; // num_records: a lane offset of 0xffffffff is out of range and lands zeros
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void sk_dma(const rsrc_t &rs, unsigned voff, unsigned soff, char *lds_dst) {
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds_dst;
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff), "s"(lds) : "memory");
+}
+// wait until all but the youngest n * PER vector-memory operations of this wave are done (n stages of PER requests each still in flight)
+template <int PER> __device__ __forceinline__ void sk_wait_stages(int n) {
+    static_assert(PER * 6 <= 63, "vmcnt is a 6-bit counter");
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER) : "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PER) : "memory");
+}
+
+// 16-byte write-through store / L1-bypassing load (agent scope): the slab hand-off between the blocks of a tile
+__device__ __forceinline__ void sk_store_sc1(float *p, const floatx4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void sk_load_sc1(floatx4 &v, const float *p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+// the loads above are invisible to hipcc's waitcnt pass: the wait names the registers so that no use can be scheduled in front of it
+__device__ __forceinline__ void sk_wait_loads(floatx4 (&x)[16]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]),
+                   "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])::"memory");
+}
+
+struct SkArgs {
+    const char *in;  // input tensor (slice view): byte pitch per pixel, byte offset of the first channel
+    unsigned in_ldb, in_offb;
+    const char *in2; // optional half-resolution source of the first in2_blocks 32-channel blocks (nn.Upsample(2x) + Concat, 1x1 only)
+    unsigned in2_ldb, in2_offb;
+    int in2_blocks;
+    int N, H, W, Ho, Wo;
+    int cpb;              // 32-channel blocks per tap
+    int KW, stride, pad;  // square taps: KH == KW
+    int nk, S;            // K steps in all (taps * cpb), K slices
+    const char *w;        // [CoutPad][nk * 128 bytes]
+    unsigned w_rowb;
+    const float *bias;
+    int Cout, CoutPad, act;
+    void *out;
+    int out_ld, out_coff, out_f32; // elements of the storage type (SPLIT: pseudo-channels unless out_f32), as ConvArgs
+    const void *res;
+    int res_ld, res_coff;
+    float *partial; // S > 1: [S][M][CoutPad] fp32
+    unsigned *tickets; // S > 1, nullable: one arrival counter per (pixel tile, cout tile), zero between launches — the block that arrives LAST combines the
+                       // slabs itself (no second launch); null: sk_finish_kernel does it
+    long long M;
+    int ptiles, nct;
+    FastDiv d_ptiles, d_nct, d_howo, d_wo, d_cpb, d_cg;
+    const int *n_dyn;
+};
+
+// what becomes of a finished run of NV consecutive couts (cb ..) of output pixel `pix`; v = the K sum WITHOUT the bias
+template <int NV> __device__ __forceinline__ void sk_load_bias(const SkArgs &a, int cb, float (&b)[NV]) { // rows exist up to CoutPad
+#pragma unroll
+    for (int e = 0; e < NV; e += 4) {
+        const float4 f = *reinterpret_cast<const float4 *>(a.bias + cb + e);
+        b[e] = f.x, b[e + 1] = f.y, b[e + 2] = f.z, b[e + 3] = f.w;
+    }
+}
+template <bool SPLIT, int NV> __device__ __forceinline__ void sk_store(const SkArgs &a, long long pix, int cb, float (&v)[NV], const float (&bias)[NV]) {
+    if (cb + NV > a.Cout) return; // padded output channels are never stored (Cout is a multiple of 8, NV of 8)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] += bias[e];
+    if (a.act) wtk_silu_scaled_run<NV>(v);
+    if (a.res) {
+        float rv[NV];
+        if constexpr (SPLIT) {
+            wtk_split_load<NV>(reinterpret_cast<const _Float16 *>(a.res) + pix * a.res_ld + a.res_coff, cb, rv);
+        } else {
+            const float *rp = reinterpret_cast<const float *>(a.res) + pix * a.res_ld + a.res_coff + cb;
+#pragma unroll
+            for (int e = 0; e < NV; e += 4) {
+                const float4 f = *reinterpret_cast<const float4 *>(rp + e);
+                rv[e] = f.x, rv[e + 1] = f.y, rv[e + 2] = f.z, rv[e + 3] = f.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] += rv[e];
+    }
+    if (!SPLIT || a.out_f32) {
+        float *op = reinterpret_cast<float *>(a.out) + pix * a.out_ld + a.out_coff + cb;
+#pragma unroll
+        for (int e = 0; e < NV; e += 4) *reinterpret_cast<float4 *>(op + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+    } else {
+        wtk_split_store<NV>(reinterpret_cast<_Float16 *>(a.out) + pix * a.out_ld + a.out_coff, cb, v);
+    }
+}
+
+template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS>
+__global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const SkArgs a) {
+    constexpr int NW = WAVES_P * WAVES_C;
+    constexpr int RPP = 8 * NW; // tile rows staged per pass of the whole block (one wave instruction = 8 rows x 128 B)
+    constexpr int PR = BM / RPP, WR = BN / RPP;
+    constexpr int WP = BM / WAVES_P, WC = BN / WAVES_C;
+    constexpr int TP = WP / 16, TC = WC / 16;
+    constexpr int NV = 4 * TC; // consecutive couts owned by a lane
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int PER = PR + WR; // LDS-DMA requests per thread and stage
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && TP >= 1 && TC >= 2 && NV % 8 == 0, "tile shape");
+    static_assert((NS & (NS - 1)) == 0 && NS >= 2 && NS <= 8 && NS * STAGE <= 160 * 1024, "ring");
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_p = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // block -> (pixel tile fastest, cout tile, K slice): the blocks that are neighbours in launch order share a weight slice
+    const unsigned bq = fdiv(blockIdx.x, a.d_ptiles);
+    const int ptile = (int)(blockIdx.x - bq * (unsigned)a.ptiles);
+    const int slice = (int)fdiv(bq, a.d_nct);
+    const int ctile = (int)(bq - (unsigned)slice * (unsigned)a.nct);
+    const int ks0 = (int)((long long)slice * a.nk / a.S), ks1 = (int)((long long)(slice + 1) * a.nk / a.S);
+    const int nkb = ks1 - ks0;
+    const int HoWo = a.Ho * a.Wo;
+    long long m_eff = a.M;
+    if (a.n_dyn) m_eff = (long long)min(max(*a.n_dyn, 0), a.N) * HoWo; // dynamic batch: tiles that start beyond its last image are not computed
+    const long long m0 = (long long)ptile * BM;
+    if (m0 >= m_eff) return;
+    const int n0 = ctile * BN;
+
+    // ---- staging assignment (as conv_igemm.hip): thread -> 16-byte physical chunk `ch` of rows r0 + RPP * i; the swizzle is applied to the SOURCE chunk
+    const int ch = tid & 7, r0 = tid >> 3;
+    const int lchunk = ch ^ (r0 & 7);
+    const int nb = (int)fdiv((unsigned)m0, a.d_howo); // image of the tile's first pixel: lane offsets are relative to it (32-bit)
+    const rsrc_t in_rs = sk_rsrc(a.in + (long long)nb * a.H * a.W * a.in_ldb + a.in_offb);
+    const rsrc_t in2_rs = sk_rsrc(a.in2 ? a.in2 + (long long)nb * (a.H >> 1) * (a.W >> 1) * a.in2_ldb + a.in2_offb : a.in);
+    const rsrc_t w_rs = sk_rsrc(a.w + (long long)n0 * a.w_rowb);
+    unsigned poff[PR], poff2[PR];
+    int hi0[PR], wi0[PR];
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+        const long long m = m0 + r0 + RPP * i;
+        if (m < a.M) {
+            const unsigned mu = (unsigned)m;
+            const int n = (int)fdiv(mu, a.d_howo);
+            const unsigned rem = mu - (unsigned)n * (unsigned)HoWo;
+            const int ho = (int)fdiv(rem, a.d_wo), wo = (int)(rem - (unsigned)ho * (unsigned)a.Wo);
+            hi0[i] = ho * a.stride - a.pad;
+            wi0[i] = wo * a.stride - a.pad;
+            poff[i] = (unsigned)((((n - nb) * a.H + hi0[i]) * a.W + wi0[i]) * (int)a.in_ldb + lchunk * 16); // may wrap below 0: only used with an in-range tap
+            poff2[i] = (unsigned)((((n - nb) * (a.H >> 1) + (ho >> 1)) * (a.W >> 1) + (wo >> 1)) * (int)a.in2_ldb + lchunk * 16);
+        } else {
+            hi0[i] = wi0[i] = -(1 << 28); // fails every bounds test
+            poff[i] = 0;
+            poff2[i] = 0xffffffffu;
+        }
+    }
+    unsigned wvoff[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int row = r0 + RPP * i;
+        const int key = ((row >> 1) & 1) | (((row / NV) & 3) << 1);
+        wvoff[i] = (unsigned)row * a.w_rowb + (unsigned)((ch ^ key) << 4);
+    }
+    auto issue = [&](int ks, char *buf) __attribute__((always_inline)) {
+        const int tap = (int)fdiv((unsigned)ks, a.d_cpb), cb = ks - tap * a.cpb; // wave-uniform
+        char *pt = buf + 8 * wave * 128, *wt = buf + (BM + 8 * wave) * 128;
+        if (cb < a.in2_blocks) { // 1x1 over [up2x(low) | high]: these channels live in the half-resolution tensor
+#pragma unroll
+            for (int i = 0; i < PR; ++i) sk_dma(in2_rs, poff2[i], (unsigned)cb * 128u, pt + RPP * i * 128);
+        } else {
+            const int kh = a.KW == 3 ? (tap * 11) >> 5 : 0, kw = tap - kh * a.KW; // tap / 3 for tap < 32; a 1x1 has the one tap
+            const unsigned delta = (unsigned)((kh * a.W + kw) * (int)a.in_ldb + cb * 128);
+#pragma unroll
+            for (int i = 0; i < PR; ++i) {
+                const bool ok = (unsigned)(hi0[i] + kh) < (unsigned)a.H && (unsigned)(wi0[i] + kw) < (unsigned)a.W;
+                sk_dma(in_rs, ok ? poff[i] + delta : 0xffffffffu, 0u, pt + RPP * i * 128);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) sk_dma(w_rs, wvoff[i], (unsigned)ks * 128u, wt + RPP * i * 128);
+    };
+
+    // the bias of this lane's couts: requested before the first operand so that its round trip is over long before the epilogue (a small layer is
+    // a chain of two or three memory latencies: every one that can run beside another counts)
+    float bias_r[NV];
+    sk_load_bias<NV>(a, n0 + wave_c * WC + lg * NV, bias_r);
+    floatx4 acc[TC][TP];
+    floatx4 acc1[SPLIT ? TC : 1][SPLIT ? TP : 1];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) acc1[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        }
+    // fragment addresses inside a stage: pixel tiles j at +j*2048 (same swizzle key), cout tiles i at +i*512 (key independent of i); second k-half = ^64
+    const int prow_l = wave_p * WP + lr;
+    const unsigned pfrag0 = prow_l * 128 + ((lg ^ (prow_l & 7)) << 4);
+    const int wrow_l = wave_c * WC + (lr >> 2) * NV + (lr & 3);
+    const int wkey_l = ((wrow_l >> 1) & 1) | (((wrow_l / NV) & 3) << 1);
+    const unsigned wfrag0 = BM * 128 + wrow_l * 128 + ((lg ^ wkey_l) << 4);
+    auto compute = [&](const char *pt) __attribute__((always_inline)) {
+        if constexpr (SPLIT) { // hi fragments = k-half 0, lo fragments = k-half 1 of the same 32 channels
+            uint4 ph[TP], wh[TC], wl[TC], pl[TP];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) ph[j] = *reinterpret_cast<const uint4 *>(pt + pfrag0 + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wh[i] = *reinterpret_cast<const uint4 *>(pt + wfrag0 + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wl[i] = *reinterpret_cast<const uint4 *>(pt + (wfrag0 ^ 64u) + i * 512);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pl[j] = *reinterpret_cast<const uint4 *>(pt + (pfrag0 ^ 64u) + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const half8 xh = __builtin_bit_cast(half8, ph[j]), xl = __builtin_bit_cast(half8, pl[j]);
+                    const half8 yh = __builtin_bit_cast(half8, wh[i]), yl = __builtin_bit_cast(half8, wl[i]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xh, acc[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, xh, acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xl, acc1[i][j], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int kh2 = 0; kh2 < 2; ++kh2) {
+                const unsigned pa = kh2 ? (pfrag0 ^ 64u) : pfrag0, wa = kh2 ? (wfrag0 ^ 64u) : wfrag0;
+                uint4 pf[TP], wf[TC];
+#pragma unroll
+                for (int j = 0; j < TP; ++j) pf[j] = *reinterpret_cast<const uint4 *>(pt + pa + j * 2048);
+#pragma unroll
+                for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const uint4 *>(pt + wa + i * 512);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) { // the same k on both operands: element e of every lane group's chunk
+                        floatx4 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf[i].x), __builtin_bit_cast(float, pf[j].x), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf[i].y), __builtin_bit_cast(float, pf[j].y), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf[i].z), __builtin_bit_cast(float, pf[j].z), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf[i].w), __builtin_bit_cast(float, pf[j].w), c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+        }
+    };
+
+    // ---- the ring: stages ks0 .. ks0 + NS - 2 are requested before anything else; step s waits for ITS stage only (counted vmcnt), meets
+    // the other waves (which also says that everybody is done reading the stage of step s - 1) and then re-fills that stage
+    const int pre = min(NS - 1, nkb);
+    for (int s = 0; s < pre; ++s) issue(ks0 + s, smem + s * STAGE);
+    for (int s = 0; s < nkb; ++s) {
+        sk_wait_stages<PER>(min(s + NS - 1, nkb) - s - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragment reads of step s - 1 are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nkb) issue(ks0 + s + NS - 1, smem + ((s + NS - 1) & (NS - 1)) * STAGE);
+        compute(smem + (s & (NS - 1)) * STAGE);
+    }
+
+    // ---- the tile: lane (pixel lr of tile j, group lg) owns couts cb .. cb + NV - 1
+    const int cb = n0 + wave_c * WC + lg * NV;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const long long pix = m0 + wave_p * WP + j * 16 + lr;
+        if (pix >= a.M) continue;
+        float v[NV];
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (SPLIT)
+                    v[t * 4 + r] = wtk_split_value(acc[t][j][r], acc1[t][j][r]);
+                else
+                    v[t * 4 + r] = acc[t][j][r];
+            }
+        if (a.S == 1) {
+            sk_store<SPLIT, NV>(a, pix, cb, v, bias_r);
+        } else {
+            float *pp = a.partial + ((long long)slice * a.M + pix) * a.CoutPad + cb;
+#pragma unroll
+            for (int e = 0; e < NV; e += 4) {
+                const floatx4 f = {v[e], v[e + 1], v[e + 2], v[e + 3]};
+                if (a.tickets)
+                    sk_store_sc1(pp + e, f);
+                else
+                    *reinterpret_cast<floatx4 *>(pp + e) = f;
+            }
+        }
+    }
+    if (a.S == 1 || !a.tickets) return;
+    // ---- the block of this tile that arrives last combines the slabs (see the header).  Every wave's slab stores are complete (vmcnt(0)) before the
+    // barrier; one lane then takes the ticket; its value reaches the other waves through LDS (the ring is free: every wave is past its last read).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *flag = reinterpret_cast<int *>(smem);
+    if (tid == 0) {
+        unsigned *tk = a.tickets + (ptile + a.ptiles * ctile);
+        const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(a.S - 1);
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // nobody else touches this ticket before the next launch
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*reinterpret_cast<volatile int *>(flag)) return;
+    const long long slab = a.M * a.CoutPad;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const long long pix = m0 + wave_p * WP + j * 16 + lr;
+        if (pix >= a.M) continue;
+        if (cb + NV > a.Cout) continue;
+        const float *pp = a.partial + pix * a.CoutPad + cb;
+        float v[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] = 0.f;
+        static_assert(NV == 8, "two float4 per slab and lane");
+        for (int s0 = 0; s0 < a.S; s0 += 8) { // eight slabs per round trip (conv_sk_slices never makes more): slabs beyond S - 1 re-read the last one and are not added
+            floatx4 x[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float *ps = pp + (long long)min(s0 + q, a.S - 1) * slab;
+                sk_load_sc1(x[2 * q], ps);
+                sk_load_sc1(x[2 * q + 1], ps + 4);
+            }
+            sk_wait_loads(x);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (s0 + q < a.S) { // slice order: v = ((p0 + p1) + p2) + ...
+                    if (s0 + q == 0) {
+                        v[0] = x[0].x, v[1] = x[0].y, v[2] = x[0].z, v[3] = x[0].w, v[4] = x[1].x, v[5] = x[1].y, v[6] = x[1].z, v[7] = x[1].w;
+                    } else {
+                        v[0] += x[2 * q].x, v[1] += x[2 * q].y, v[2] += x[2 * q].z, v[3] += x[2 * q].w;
+                        v[4] += x[2 * q + 1].x, v[5] += x[2 * q + 1].y, v[6] += x[2 * q + 1].z, v[7] += x[2 * q + 1].w;
+                    }
+                }
+        }
+        sk_store<SPLIT, NV>(a, pix, cb, v, bias_r);
+    }
+}
+
+// slabs of a split layer -> the layer's output: one thread per (pixel, run of 8 couts), slabs added in slice order
+template <bool SPLIT> __global__ __launch_bounds__(256) void sk_finish_kernel(const SkArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = a.Cout >> 3;
+    long long m_eff = a.M;
+    if (a.n_dyn) m_eff = (long long)min(max(*a.n_dyn, 0), a.N) * a.Ho * a.Wo;
+    if (t >= m_eff * cg) return;
+    const unsigned pix = fdiv((unsigned)t, a.d_cg);
+    const int cb = (int)((unsigned)t - pix * (unsigned)cg) * 8;
+    float v[8];
+    const float *pp = a.partial + (long long)pix * a.CoutPad + cb;
+    const long long slab = a.M * a.CoutPad;
+    {
+        const float4 x = *reinterpret_cast<const float4 *>(pp), y = *reinterpret_cast<const float4 *>(pp + 4);
+        v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w, v[4] = y.x, v[5] = y.y, v[6] = y.z, v[7] = y.w;
+    }
+    for (int s = 1; s < a.S; ++s) {
+        const float4 x = *reinterpret_cast<const float4 *>(pp + s * slab), y = *reinterpret_cast<const float4 *>(pp + s * slab + 4);
+        v[0] += x.x, v[1] += x.y, v[2] += x.z, v[3] += x.w, v[4] += y.x, v[5] += y.y, v[6] += y.z, v[7] += y.w;
+    }
+    float bias[8];
+    sk_load_bias<8>(a, cb, bias);
+    sk_store<SPLIT, 8>(a, (long long)pix, cb, v, bias);
+}
+
+template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS> hipError_t sk_launch_t(SkArgs a, hipStream_t st) {
+    a.ptiles = (int)((a.M + BM - 1) / BM);
+    a.nct = a.CoutPad / BN;
+    a.d_ptiles = make_fastdiv((unsigned)a.ptiles);
+    a.d_nct = make_fastdiv((unsigned)a.nct);
+    const long long grid = (long long)a.ptiles * a.nct * a.S;
+    if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_sk_kernel<SPLIT, BM, BN, WAVES_P, WAVES_C, NS>), dim3((unsigned)grid), dim3(64 * WAVES_P * WAVES_C), 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// K slices of a layer with nk steps of 32 channels: a function of the layer alone (see the header: batch invariance)
+// nk <= sk_single_max(): one block walks the whole K through the ring (no slabs, no hand-off); above it slices of ~sk_slice_steps() steps, at most 8
+// slices (the combining block reads all slabs in ONE round trip).  WTK_SK_SINGLE_MAX / WTK_SK_SLICE_STEPS: tuning switches, read once per process.
+static int sk_env(const char *name, int dflt) {
+    const char *e = std::getenv(name);
+    return e && e[0] ? std::atoi(e) : dflt;
+}
+static int sk_single_max() {
+    static const int v = sk_env("WTK_SK_SINGLE_MAX", 12);
+    return v;
+}
+static int sk_slice_steps() {
+    static const int v = sk_env("WTK_SK_SLICE_STEPS", 8);
+    return v > 0 ? v : 8;
+}
+int conv_sk_slices(int nk) {
+    if (nk <= sk_single_max()) return 1;
+    const int s = (nk + sk_slice_steps() - 1) / sk_slice_steps();
+    return s < 2 ? 2 : (s > 8 ? 8 : s);
+}
+
+bool conv_sk_eligible(const ConvArgs &a, int split) {
+    const int esz = split ? 2 : 4;
+    const int cin_real = split ? a.Cin / 2 : a.Cin;
+    if (a.KH != a.KW || (a.KH != 1 && a.KH != 3) || a.pad != a.KH / 2 || (a.stride != 1 && a.stride != 2)) return false;
+    if (cin_real % 32 || cin_real <= 0 || (long long)a.Kpad * esz != (long long)a.KH * a.KW * cin_real * 4) return false; // rows of 32 channels, no K padding
+    if (a.out2 || a.tail_w) return false; // (tile_w, the igemm kernel's 2-D pixel tiles, is ignored: pixels are walked linearly here)
+    if (a.CoutPad % 32 || a.Cout % 8 || a.Cout > a.CoutPad) return false;
+    if (a.in2 && (a.KH != 1 || a.stride != 1 || a.in2_split <= 0 || (a.in2_split * esz) % 128 || (a.H & 1) || (a.W & 1))) return false;
+    if (a.M <= 0 || a.M > 0x7fffffffLL) return false;
+    if ((long long)a.H * a.W * a.in_ld * esz * 2 > 0x7fffffffLL) return false; // lane offsets: two neighbouring images inside 31 bits
+    return true;
+}
+
+size_t conv_sk_partial_bytes(const ConvArgs &a, int split) {
+    const int esz = split ? 2 : 4;
+    const int nk = (int)((long long)a.Kpad * esz / 128);
+    const int S = conv_sk_slices(nk);
+    return S > 1 ? (size_t)S * (size_t)a.M * a.CoutPad * sizeof(float) : 0;
+}
+
+size_t conv_sk_ticket_count(long long M, int cout_pad) { return (size_t)((M + 63) / 64) * (size_t)(cout_pad / 32); } // the smallest tile: 64 px x 32 couts
+
+// `a` as the implicit-GEMM launchers take it (split: pseudo-channel arguments); `partial` = conv_sk_partial_bytes(a, split) bytes of scratch of this op
+hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
+    if (!conv_sk_eligible(a, split)) return hipErrorInvalidValue;
+    const int esz = split ? 2 : 4;
+    SkArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.in = reinterpret_cast<const char *>(a.in), k.in_ldb = (unsigned)a.in_ld * esz, k.in_offb = (unsigned)a.in_coff * esz;
+    if (a.in2) {
+        k.in2 = reinterpret_cast<const char *>(a.in2), k.in2_ldb = (unsigned)a.in2_ld * esz, k.in2_offb = (unsigned)a.in2_coff * esz;
+        k.in2_blocks = a.in2_split * esz / 128;
+    }
+    k.N = a.N, k.H = a.H, k.W = a.W, k.Ho = a.Ho, k.Wo = a.Wo;
+    k.cpb = a.Cin * esz / 128;
+    k.KW = a.KW, k.stride = a.stride, k.pad = a.pad;
+    k.nk = (int)((long long)a.Kpad * esz / 128);
+    k.S = conv_sk_slices(k.nk);
+    k.w = reinterpret_cast<const char *>(a.w), k.w_rowb = (unsigned)k.nk * 128u;
+    k.bias = a.bias;
+    k.Cout = a.Cout, k.CoutPad = a.CoutPad, k.act = a.act;
+    k.out = a.out, k.out_ld = a.out_ld, k.out_coff = a.out_coff, k.out_f32 = a.out_f32;
+    k.res = a.res, k.res_ld = a.res_ld, k.res_coff = a.res_coff;
+    k.partial = partial;
+    // in-kernel combination while the slabs are small (a dependent launch costs ~4.7 us); big slabs (large batches) go through plain stores and
+    // the second launch: write-through stores of tens of megabytes cost more than the launch.  Same arithmetic either way.
+    static const long long inkernel_max = (long long)sk_env("WTK_SK_INKERNEL_MAX_KB", 4096) * 1024;
+    k.tickets = (long long)k.S * a.M * a.CoutPad * 4 <= inkernel_max ? tickets : nullptr;
+    k.M = a.M;
+    k.n_dyn = a.n_dyn;
+    k.d_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    k.d_wo = make_fastdiv((unsigned)a.Wo);
+    k.d_cpb = make_fastdiv((unsigned)k.cpb);
+    k.d_cg = make_fastdiv((unsigned)(a.Cout / 8));
+    if (k.S > 1 && !partial) return hipErrorInvalidValue;
+    if ((k.in2 != nullptr) != (k.in2_blocks > 0) || k.in2_blocks > k.cpb) return hipErrorInvalidValue;
+    // Tile (it does not enter the arithmetic): the largest one whose blocks still cover the chip.  The two 128-pixel tiles (large batches) must give
+    // every CU a block; the 64-pixel tiles are for layers that cannot — there ONE round of blocks matters more than a full chip: a layer of 192 blocks
+    // of 64 x 64 is over in one latency-bound round, 384 blocks of 64 x 32 take a round and a half (model.7 at B = 1: 16 us against 9).
+    auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * (long long)(a.CoutPad / bn) * k.S; };
+    const long long cus = (long long)num_cus;
+    hipError_t e;
+    static const int force = sk_env("WTK_SK_TILE", -1); // tuning switch: 0 128x128, 1 128x64, 2 64x64, 3 64x32 wherever the couts allow it
+    if (force == 0 && a.CoutPad % 128 == 0)
+        return split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st);
+    if ((force == 0 || force == 1) && a.CoutPad % 64 == 0 && (k.S == 1 || k.tickets))
+        return split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st);
+    if ((force == 0 || force == 1 || force == 2) && a.CoutPad % 64 == 0 && (k.S == 1 || k.tickets))
+        return split ? sk_launch_t<true, 64, 64, 2, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 2, 2, 8>(k, st);
+    if (force >= 0 && (k.S == 1 || k.tickets)) return split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st);
+    if (a.CoutPad % 128 == 0 && blocks(128, 128) >= cus)
+        e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st);
+    else if (a.CoutPad % 64 == 0 && blocks(128, 64) >= cus)
+        e = split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st);
+    else if (a.CoutPad % 64 == 0 && (5 * blocks(64, 64) >= 3 * cus || a.CoutPad % 32 != 0))
+        e = split ? sk_launch_t<true, 64, 64, 2, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 2, 2, 8>(k, st);
+    else
+        e = split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st);
+    if (e != hipSuccess || k.S == 1 || k.tickets) return e;
+    const long long threads = a.M * (a.Cout / 8);
+    if (split)
+        hipLaunchKernelGGL(sk_finish_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
+    else
+        hipLaunchKernelGGL(sk_finish_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+
+} // namespace wtk

@@ -12,6 +12,13 @@ namespace wtk {
 
 template <typename T> __device__ __forceinline__ float ldf(const T *p) { return (float)*p; }
 
+// Range guard (wtk_yolo_status): the fp16 and f16x3 modes keep activations as fp16 (pairs), so a model whose activations leave the fp16 range
+// (|x| >= 65 504 in the log2(e)-scaled domain) produces infinities, which every layer behind them turns into more infinities / NaNs — all the way into
+// the head logits of the affected receptive fields.  The arg-max below would silently step over such anchors (a NaN never compares greater), so the
+// scan that reads every class logit anyway raises a sticky flag instead: one v_cmp_class per logit here, nothing in any conv epilogue.
+constexpr int kStatusNonFinite = 1;
+__device__ __forceinline__ bool not_finite(float x) { return !(fabsf(x) <= 3.402823466e+38f); }
+
 // order: larger score wins; equal scores -> lower anchor index wins (stable-sort tie break)
 __device__ __forceinline__ void better(float &s, int &i, float s2, int i2) {
     if (s2 > s || (s2 == s && i2 < i)) {
@@ -33,6 +40,7 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
     // logit-based (ties with the winner count: margin <= 0).
     float best = -INFINITY, best_l = -INFINITY, second = -INFINITY;
     int best_i = 0x7fffffff;
+    bool bad = false;
     auto merge = [](float &b, int &bi, float &bl, float &s2nd, float b2, int bi2, float bl2, float s2) __attribute__((always_inline)) {
         if (b2 > b || (b2 == b && bi2 < bi)) {
             s2nd = fmaxf(fmaxf(bl, s2nd), s2);
@@ -55,10 +63,16 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
         const int Al = lvl == 0 ? A0 : (lvl == 1 ? A1 : A2);
         const T *c = reinterpret_cast<const T *>(a.cls[lvl]) + ((long long)n * Al + j) * a.cls_ld;
         float m = ldf(c);
-        for (int k = 1; k < a.nc; ++k) m = fmaxf(m, ldf(c + k)); // conf = max over classes
+        bad |= not_finite(m);
+        for (int k = 1; k < a.nc; ++k) {
+            const float v = ldf(c + k);
+            bad |= not_finite(v);
+            m = fmaxf(m, v); // conf = max over classes
+        }
         // score = sigmoid(logit) in fp32, the same expression as head_nms_kernel's
         merge(best, best_i, best_l, second, 1.0f / (1.0f + expf(-m)), i, m, -INFINITY);
     }
+    if (bad && a.status) __hip_atomic_fetch_or(a.status, kStatusNonFinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // rare path: only a broken model gets here
     // wavefront butterfly (64 lanes)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -108,11 +122,14 @@ __global__ __launch_bounds__(1024) void head_select_kernel(const HeadArgs a) {
         const T *b = reinterpret_cast<const T *>(a.box[lvl]) + ((long long)n * Al + j) * 64 + lane * 16;
         float x[16];
         float mx = -INFINITY;
+        bool badb = false;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             x[k] = ldf(b + k);
+            badb |= not_finite(x[k]);
             mx = fmaxf(mx, x[k]);
         }
+        if (badb && a.status) __hip_atomic_fetch_or(a.status, kStatusNonFinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the survivor's box logits
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -225,10 +242,13 @@ __global__ __launch_bounds__(1024) void head_nms_kernel(const NmsArgs q) {
         const T *c = reinterpret_cast<const T *>(a.cls[lvl]) + ((long long)n * Al + j) * a.cls_ld;
         float m = ldf(c);
         int mk = 0;
+        bool bad = not_finite(m);
         for (int k = 1; k < a.nc; ++k) { // first maximum wins, as torch.max
             const float v = ldf(c + k);
+            bad |= not_finite(v);
             if (v > m) m = v, mk = k;
         }
+        if (bad && a.status) __hip_atomic_fetch_or(a.status, kStatusNonFinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const float score = 1.0f / (1.0f + expf(-m));
         const bool cand = score > a.conf;
         sc[i] = cand ? score : -INFINITY;

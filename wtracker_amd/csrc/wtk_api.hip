@@ -498,6 +498,9 @@ struct Op {
     float *bias = nullptr;
     double macs_per_image = 0;
     int spec = -1; // index of the (first) conv blob this op computes, for wtk_yolo_debug_tensor
+    int sk = 0;                  // latency plan: this conv runs on conv_sk_kernel (split-K implicit GEMM, conv_sk.hip)
+    float *sk_partial = nullptr; // ... and this is its slab scratch ([slices][max_batch * ho * wo][cout_pad] fp32; null: one slice)
+    unsigned *sk_tickets = nullptr; // ... and the arrival counters of its tiles (zero between launches; null: one slice, or WTK_SK_FINISH=1)
 };
 
 } // namespace
@@ -549,6 +552,13 @@ struct wtk_yolo {
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
     int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
     int num_cus = 0;
+    // Latency plan (small batches: the reference's own operating point, one B = cycle_frame_num call and one B = 1 call per cycle,
+    // yolo_controller.py:96-98,108-109).  Chosen when the handle is created — max_batch <= 16 and a reference-precision dtype, or WTK_LATENCY_PLAN=0/1 —
+    // and NOT per call: every conv behind the fused front then runs on conv_sk_kernel whatever the batch of the call, so a frame's logits do not
+    // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
+    int latency = 0;
+    int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status)
+    int status_static = 0;      // flags fixed at create time (none today)
     int profiling = 0;
     // kernel ids of the profile: 0 stem, 1 conv_igemm, 2 pool, 3 head, 4 conv3x3_halo (+ fused tails), 5 fused front / C2f tail,
     // 6 conv3x3_c32; the public class 1 ("conv") of wtk_yolo_get_profile is the sum of 1, 4, 5, 6
@@ -570,6 +580,7 @@ struct wtk_yolo {
         float conf;
         void *o_xywh, *o_conf, *o_anchor;
         hipGraphExec_t exec;
+        hipStream_t last_stream = nullptr; // stream of the last replay: synchronised before the exec is destroyed (a replay may still be in flight there)
         // views form (wtk_yolo_predict_views): the view table's device addresses and the view shape are part of the key
         const void *idx = nullptr, *pos = nullptr;
         int vw = 0, vh = 0, nf = 0;
@@ -733,6 +744,16 @@ static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_pa
             }
         }
     }
+    if (h->is_f16 || h->split) { // range guard of the fp16-storage modes (include/wtk_hip.h: wtk_yolo_status)
+        for (size_t i = 0; i < wf.size(); ++i) {
+            const float m = std::fabs(wf[i]);
+            if (!(m <= 65504.0f))
+                return fail("wtk_yolo_create: a folded weight of conv blob " + std::to_string(op.spec) + " (|w| = " + std::to_string(m) +
+                            " in the library's scaled domain) is outside the fp16 range: this model needs dtype WTK_F32");
+        }
+    }
+    for (float b : bf)
+        if (!std::isfinite(b)) return fail("wtk_yolo_create: a bias of conv blob " + std::to_string(op.spec) + " is not finite");
     if (dev_alloc(h, (void **)&op.bias, bf.size() * sizeof(float))) return 1;
     HIP_TRY(hipMemcpy(op.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
     if (h->split) {
@@ -884,6 +905,7 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     (void)hipFree(h->nms_score);
     (void)hipFree(h->nms_box);
     (void)hipFree(h->nms_cls);
+    if (h->status_host) (void)hipHostFree(h->status_host);
     for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; ++i)
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
@@ -898,8 +920,13 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     delete h;
 }
 
-extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
+extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) { return wtk_yolo_create_planned(out, d, WTK_PLAN_AUTO); }
+extern "C" int wtk_yolo_plan(wtk_yolo *h) { return h ? (h->latency ? WTK_PLAN_LATENCY : WTK_PLAN_THROUGHPUT) : -1; }
+
+extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, int32_t plan) {
     if (!out || !d || !d->convs) return fail("wtk_yolo_create: null argument");
+    if (plan != WTK_PLAN_AUTO && plan != WTK_PLAN_THROUGHPUT && plan != WTK_PLAN_LATENCY) return fail("wtk_yolo_create_planned: plan must be WTK_PLAN_AUTO, _THROUGHPUT or _LATENCY");
+    if (plan == WTK_PLAN_LATENCY && d->dtype == WTK_F16) return fail("wtk_yolo_create_planned: the latency plan is built for WTK_F32 and WTK_F16X3 handles");
     if (d->dtype != WTK_F32 && d->dtype != WTK_F16 && d->dtype != WTK_F16X3) return fail("wtk_yolo_create: dtype must be WTK_F32, WTK_F16 or WTK_F16X3");
     if (d->imgsz_h <= 0 || d->imgsz_w <= 0 || d->imgsz_h % 32 || d->imgsz_w % 32) return fail("wtk_yolo_create: imgsz must be a positive multiple of 32");
     if (d->max_batch <= 0) return fail("wtk_yolo_create: max_batch must be positive");
@@ -954,6 +981,10 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
         h->num_cus = prop.multiProcessorCount;
     }
+    h->latency = d->max_batch <= 16 && !h->is_f16;
+    if (const char *e = std::getenv("WTK_LATENCY_PLAN")) h->latency = e[0] == '1' && !h->is_f16;
+    if (plan != WTK_PLAN_AUTO) h->latency = plan == WTK_PLAN_LATENCY; // the caller's word beats the rule and the environment
+    if (h->latency) h->use_tail = 0, h->graph_views = 1; // replayed captures: ~100 launches of a few microseconds each are host bound when launched one by one
     if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
     if (const char *e = std::getenv("WTK_GRAPH_VIEWS")) h->graph_views = e[0] == '1';
 
@@ -1002,6 +1033,13 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
             for (int tap = 0; tap < 9; ++tap)
                 for (int ch = 0; ch < 3; ++ch) // the stem reads unscaled pixels and produces scaled activations
                     wp[((size_t)co * taps + tap) * 4 + ch] = (float)((double)w0[((size_t)co * 9 + tap) * 3 + ch] * (double)kActScale);
+        if (h->is_f16 || stem_split)
+            for (float x : wp) {
+                if (!(std::fabs(x) <= 65504.0f)) {
+                    wtk_yolo_destroy(h);
+                    return fail("wtk_yolo_create: a folded weight of conv blob " + std::to_string(i0) + " (model.0) is outside the fp16 range: this model needs dtype WTK_F32");
+                }
+            }
         std::vector<float> stem_bias(c[0]);
         for (int co = 0; co < c[0]; ++co) stem_bias[co] = (float)((double)d->convs[i0].bias[co] * (double)kActScale);
         void *wdev;
@@ -1147,6 +1185,32 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     }
     h->anchors = h8 * w8 + h16 * w16 + h32 * w32;
     for (const Op &op : h->ops) h->macs_per_frame += op.macs_per_image;
+    if (h->latency) { // which convs the split-K kernel takes (everything with rows of 32 input channels), and their slab scratch
+        for (size_t i = 3; i < h->ops.size(); ++i) { // ops[0..2] stay the fused front's
+            Op &op = h->ops[i];
+            if (op.kind != OP_CONV || op.folded || op.tail_op >= 0 || op.out2_buf >= 0 || op.cin % 32 || (op.k != 1 && op.k != 3) || op.cout_pad % 32 || op.cout % 8) continue;
+            if (op.in2_buf >= 0 && (op.k != 1 || op.in2_split % 32)) continue;
+            op.sk = 1;
+            const int S = conv_sk_slices(op.k * op.k * op.cin / 32);
+            const Buf &ob = h->bufs[op.out_buf];
+            if (S > 1 && dev_alloc(h, (void **)&op.sk_partial, (size_t)S * h->max_batch * ob.h * ob.w * op.cout_pad * sizeof(float))) {
+                wtk_yolo_destroy(h);
+                return 1;
+            }
+            const bool two_launches = std::getenv("WTK_SK_FINISH") && std::getenv("WTK_SK_FINISH")[0] == '1'; // A/B switch: slabs combined by a second launch
+            if (S > 1 && !two_launches) {
+                const size_t nt = conv_sk_ticket_count((long long)h->max_batch * ob.h * ob.w, op.cout_pad) * sizeof(unsigned);
+                if (dev_alloc(h, (void **)&op.sk_tickets, nt)) {
+                    wtk_yolo_destroy(h);
+                    return 1;
+                }
+                if (hipMemset(op.sk_tickets, 0, nt) != hipSuccess) {
+                    wtk_yolo_destroy(h);
+                    return fail("wtk_yolo_create: hipMemset failed");
+                }
+            }
+        }
+    }
     // ops[0..2] are stem, model.1, model.2.cv1 by construction; fuse them when the widths match the kernel
     {
         const char *e = std::getenv("WTK_NO_FUSED_FRONT");
@@ -1183,6 +1247,12 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
         wtk_yolo_destroy(h);
         return 1;
     }
+    if (hipHostMalloc((void **)&h->status_host, 64, hipHostMallocMapped) != hipSuccess) {
+        h->status_host = nullptr;
+        wtk_yolo_destroy(h);
+        return fail("wtk_yolo_create: hipHostMalloc failed");
+    }
+    *h->status_host = 0;
     if (dev_alloc(h, &h->zero_page, 256)) {
         wtk_yolo_destroy(h);
         return 1;
@@ -1194,6 +1264,13 @@ extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) {
     // streams (side streams, the host entry points' stream) are taken from the process pool at first use: a handle that never runs
     // with side streams (the hybrid's second look) or never sees a host call does not occupy a hardware queue slot
     *out = h;
+    return 0;
+}
+
+extern "C" int wtk_yolo_status(wtk_yolo *h, int32_t *flags, int32_t clear) {
+    if (!h || !flags) return fail("wtk_yolo_status: null argument");
+    *flags = h->status_static | (h->status_host ? __atomic_load_n(h->status_host, __ATOMIC_RELAXED) : 0);
+    if (clear && h->status_host) __atomic_store_n(h->status_host, 0, __ATOMIC_RELAXED);
     return 0;
 }
 
@@ -1278,6 +1355,11 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
     a.out_conf = out_conf;
     a.out_anchor = out_anchor;
     a.out_margin = h->o_margin;
+    a.status = nullptr;
+    if (h->status_host) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, h->status_host, 0) == hipSuccess) a.status = reinterpret_cast<int *>(dp);
+    }
     a.conf_logit = conf > 0.f && conf < 1.f ? std::log(conf / (1.f - conf)) : (conf <= 0.f ? -INFINITY : INFINITY);
     if (nms) {
         NmsArgs q;
@@ -1482,7 +1564,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             HIP_TRY(launch_sppf_pool(a, h->is_f16, st));
             ++launches[2];
         } else {
-            const int kid = op.halo == 2 ? 6 : (op.halo ? 4 : 1);
+            const int kid = op.sk ? 1 : (op.halo == 2 ? 6 : (op.halo ? 4 : 1));
             if (mark(kid)) return 1;
             const Buf &ib = h->bufs[op.in_buf];
             const Buf &ob = h->bufs[op.out_buf];
@@ -1538,7 +1620,11 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 a.res_ld *= 2, a.res_coff *= 2, a.out2_ld *= 2, a.out2_coff *= 2;
                 if (!a.out_f32) a.out_ld *= 2, a.out_coff *= 2;
             }
-            if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
+            if (op.sk) {
+                a.tile_w = 0;
+                if (!conv_sk_eligible(a, h->split)) return fail("internal: conv " + std::to_string(oi) + " of the latency plan does not fit conv_sk_kernel");
+                HIP_TRY(launch_conv_sk(a, h->split, op.sk_partial, op.sk_tickets, h->num_cus, st));
+            } else if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
                 split_s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0 && !ob.f32)) {
                 // strided 3x3, split operands: the parity-plane window kernel on pseudo-channels
                 HaloArgs g;
@@ -1693,11 +1779,24 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     return 0;
 }
 
+// Captured launches carry the stream layout / dynamic-batch pointer they were captured with: drop them all.  Each exec is destroyed only after the
+// stream of its last replay has drained (no device-wide synchronise: other lanes keep running, and a global-mode capture open in another thread
+// stays legal); argument sets met once are forgotten too.
+static void drop_graphs(wtk_yolo *h) {
+    for (auto &g : h->graphs) {
+        (void)hipStreamSynchronize(g.last_stream);
+        (void)hipGraphExecDestroy(g.exec);
+    }
+    h->graphs.clear();
+    h->seen_once.clear();
+}
+
 // Replay the captured forward pass of this argument set, or capture it now (the whole launch sequence incl. the side streams).
 static int graph_replay_or_capture(wtk_yolo *h, wtk_yolo::GraphEntry key, hipStream_t st, const ViewSrc *vs) {
     for (auto &g : h->graphs)
         if (g.same_args(key)) {
             HIP_TRY(hipGraphLaunch(g.exec, st));
+            g.last_stream = st;
             return 0;
         }
     hipGraph_t graph = nullptr;
@@ -1717,9 +1816,12 @@ static int graph_replay_or_capture(wtk_yolo *h, wtk_yolo::GraphEntry key, hipStr
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) return fail_hip("hipGraphInstantiate", ei);
     if (h->graphs.size() >= 16) { // bounded cache: callers that rotate buffers would otherwise grow it without limit
+        if (h->graphs.front().last_stream != st) (void)hipStreamSynchronize(h->graphs.front().last_stream); // (the same stream orders the destroy behind the replay itself)
+        else (void)hipStreamSynchronize(st);
         (void)hipGraphExecDestroy(h->graphs.front().exec);
         h->graphs.erase(h->graphs.begin());
     }
+    key.last_stream = st;
     h->graphs.push_back(key);
     HIP_TRY(hipGraphLaunch(key.exec, st));
     return 0;
@@ -1745,9 +1847,21 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     // Only for the handle's own staging buffers (the *_host entry points): their addresses never change, so
     // one capture per (B, H, W, C, conf) is replayed forever; arbitrary caller buffers would thrash the cache.
     const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
-    const bool use_graph = own_buffers && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
+    // A latency-plan handle (~100 short launches) also replays for caller buffers: an argument set is captured the second time it is met, so a caller
+    // that rotates its buffers never pays for a capture.
+    const bool use_graph = (own_buffers || h->latency) && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
     if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
     wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
+    if (!own_buffers) {
+        bool known = false;
+        for (auto &g : h->graphs) known = known || g.same_args(key);
+        for (auto &g : h->seen_once) known = known || g.same_args(key);
+        if (!known) {
+            if (h->seen_once.size() >= 16) h->seen_once.erase(h->seen_once.begin());
+            h->seen_once.push_back(key);
+            return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
+        }
+    }
     return graph_replay_or_capture(h, key, st, nullptr);
 }
 
@@ -1843,9 +1957,7 @@ extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
     if (!h || n < 0 || n > 2) return fail("wtk_yolo_set_side_streams: n must be 0, 1 or 2");
     if (h->side_streams >= 3) return fail("wtk_yolo_set_side_streams: the handle was planned with WTK_SIDE_STREAMS=3");
     DEVICE_GUARD(h);
-    if (!h->graphs.empty()) HIP_TRY(hipDeviceSynchronize()); // captured launches (host stream or a caller's) carry the old stream layout
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
+    drop_graphs(h); // captured launches (host stream or a caller's) carry the old stream layout
     h->side_streams = n;
     h->use_side = n > 0;
     return 0;
@@ -1854,12 +1966,10 @@ extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
 extern "C" int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev) {
     if (!h) return fail("wtk_yolo_set_dynamic_batch: null handle");
     h->n_dyn = n_dev;
-    if (!h->graphs.empty()) { // captured launches of the host entry points carry the old pointer
+    if (!h->graphs.empty() || !h->seen_once.empty()) { // captured launches carry the old pointer
         DEVICE_GUARD(h);
-        HIP_TRY(hipDeviceSynchronize()); // replays may be in flight on the host stream or on a caller's
+        drop_graphs(h);
     }
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
     return 0;
 }
 
@@ -2138,6 +2248,8 @@ extern "C" int wtk_hybrid_predict(wtk_hybrid *h, const uint8_t *frames_dev, int3
         if (fb <= 0 || fb % 16 || reinterpret_cast<uintptr_t>(frames_dev) % 16)
             return fail("wtk_hybrid_predict (defer > 1): frames must be 16-byte aligned and a multiple of 16 bytes each");
         if (reinterpret_cast<uintptr_t>(out_xywh) % 16) return fail("wtk_hybrid_predict (defer > 1): xywh rows must be 16-byte aligned");
+        // ... including the fast pass's own argument checks: a call it would reject must not fix the queue's frame shape for the object's life
+        if ((C != 1 && C != 3) || H <= 0 || W <= 0) return fail("wtk_hybrid_predict: frames must be H x W x 1 (gray) or H x W x 3 (BGR)");
         if (h->q_frames && (h->q_H != H || h->q_W != W || h->q_C != C))
             return fail("wtk_hybrid_predict (defer > 1): every call must bring frames of the same shape");
         if (!h->q_frames) { // the queue's frame copies: allocated at the first call, for its frame shape

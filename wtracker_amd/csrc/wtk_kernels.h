@@ -200,6 +200,13 @@ int conv_cfg_bn(int cfg);
 hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t stream);
 hipError_t launch_conv_split(const ConvArgs &a, int cfg, hipStream_t stream); // split-fp16 operands (see kSplitScale above)
 hipError_t conv_init_attributes();
+// Small-batch (latency) plan: split-K implicit GEMM, split-fp16 or fp32 operands (conv_sk.hip).  `a` as launch_conv_split / launch_conv take it.
+int conv_sk_slices(int nk); // K slices of a layer of nk steps (32 channels of one tap each): a function of the layer alone
+bool conv_sk_eligible(const ConvArgs &a, int split);
+size_t conv_sk_partial_bytes(const ConvArgs &a, int split); // scratch of the op: [slices][M][CoutPad] fp32 (0: one slice)
+// tickets: conv_sk_ticket_count(a) zero-initialised counters of this op (the last block of a tile combines the slabs in-kernel), or null (second launch: sk_finish_kernel)
+size_t conv_sk_ticket_count(long long M, int cout_pad);
+hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned *tickets, int num_cus, hipStream_t stream);
 // fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
 hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream);
@@ -412,6 +419,7 @@ struct HeadArgs {
     // |best - logit(conf)|) — how far the fp32 result is from choosing another anchor or from flipping detection / NaN row
     float *out_margin;
     float conf_logit; // log(conf / (1 - conf))
+    int *status;      // nullable: sticky flags of the handle in pinned HOST memory (bit 0: a non-finite head logit was read; wtk_yolo_status)
 };
 hipError_t launch_head(const HeadArgs &a, int is_f16, hipStream_t stream);
 

@@ -50,7 +50,7 @@ class _YoloDesc(C.Structure):
 SYMBOLS = [
     "wtk_last_error", "wtk_abi_version", "wtk_device_count",
     "wtk_mlp_create", "wtk_mlp_destroy", "wtk_mlp_forward", "wtk_mlp_forward_host", "wtk_mlp_predict_track",
-    "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_destroy", "wtk_yolo_predict",
+    "wtk_yolo_conv_count", "wtk_yolo_conv_info", "wtk_yolo_create", "wtk_yolo_create_planned", "wtk_yolo_plan", "wtk_yolo_status", "wtk_yolo_destroy", "wtk_yolo_predict",
     "wtk_yolo_predict_host", "wtk_yolo_debug_head", "wtk_yolo_decode_host", "wtk_yolo_workload",
     "wtk_yolo_set_profiling", "wtk_yolo_get_profile", "wtk_yolo_get_kernel_profile", "wtk_crop_views", "wtk_yolo_debug_tensor",
     "wtk_yolo_predict_views", "wtk_track_median_centers", "wtk_track_polyfit", "wtk_track_training_pairs",
@@ -133,6 +133,9 @@ def load() -> C.CDLL:
     lib.wtk_yolo_conv_info.argtypes = [f32, f32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
                                        C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
     lib.wtk_yolo_create.argtypes = [C.POINTER(vp), C.POINTER(_YoloDesc)]
+    lib.wtk_yolo_create_planned.argtypes = [C.POINTER(vp), C.POINTER(_YoloDesc), i32]
+    lib.wtk_yolo_plan.argtypes = [vp]
+    lib.wtk_yolo_status.argtypes = [vp, C.POINTER(i32), i32]
     lib.wtk_yolo_destroy.argtypes = [vp]
     lib.wtk_yolo_destroy.restype = None
     lib.wtk_yolo_predict.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
@@ -391,6 +394,10 @@ def yolo_conv_table(width: float, depth: float, max_channels: int, nc: int) -> l
     return out
 
 
+STATUS_NONFINITE = 1
+PLANS = {"auto": 0, "throughput": 1, "latency": 2}
+
+
 class HipYolo:
     """Device YOLOv8 detector (wtk_yolo) for one network input size.
 
@@ -398,8 +405,12 @@ class HipYolo:
     wtracker_amd.yolo_spec.conv_table(scale, nc)."""
 
     def __init__(self, weights: dict, imgsz: tuple[int, int], max_batch: int, dtype: str = "fp16", nc: int = 1,
-                 width: float = 0.5, depth: float = 0.33, max_channels: int = 1024, device: int = 0):
+                 width: float = 0.5, depth: float = 0.33, max_channels: int = 1024, device: int = 0, plan: str = "auto"):
+        """plan: "auto" (latency when max_batch <= 16 and the dtype is fp32 / f16x3, else throughput; WTK_LATENCY_PLAN=0/1 overrides), "throughput" or
+        "latency" (include/wtk_hip.h: wtk_yolo_create_planned) — fixed for the handle's life, so a frame's result does not depend on the batch it is in."""
         lib = load()
+        if plan not in PLANS:
+            raise WtkError(f"plan must be one of {sorted(PLANS)}")
         table = yolo_conv_table(width, depth, max_channels, nc)
         arr = (_ConvBlob * len(table))()
         self._keep = []
@@ -416,7 +427,8 @@ class HipYolo:
         desc = _YoloDesc(device, DTYPES[dtype], int(imgsz[0]), int(imgsz[1]), int(max_batch), nc, width, depth, max_channels,
                          len(table), arr)
         self._h = C.c_void_p()
-        _check(lib.wtk_yolo_create(C.byref(self._h), C.byref(desc)), "wtk_yolo_create")
+        _check(lib.wtk_yolo_create_planned(C.byref(self._h), C.byref(desc), PLANS[plan]), "wtk_yolo_create_planned")
+        self.plan = "latency" if lib.wtk_yolo_plan(self._h) == PLANS["latency"] else "throughput"
         self._keep = []  # the library copied everything to the device
         self.imgsz = (int(imgsz[0]), int(imgsz[1]))
         self.max_batch = int(max_batch)
@@ -459,6 +471,14 @@ class HipYolo:
         """Device pointers / torch CUDA tensors; asynchronous on `stream`."""
         _check(load().wtk_yolo_predict(self._h, _ptr(frames_dev), B, H, W, Cc, conf, iou, max_det, _ptr(out_xywh),
                                        _ptr(out_conf), _ptr(out_anchor), C.c_void_p(stream)), "wtk_yolo_predict")
+
+    def status(self, clear: bool = False) -> int:
+        """Range-guard flags (include/wtk_hip.h: WTK_STATUS_NONFINITE = 1, sticky, raised by the head kernels when a head logit is inf / NaN — an
+        activation left the fp16 range somewhere in the network).  No device call: valid for the work the
+        caller has synchronised with."""
+        f = C.c_int32()
+        _check(load().wtk_yolo_status(self._h, C.byref(f), int(clear)), "wtk_yolo_status")
+        return f.value
 
     def set_dynamic_batch(self, n_dev):
         """`n_dev`: device int32 scalar (tensor / pointer) holding the number of batch rows that matter in the following calls, or None."""
