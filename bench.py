@@ -81,7 +81,7 @@ HYBRID_CAL_FRAMES, HYBRID_CAL_SEED = 512, 40000
 # HYBRID_DEFER batches); queue of HYBRID_QUEUE rows per lane = 40 % of the frames it can receive — a fuller queue is COUNTED (overflow) and demotes the mode.
 HYBRID_DEFER, HYBRID_QUEUE_PER_64 = 5, 128
 HYBRID_EXACT_MEM_GB = 48.0  # f16x3 workspace of one lane's second-look handle
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 # The headline is a REFERENCE-PRECISION mode (the reference computes in fp32: yolo/yolo_train_config.yaml:51 `half: False`): the fastest of these whose
 # survivor index equals the fp32 restatement's on every parity frame of the run AND whose boxes pass BASELINE.md section 4's gate (matched IoU >= 0.999).
 # fp16 (throughput) and hybrid (fp16 rows + a full-precision second look at weak decisions: index-exact by a calibrated margin, boxes of the
@@ -192,7 +192,7 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
            "frames": f"{ec.num_frames} synthetic {size}x{size} uint8 gray frames resident in HBM, camera view 360x360 -> imgsz 384, conf {conf}",
            "timing_ms": [200, 40, 50], "cycle_frames": 15, "cycles": cycles, "calls_per_cycle": "one B=15 _cycle_predict_all + one B=1 provide_movement_vector"}
     ref_moves = None
-    for dtype, plan in (("f16x3", "latency"), ("fp32", "latency"), ("f16x3", "throughput")):
+    for dtype, plan in (("f16x3", "auto"), ("fp32", "auto"), ("f16x3", "latency"), ("f16x3", "throughput")):
         cfg = YoloConfig(model_path=tmp.name, device=f"cuda:{device}", pred_kwargs={"imgsz": 384, "conf": conf}, dtype=dtype, scale=scale, max_batch=16, plan=plan)
         drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))  # warm-up pass: handle creation, captures
         res, moves, _ = drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))
@@ -204,8 +204,9 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
             ref_moves = moves
         res["moves_equal_first_mode"] = moves == ref_moves
         out[f"{dtype}_{plan}"] = res
-    out["plans"] = ("*_latency = the plan HipYoloController's handles get for calls of <= 16 frames (YoloConfig.plan = 'auto'): split-K convs (conv_sk.hip) and a replayed "
-                    "hipGraph per (batch size, buffers); f16x3_throughput = the same calls on the large-batch kernels (what every call ran on before round 5)")
+    out["plans"] = ("*_auto = YoloConfig.plan 'auto' (the default): the single-frame call on a latency-plan handle (split-K convs, conv_sk.hip, replayed hipGraph), the "
+                    "15-frame call on a throughput-plan handle — each call on the plan that is faster for it; f16x3_latency = both calls on ONE latency-plan handle (a frame's "
+                    "result is bit-identical whichever call sees it); f16x3_throughput = both calls on the large-batch kernels (what every call ran on before round 5)")
     # the CPU restatement's controller on the host cores, same frames and driver
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
@@ -785,7 +786,7 @@ def main():
     out["end_to_end"] = head["end_to_end"]
     if closed is not None:
         out["closed_loop"] = closed
-        out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_latency"]["frames_per_s"]
+        out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_auto"]["frames_per_s"]
     if lat is not None:
         out["latency"] = lat
         for r in lat["rows"]:  # two scalars per reference-precision mode in the main line: the reference's two calls

@@ -37,7 +37,10 @@ def test_hybrid_calibrated_margin_out_of_sample_2048_frames_per_weight_seed(hip_
     frames, cal = _frames(2048), _frames(512, seed=40000)
     rep = run_weight_seed(weight_seed, frames, 640, 64, MARGIN, 0.1, oracle_frames=128, cal_frames=cal, defer=4)
     with capsys.disabled():
-        print(f"\nhybrid_validation weight_seed={weight_seed} " + json.dumps(rep))
+        c_ = rep["calibration"]  # ONE line per draw (the full report is what tools/hybrid_validation.py writes under profiles/)
+        print(f"\nhybrid_validation weight_seed={weight_seed}: margin {c_['margin']:.4f} (sigma {c_['margin_noise_sigma']:.4f}), fp16 mismatches "
+              f"{len(rep['fp16_mismatch_margins_sorted_desc'])} (largest margin {rep['fp16_mismatch_margin_max']:.4f}), hybrid mismatches "
+              f"{rep['hybrid_index_mismatches_vs_f16x3']}, overflow {rep['hybrid_overflow_rows']}, rows replaced {rep['hybrid_rows_replaced']} of {rep['frames']}")
     assert rep["frames"] == 2048 and rep["calibration"]["frames"] == 512
     # the synthetic weights of this draw give scores below saturation (per-seed gain tables, tools/calibrate_synth_gains.py)
     assert rep["detections_f16x3"] > 0.2 * 2048 and rep["best_score_f16x3"]["p50"] < 0.9995

@@ -39,12 +39,12 @@ def test_auto_rule_and_explicit_plans(hip_lib, monkeypatch):
     w = ys.synthetic_weights("s", 1, seed=0)
     mk = lambda **kw: hip.HipYolo(w, (128, 128), **kw)
     monkeypatch.delenv("WTK_LATENCY_PLAN", raising=False)
-    for dtype, mb, want in (("fp32", 16, "latency"), ("f16x3", 1, "latency"), ("f16x3", 17, "throughput"), ("fp16", 8, "throughput")):
+    for dtype, mb, want in (("fp32", 4, "latency"), ("f16x3", 1, "latency"), ("f16x3", 5, "throughput"), ("fp16", 2, "throughput")):
         d = mk(max_batch=mb, dtype=dtype)
         assert d.plan == want, (dtype, mb, d.plan)
         d.close()
     monkeypatch.setenv("WTK_LATENCY_PLAN", "0")  # the variable overrides AUTO ...
-    d = mk(max_batch=8, dtype="fp32")
+    d = mk(max_batch=2, dtype="fp32")
     assert d.plan == "throughput"
     d.close()
     d = mk(max_batch=8, dtype="fp32", plan="latency")  # ... and an explicit plan beats the variable
@@ -167,10 +167,37 @@ def test_in_kernel_slab_combination_equals_the_two_launch_form(hip_lib, dtype, m
     a.close(), b.close()
 
 
-def test_replayed_capture_for_caller_buffers_equals_eager(hip_lib):
-    """A latency handle replays a captured hipGraph for caller buffers from the third call with the same argument set on (seen once -> captured ->
-    replayed); the rows must be the eager rows, and new frame CONTENT in the same buffer must be honoured by the replay."""
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_walking_all_atoms_in_one_block_equals_one_block_per_atom(hip_lib, dtype, monkeypatch):
+    """An output value is defined as ((A_0 + A_1) + ...) over the layer's K atoms.  The launcher picks per call between one block per atom (slabs +
+    combination) and one block that walks all atoms and folds them at the atom boundaries (many pixels: no slabs), and between four tile shapes.
+    WTK_SK_FORM / WTK_SK_TILE force each choice for every layer: all of them must give the same logits bit for bit — that is what makes the choice
+    free to depend on the batch."""
+    size, B = 384, 5
+    monkeypatch.setenv("WTK_GRAPH_MAX_BATCH", "0")  # eager launches: the switches are read at launch time
+    _, det, _ = _handle(size, dtype)
+    frames = fr.diverse_frames(8, size, seed=321)[:B]
+    ref = None
+    for form, tile in (("-1", "-1"), ("0", "-1"), ("1", "-1"), ("0", "2"), ("1", "3"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("WTK_SK_FORM", form)
+        monkeypatch.setenv("WTK_SK_TILE", tile)
+        x, c, a = det.predict_host(frames, conf=0.1)
+        b, k = det.debug_head(B)
+        if ref is None:
+            ref = (x, a, b, k)
+            continue
+        np.testing.assert_array_equal(k, ref[3], err_msg=f"form {form} tile {tile}")
+        np.testing.assert_array_equal(b, ref[2], err_msg=f"form {form} tile {tile}")
+        np.testing.assert_array_equal(a, ref[1])
+        np.testing.assert_array_equal(x, ref[0])
+    det.close()
+
+
+def test_replayed_capture_for_caller_buffers_equals_eager(hip_lib, monkeypatch):
+    """With WTK_GRAPH_VIEWS=1 a latency handle replays a captured hipGraph for caller buffers from the third call with the same argument set on (seen
+    once -> captured -> replayed); the rows must be the eager rows, and new frame CONTENT in the same buffer must be honoured by the replay."""
     size, B = 384, 15
+    monkeypatch.setenv("WTK_GRAPH_VIEWS", "1")
     _, det, _ = _handle(size, "f16x3")
     dev = torch.device("cuda", 0)
     fa = torch.from_numpy(fr.diverse_frames(16, size, seed=1)[:B]).to(dev)

@@ -1,0 +1,25 @@
+# Profile artefacts of round 5 (tools/refresh_profiles_r05.sh copies them under profiles/): the default bench workload (batch 64, 640x640) in the HEADLINE
+# mode (f16x3) and in the fp16 mode.  Every pass is the bench command itself (`python3 bench.py ...` right after `--`); PMC passes are separate runs with
+# no trace domain next to --pmc.
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-fp32 --cpu-frames 0 --no-check"
+for M in f16x3 fp16; do
+  # 1. kernel stats of the DEFAULT command's timed workload in this mode (2 lanes, side streams on)
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5pf_stats_$M -o bench -- $B --dtype $M --steps 10 --warmup 4 --repeats 2 > $R/gpurun_out/r5pf_stats_$M.log 2>&1 || echo "stats $M failed"
+  # 2. single-stream trace for the per-layer table and the per-kernel averages the roofline object is checked against
+  WTK_NO_SIDE_STREAM=1 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r5pf_layers_$M -o bench -- $B --dtype $M --steps 10 --warmup 4 --repeats 1 --lanes 1 --no-profile > $R/gpurun_out/r5pf_layers_$M.log 2>&1 || echo "layers $M failed"
+  # 3. HBM traffic and MFMA-busy: separate PMC passes
+  WTK_NO_SIDE_STREAM=1 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r5pf_fetch_$M -o p -- $B --dtype $M --steps 2 --warmup 1 --repeats 1 --lanes 1 --no-profile > $R/gpurun_out/r5pf_fetch_$M.log 2>&1 || echo "fetch $M failed"
+  WTK_NO_SIDE_STREAM=1 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r5pf_write_$M -o p -- $B --dtype $M --steps 2 --warmup 1 --repeats 1 --lanes 1 --no-profile > $R/gpurun_out/r5pf_write_$M.log 2>&1 || echo "write $M failed"
+  WTK_NO_SIDE_STREAM=1 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/r5pf_mfma_$M -o p -- $B --dtype $M --steps 2 --warmup 1 --repeats 1 --lanes 1 --no-profile > $R/gpurun_out/r5pf_mfma_$M.log 2>&1 || echo "mfma $M failed"
+  echo "$M passes done"
+done
+ls $R/gpurun_out | grep r5pf_ | head -30
+# 4. the latency plan: kernel stats + timeline of the single-frame call (B = 1 at 384^2, f16x3 and fp32) and of B = 1 at 640^2 (BASELINE config 2)
+for cfg in "f16x3 1 384" "fp32 1 384" "f16x3 1 640" "f16x3 15 384"; do
+  set -- $cfg; DT=$1; BB=$2; S=$3
+  N=${DT}_b${BB}_${S}
+  WTK_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5pf_lat_$N -o lat -- python3 $R/tools/gpu_sessions/time_mode.py --dtype $DT --steps 20 --batch $BB --size $S --plan latency > $R/gpurun_out/r5pf_lat_$N.log 2>&1 || echo "latency trace $N failed"
+done
+ls $R/gpurun_out | grep r5pf_ | head -40

@@ -316,10 +316,12 @@ class YoloConfig:
     recheck_dtype: str = "auto"
     scale: str = "s"
     max_batch: int = 64
-    # launch plan of the detector handles (include/wtk_hip.h: wtk_yolo_create_planned).  "auto": calls of up to LATENCY_MAX_BATCH frames — the reference's
-    # own calls: one cycle batch (9 / 15 frames) and one single frame per cycle, yolo_controller.py:96-98,108-109 — go to ONE handle on the latency plan
-    # (split-K convs, replayed captures; a frame's result does not depend on which of the two calls sees it), larger batches to a throughput-plan handle;
-    # "throughput" / "latency": every call on that plan.  fp16 handles always run the throughput plan.
+    # launch plan of the detector handles (include/wtk_hip.h: wtk_yolo_create_planned).  The reference calls the detector twice per cycle: one single frame
+    # (provide_movement_vector, yolo_controller.py:96-98) and one cycle batch of 9 / 15 frames (_cycle_predict_all, :108-109).  "auto": calls of up to
+    # LATENCY_MAX_BATCH frames go to a handle on the latency plan (split-K convs, replayed captures: 0.53 ms instead of 1.0 ms for the single frame), larger
+    # ones to a throughput-plan handle (1.3 ms instead of 1.7 ms for 15 frames): each call on the plan that is faster for it; the two handles agree within
+    # the tolerance both meet against the fp32 restatement, not bit for bit.  "latency": every call up to 16 frames on ONE latency-plan handle — a frame's
+    # result is then bit-identical whichever of the two calls sees it; "throughput": every call on the large-batch kernels.  fp16: always throughput.
     plan: str = "auto"
     model: Any = field(default=None, init=False, repr=False)
 
@@ -361,7 +363,7 @@ class _YoloModel:
         self.weights, self.nc = yolo_spec.load_weights(cfg.model_path)
         self._dets: dict = {}
 
-    LATENCY_MAX_BATCH = 16
+    LATENCY_MAX_BATCH = 4  # measured cross-over between the plans near B = 6 at imgsz 384 (profiles/r05_notes.md)
 
     def detector(self, net_hw: tuple, batch: int, dtype: Optional[str] = None) -> hip.HipYolo:
         dtype = dtype or self.cfg.dtype
@@ -376,7 +378,7 @@ class _YoloModel:
             if det is not None:
                 det.close()
             width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
-            cap = max(batch, self.LATENCY_MAX_BATCH if plan == "latency" else self.cfg.max_batch)
+            cap = max(batch, 16 if plan == "latency" else self.cfg.max_batch)
             det = hip.HipYolo(self.weights, net_hw, cap, dtype=dtype, nc=self.nc, width=width, depth=depth, max_channels=maxch,
                               device=self.cfg.device_index(), plan=plan)
             self._dets[key] = det

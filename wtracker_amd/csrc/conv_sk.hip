@@ -14,9 +14,13 @@
 // store; it also re-arms the ticket).  sk_finish_kernel is the same combination as a second launch (WTK_SK_FINISH=1): a dependent launch costs
 // ~4.7 us here, which is what a small layer's whole convolution costs.  Both forms add the slabs in the same order: bit-identical.
 //
-// Determinism and batch invariance.  The slicing of K is a function of the LAYER alone (conv_sk_slices), every output value is
-// the sum of its slices' MFMA chains in slice order, and the tile shape (chosen from the batch) does not enter the arithmetic:
-// a frame gets the same logits at B = 1 and at B = 15.  No atomics.
+// Determinism and batch invariance.  K is cut into ATOMS — a function of the LAYER alone (conv_sk_slices: <= 12 steps: one atom; else atoms of ~8
+// steps, at most 8) — and an output value is DEFINED as ((A_0 + A_1) + A_2) + ..., A_i = the MFMA chain over atom i's steps started from zero
+// (split mode: acc + 2^-11 acc1 of that chain).  Two launch forms produce exactly that value:
+//   S = NA  one block per (tile, atom): A_i goes to slab i, the combining block adds the slabs in atom order;
+//   S = 1   one block walks all atoms through one continuous ring and folds A_i into its running total at every atom boundary
+// so the form (like the tile shape) is chosen per LAUNCH from the batch — many pixels: S = 1, no slabs at all; few pixels: S = NA, every CU gets
+// work — and a frame still gets the same logits at B = 1 and at B = 15, bit for bit.  No atomics on data.
 //
 // Operand layout: the igemm kernel's (conv_igemm.hip): NHWC activations as channel-slice views, weights [CoutPad][K] with K = (tap, channel);
 // a step's two operand tiles are staged by LDS-DMA (buffer_load ... lds from inline asm, source-side XOR swizzle) and read back as
@@ -25,6 +29,8 @@
 //   fp32   32 floats per row, exact v_mfma_f32_16x16x4_f32
 #include "wtk_kernels.h"
 
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -79,7 +85,8 @@ struct SkArgs {
     int N, H, W, Ho, Wo;
     int cpb;              // 32-channel blocks per tap
     int KW, stride, pad;  // square taps: KH == KW
-    int nk, S;            // K steps in all (taps * cpb), K slices
+    int nk, S;            // K steps in all (taps * cpb); blocks per tile along K: 1 or NA
+    int NA;               // K atoms of the layer (conv_sk_slices): the unit of summation, see the header
     const char *w;        // [CoutPad][nk * 128 bytes]
     unsigned w_rowb;
     const float *bias;
@@ -160,8 +167,12 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
     const int ptile = (int)(blockIdx.x - bq * (unsigned)a.ptiles);
     const int slice = (int)fdiv(bq, a.d_nct);
     const int ctile = (int)(bq - (unsigned)slice * (unsigned)a.nct);
-    const int ks0 = (int)((long long)slice * a.nk / a.S), ks1 = (int)((long long)(slice + 1) * a.nk / a.S);
+    // this block's atoms: all of them (S = 1) or atom `slice` (S = NA); atom i = steps [i nk / NA, (i + 1) nk / NA)
+    int atom = a.S == 1 ? 0 : slice;
+    // (nk <= a few hundred, NA <= 8: 32-bit products; the 64-bit quotient hipcc would otherwise expand costs more than a K step)
+    const int ks0 = (int)((unsigned)(atom * a.nk) / (unsigned)a.NA), ks1 = a.S == 1 ? a.nk : (int)((unsigned)((atom + 1) * a.nk) / (unsigned)a.NA);
     const int nkb = ks1 - ks0;
+    int atom_end = (int)((unsigned)((atom + 1) * a.nk) / (unsigned)a.NA) - ks0; // step index (from ks0) at which the current atom is complete
     const int HoWo = a.Ho * a.Wo;
     long long m_eff = a.M;
     if (a.n_dyn) m_eff = (long long)min(max(*a.n_dyn, 0), a.N) * HoWo; // dynamic batch: tiles that start beyond its last image are not computed
@@ -290,13 +301,38 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
     // the other waves (which also says that everybody is done reading the stage of step s - 1) and then re-fills that stage
     const int pre = min(NS - 1, nkb);
     for (int s = 0; s < pre; ++s) issue(ks0 + s, smem + s * STAGE);
-    for (int s = 0; s < nkb; ++s) {
-        sk_wait_stages<PER>(min(s + NS - 1, nkb) - s - 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragment reads of step s - 1 are done
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + NS - 1 < nkb) issue(ks0 + s + NS - 1, smem + ((s + NS - 1) & (NS - 1)) * STAGE);
-        compute(smem + (s & (NS - 1)) * STAGE);
+    floatx4 tot[TC][TP]; // ((A_0 + A_1) + ...) of the atoms finished so far
+    // (two nested loops — atoms outside, the atom's steps inside — rather than a fold under an `if` in one flat loop: with the flat form hipcc kept the
+    // chains in AGPRs and copied all of them out and back at EVERY step; the ring itself runs on across the atom boundaries)
+    int s = 0;
+    for (bool first_atom = true; s < nkb; first_atom = false) {
+        for (; s < atom_end; ++s) {
+            sk_wait_stages<PER>(min(s + NS - 1, nkb) - s - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragment reads of step s - 1 are done
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + NS - 1 < nkb) issue(ks0 + s + NS - 1, smem + ((s + NS - 1) & (NS - 1)) * STAGE);
+            compute(smem + (s & (NS - 1)) * STAGE);
+        }
+        // atom complete: its value joins the total, the chains start again from zero
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                floatx4 av;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (SPLIT)
+                        av[r] = wtk_split_value(acc[i][j][r], acc1[i][j][r]);
+                    else
+                        av[r] = acc[i][j][r];
+                }
+                tot[i][j] = first_atom ? av : tot[i][j] + av;
+                acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT) acc1[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            }
+        ++atom;
+        atom_end = min((int)((unsigned)((atom + 1) * a.nk) / (unsigned)a.NA) - ks0, nkb);
     }
 
     // ---- the tile: lane (pixel lr of tile j, group lg) owns couts cb .. cb + NV - 1
@@ -309,12 +345,7 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
 #pragma unroll
         for (int t = 0; t < TC; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (SPLIT)
-                    v[t * 4 + r] = wtk_split_value(acc[t][j][r], acc1[t][j][r]);
-                else
-                    v[t * 4 + r] = acc[t][j][r];
-            }
+            for (int r = 0; r < 4; ++r) v[t * 4 + r] = tot[t][j][r];
         if (a.S == 1) {
             sk_store<SPLIT, NV>(a, pix, cb, v, bias_r);
         } else {
@@ -475,47 +506,72 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned
     k.cpb = a.Cin * esz / 128;
     k.KW = a.KW, k.stride = a.stride, k.pad = a.pad;
     k.nk = (int)((long long)a.Kpad * esz / 128);
-    k.S = conv_sk_slices(k.nk);
+    k.NA = conv_sk_slices(k.nk);
+    k.S = k.NA;
     k.w = reinterpret_cast<const char *>(a.w), k.w_rowb = (unsigned)k.nk * 128u;
     k.bias = a.bias;
     k.Cout = a.Cout, k.CoutPad = a.CoutPad, k.act = a.act;
     k.out = a.out, k.out_ld = a.out_ld, k.out_coff = a.out_coff, k.out_f32 = a.out_f32;
     k.res = a.res, k.res_ld = a.res_ld, k.res_coff = a.res_coff;
     k.partial = partial;
-    // in-kernel combination while the slabs are small (a dependent launch costs ~4.7 us); big slabs (large batches) go through plain stores and
-    // the second launch: write-through stores of tens of megabytes cost more than the launch.  Same arithmetic either way.
-    static const long long inkernel_max = (long long)sk_env("WTK_SK_INKERNEL_MAX_KB", 4096) * 1024;
-    k.tickets = (long long)k.S * a.M * a.CoutPad * 4 <= inkernel_max ? tickets : nullptr;
+    k.tickets = nullptr; // decided with the form below
     k.M = a.M;
     k.n_dyn = a.n_dyn;
     k.d_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
     k.d_wo = make_fastdiv((unsigned)a.Wo);
     k.d_cpb = make_fastdiv((unsigned)k.cpb);
     k.d_cg = make_fastdiv((unsigned)(a.Cout / 8));
-    if (k.S > 1 && !partial) return hipErrorInvalidValue;
+    if (k.NA > 1 && !partial) return hipErrorInvalidValue;
     if ((k.in2 != nullptr) != (k.in2_blocks > 0) || k.in2_blocks > k.cpb) return hipErrorInvalidValue;
-    // Tile (it does not enter the arithmetic): the largest one whose blocks still cover the chip.  The two 128-pixel tiles (large batches) must give
-    // every CU a block; the 64-pixel tiles are for layers that cannot — there ONE round of blocks matters more than a full chip: a layer of 192 blocks
-    // of 64 x 64 is over in one latency-bound round, 384 blocks of 64 x 32 take a round and a half (model.7 at B = 1: 16 us against 9).
-    auto blocks = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * (long long)(a.CoutPad / bn) * k.S; };
-    const long long cus = (long long)num_cus;
+    // ---- form (S = 1: one block per tile walks every atom; S = NA: one block per atom + slab combination) and tile, per launch: neither enters the
+    // arithmetic (see the header).  A small cost model in microseconds, calibrated on profiles/r05_notes.md's forced-tile timelines: blocks run one per
+    // CU (96-128 KB of LDS) in rounds; a block costs a fixed latency chain, its operand bytes at what a CU's memory path delivers, and — split
+    // form — the hand-off (write-through slabs, ticket, slab reads) or the second launch.
+    const int force_tile = sk_env("WTK_SK_TILE", -1); // tuning switches: 0 128x128, 1 128x64, 2 64x64, 3 64x32 (where the couts allow)
+    const int force_form = sk_env("WTK_SK_FORM", -1); // 0: always S = NA, 1: always S = 1
+    static const long long inkernel_max = (long long)sk_env("WTK_SK_INKERNEL_MAX_KB", 4096) * 1024;
+    struct Cand {
+        int bm, bn, id;
+    };
+    const Cand cands[4] = {{128, 128, 0}, {128, 64, 1}, {64, 64, 2}, {64, 32, 3}};
+    const double cus = (double)num_cus;
+    double best_t = 1e30;
+    int best_tile = 3, best_S = k.NA;
+    for (const Cand &c : cands) {
+        if (a.CoutPad % c.bn) continue;
+        if (force_tile >= 0 && c.id != force_tile && !(a.CoutPad % cands[force_tile].bn)) continue;
+        for (int S : {1, k.NA}) {
+            if (force_form == 0 && S != k.NA) continue;
+            if (force_form == 1 && S != 1) continue;
+            const double tiles = (double)((a.M + c.bm - 1) / c.bm) * (a.CoutPad / c.bn);
+            const double blocks = tiles * S;
+            const double rounds = std::ceil(blocks / cus);
+            const double steps = std::ceil((double)k.nk / S);
+            const double stage_kb = (c.bm + c.bn) * 128.0 / 1024.0;
+            // (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU's four waves get ~40 KB/us of operands through their
+            // LDS-DMA requests whether the chip is full or not — the requests' issue cost, not the memory system, is the limit at one block per CU —;
+            // the in-kernel hand-off costs ~4 us + the combining block's slab reads at ~60 KB/us; a second launch ~4.7 us + the slabs through L2)
+            double t = rounds * (1.9 + steps * stage_kb / 40.0);
+            if (S > 1) {
+                const double slab_bytes = (double)S * a.M * a.CoutPad * 4.0;
+                const double tile_kb = c.bm * c.bn * 4.0 / 1024.0;
+                t += slab_bytes <= (double)inkernel_max ? 4.0 + S * tile_kb / 60.0 : 4.7 + 2.0 * slab_bytes / 3.0e6;
+            }
+            if (t < best_t) best_t = t, best_tile = c.id, best_S = S;
+            if (k.NA == 1) break;
+        }
+    }
+    k.S = best_S;
+    if (sk_env("WTK_SK_VERBOSE", 0))
+        std::fprintf(stderr, "conv_sk: M %lld cout %d nk %d atoms %d -> tile %d form S=%d (est %.1f us)\n", a.M, a.CoutPad, k.nk, k.NA, best_tile, best_S, best_t);
+    k.tickets = (k.S > 1 && (long long)k.S * a.M * a.CoutPad * 4 <= inkernel_max) ? tickets : nullptr;
     hipError_t e;
-    static const int force = sk_env("WTK_SK_TILE", -1); // tuning switch: 0 128x128, 1 128x64, 2 64x64, 3 64x32 wherever the couts allow it
-    if (force == 0 && a.CoutPad % 128 == 0)
-        return split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st);
-    if ((force == 0 || force == 1) && a.CoutPad % 64 == 0 && (k.S == 1 || k.tickets))
-        return split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st);
-    if ((force == 0 || force == 1 || force == 2) && a.CoutPad % 64 == 0 && (k.S == 1 || k.tickets))
-        return split ? sk_launch_t<true, 64, 64, 2, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 2, 2, 8>(k, st);
-    if (force >= 0 && (k.S == 1 || k.tickets)) return split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st);
-    if (a.CoutPad % 128 == 0 && blocks(128, 128) >= cus)
-        e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st);
-    else if (a.CoutPad % 64 == 0 && blocks(128, 64) >= cus)
-        e = split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st);
-    else if (a.CoutPad % 64 == 0 && (5 * blocks(64, 64) >= 3 * cus || a.CoutPad % 32 != 0))
-        e = split ? sk_launch_t<true, 64, 64, 2, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 2, 2, 8>(k, st);
-    else
-        e = split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st);
+    switch (best_tile) {
+    case 0: e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st); break;
+    case 1: e = split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st); break;
+    case 2: e = split ? sk_launch_t<true, 64, 64, 2, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 2, 2, 8>(k, st); break;
+    default: e = split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st); break;
+    }
     if (e != hipSuccess || k.S == 1 || k.tickets) return e;
     const long long threads = a.M * (a.Cout / 8);
     if (split)

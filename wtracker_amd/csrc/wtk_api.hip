@@ -553,7 +553,7 @@ struct wtk_yolo {
     int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
     int num_cus = 0;
     // Latency plan (small batches: the reference's own operating point, one B = cycle_frame_num call and one B = 1 call per cycle,
-    // yolo_controller.py:96-98,108-109).  Chosen when the handle is created — max_batch <= 16 and a reference-precision dtype, or WTK_LATENCY_PLAN=0/1 —
+    // yolo_controller.py:96-98,108-109).  Chosen when the handle is created — max_batch <= 4 and a reference-precision dtype, WTK_LATENCY_PLAN=0/1, or the caller's word (wtk_yolo_create_planned) —
     // and NOT per call: every conv behind the fused front then runs on conv_sk_kernel whatever the batch of the call, so a frame's logits do not
     // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
     int latency = 0;
@@ -981,10 +981,18 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
         HIP_TRY(hipGetDeviceProperties(&prop, d->device));
         h->num_cus = prop.multiProcessorCount;
     }
-    h->latency = d->max_batch <= 16 && !h->is_f16;
+    h->latency = d->max_batch <= 4 && !h->is_f16;
     if (const char *e = std::getenv("WTK_LATENCY_PLAN")) h->latency = e[0] == '1' && !h->is_f16;
     if (plan != WTK_PLAN_AUTO) h->latency = plan == WTK_PLAN_LATENCY; // the caller's word beats the rule and the environment
-    if (h->latency) h->use_tail = 0, h->graph_views = 1; // replayed captures: ~100 launches of a few microseconds each are host bound when launched one by one
+    // Replayed captures on this plan (caller buffers included: an argument set is captured the second time it is met): 0.53 ms against 0.57 ms of eager
+    // launches at B = 1 — unless the process asked the runtime for more than its four default hardware queues: a capture that forks into the side streams
+    // then ran 2-4 x SLOWER for the second and third handle of the process (profiles/r05_notes.md section 4), so such a process (bench.py's throughput
+    // lanes need the eight queues) launches eagerly.  WTK_GRAPH_VIEWS=0 / 1 decides explicitly.
+    if (h->latency) {
+        const char *q = std::getenv("GPU_MAX_HW_QUEUES");
+        h->graph_views = !(q && std::atoi(q) > 4);
+    }
+    if (h->latency) h->use_tail = 0;
     if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
     if (const char *e = std::getenv("WTK_GRAPH_VIEWS")) h->graph_views = e[0] == '1';
 
@@ -1847,9 +1855,9 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     // Only for the handle's own staging buffers (the *_host entry points): their addresses never change, so
     // one capture per (B, H, W, C, conf) is replayed forever; arbitrary caller buffers would thrash the cache.
     const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
-    // A latency-plan handle (~100 short launches) also replays for caller buffers: an argument set is captured the second time it is met, so a caller
+    // With WTK_GRAPH_VIEWS=1 a latency-plan handle also replays for caller buffers: an argument set is captured the second time it is met, so a caller
     // that rotates its buffers never pays for a capture.
-    const bool use_graph = (own_buffers || h->latency) && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
+    const bool use_graph = (own_buffers || (h->latency && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
     if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
     wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
     if (!own_buffers) {

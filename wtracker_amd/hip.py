@@ -109,6 +109,26 @@ def request_hw_queues(n: int = 8) -> bool:
     return True
 
 
+_warned_queues = False
+
+
+def warn_if_streams_exceed_hw_queues(n_busy_streams: int) -> bool:
+    """One warning per process when a caller is about to keep more streams busy than the HIP runtime has hardware queues by default (4) and
+    GPU_MAX_HW_QUEUES was not set: streams that share a queue serialise (-3 % for the bench's five streams, up to -40 % for unlucky layouts,
+    profiles/r02_notes.md section 8).  `request_hw_queues()` before the first HIP call is the fix; it is opt-in because child processes inherit the
+    variable.  Returns True when the warning was issued."""
+    global _warned_queues
+    if _warned_queues or n_busy_streams <= 4 or "GPU_MAX_HW_QUEUES" in os.environ:
+        return False
+    import warnings
+
+    _warned_queues = True
+    warnings.warn(f"wtracker_amd: {n_busy_streams} HIP streams will be busy at once but GPU_MAX_HW_QUEUES is unset (runtime default: 4 hardware queues; streams that "
+                  "share one serialise).  Call wtracker_amd.hip.request_hw_queues() before the first HIP call of the process, or export GPU_MAX_HW_QUEUES=8.",
+                  RuntimeWarning, stacklevel=3)
+    return True
+
+
 def load() -> C.CDLL:
     """Load libwtk_hip.so (built in-tree by `python -m wtracker_amd._build` / __graft_entry__.build())."""
     global _lib
@@ -135,7 +155,8 @@ def load() -> C.CDLL:
     lib.wtk_yolo_create.argtypes = [C.POINTER(vp), C.POINTER(_YoloDesc)]
     lib.wtk_yolo_create_planned.argtypes = [C.POINTER(vp), C.POINTER(_YoloDesc), i32]
     lib.wtk_yolo_plan.argtypes = [vp]
-    lib.wtk_yolo_status.argtypes = [vp, C.POINTER(i32), i32]
+    if hasattr(lib, "wtk_yolo_status") or not os.environ.get("WTK_HIP_LIB"):  # (an older build named by WTK_HIP_LIB for an A/B timing may lack it)
+        lib.wtk_yolo_status.argtypes = [vp, C.POINTER(i32), i32]
     lib.wtk_yolo_destroy.argtypes = [vp]
     lib.wtk_yolo_destroy.restype = None
     lib.wtk_yolo_predict.argtypes = [vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp]
@@ -406,7 +427,7 @@ class HipYolo:
 
     def __init__(self, weights: dict, imgsz: tuple[int, int], max_batch: int, dtype: str = "fp16", nc: int = 1,
                  width: float = 0.5, depth: float = 0.33, max_channels: int = 1024, device: int = 0, plan: str = "auto"):
-        """plan: "auto" (latency when max_batch <= 16 and the dtype is fp32 / f16x3, else throughput; WTK_LATENCY_PLAN=0/1 overrides), "throughput" or
+        """plan: "auto" (latency when max_batch <= 4 and the dtype is fp32 / f16x3, else throughput; WTK_LATENCY_PLAN=0/1 overrides), "throughput" or
         "latency" (include/wtk_hip.h: wtk_yolo_create_planned) — fixed for the handle's life, so a frame's result does not depend on the batch it is in."""
         lib = load()
         if plan not in PLANS:

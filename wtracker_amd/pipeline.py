@@ -93,6 +93,8 @@ class TrackPipeline:
         # out pooled streams round-robin, and which hardware queue a stream sits on changes what runs concurrently with what)
         if streams is not None and len(streams) != n_lanes:
             raise ValueError("one stream per lane")
+        if self._cuda and n_lanes > 1:  # lanes + the process-wide pair of side streams + the caller's default stream
+            hip.warn_if_streams_exceed_hw_queues(n_lanes + 2 + 1)
         self.streams = list(streams) if streams is not None else ([torch.cuda.Stream(device=self.device) for _ in range(n_lanes)] if n_lanes > 1 and self._cuda else [None] * n_lanes)
         # A lane whose detector holds rows back (HybridDetector(defer = D): the weak rows of D calls share one full-precision pass) hands out
         # rows that are FINAL only after its next flush.  Everything downstream of the rows — the exchange between ranks and the ResMLP —
