@@ -53,7 +53,8 @@ if ROOT not in sys.path:
 # (`--backend gloo`, every rank on cuda:0) keeps the runtime default: there the processes share a device and their queues add up (19.5 k -> 4.9 k).
 _pre = argparse.ArgumentParser(add_help=False)
 _pre.add_argument("--backend", default="nccl")
-if _pre.parse_known_args()[0].backend == "nccl":
+_pre.add_argument("--legs-child", action="store_true")  # (the small-batch legs' child process keeps the runtime default: a controller user's environment)
+if _pre.parse_known_args()[0].backend == "nccl" and not _pre.parse_known_args()[0].legs_child:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
@@ -148,7 +149,7 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     from wtracker_amd.controllers import HipYoloController, YoloConfig
     from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger
 
-    size, cycles = 1024, 10
+    size, cycles = 1024, 30
     ec = ExperimentConfig("closed_loop", cycles * 15 + 1, 60, (size, size), 90, (size // 2, size // 2))
     frames_np, _ = fr.synthetic_frames(ec.num_frames, size, seed=77)
     dev_frames = torch.from_numpy(frames_np).to(torch.device("cuda", device))
@@ -180,15 +181,25 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
             return m
 
         ctrl.provide_movement_vector = wrapped
+        ends = []  # wall clock at every cycle end: the steady state is the MEDIAN cycle (a run of 30 cycles holds the controller's first calls — new
+        oce = ctrl.on_cycle_end  # buffers, captures — and the odd host hiccup of tens of milliseconds, which a real run of thousands of cycles does not see)
+
+        def cycle_end(sim):
+            oce(sim)
+            ends.append(time.perf_counter())
+
+        ctrl.on_cycle_end = cycle_end
         log = TrackLogger(ctrl)
         t0 = time.perf_counter()
         Simulator(tc, ec, log, reader=ArrayReader(frames_np)).run()
         dt = time.perf_counter() - t0
         med = lambda v: float(np.median(v) * 1e3) if len(v) else None
-        return {"seconds": dt, "frames_per_s": ec.num_frames / dt, "ms_per_cycle": dt / cycles * 1e3, "ms_cycle_batch_call_B15": med(calls[15][1:] or calls[15]),
+        cyc = np.diff(np.array(ends)) if len(ends) > 2 else np.array([dt / cycles])
+        return {"seconds": dt, "frames_per_s": 15.0 / float(np.median(cyc)), "ms_per_cycle": float(np.median(cyc)) * 1e3, "ms_per_cycle_p90": float(np.quantile(cyc, 0.9)) * 1e3,
+                "frames_per_s_whole_run": ec.num_frames / dt, "ms_cycle_batch_call_B15": med(calls[15][1:] or calls[15]),
                 "ms_single_frame_call_B1": med(calls[1][1:] or calls[1]), "calls_B15": len(calls[15]), "calls_B1": len(calls[1])}, moves, log.rows
 
-    out = {"what": "closed loop through the controller API at the reference's operating point; host-inclusive wall time of Simulator.run (tests/harness)",
+    out = {"what": "closed loop through the controller API at the reference's operating point; host-inclusive wall time under tests/harness' Simulator.run; frames_per_s = 15 / the median cycle",
            "frames": f"{ec.num_frames} synthetic {size}x{size} uint8 gray frames resident in HBM, camera view 360x360 -> imgsz 384, conf {conf}",
            "timing_ms": [200, 40, 50], "cycle_frames": 15, "cycles": cycles, "calls_per_cycle": "one B=15 _cycle_predict_all + one B=1 provide_movement_vector"}
     ref_moves = None
@@ -408,6 +419,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="measure the headline mode only (no per-mode sub-objects)")
     ap.add_argument("--no-hybrid", action="store_true", help="skip the hybrid sub-object (and its calibration pass)")
     ap.add_argument("--no-check", action="store_true", help="skip headline_check (profiling passes: nothing but the timed workload's kernels in the trace)")
+    ap.add_argument("--legs-child", action="store_true", help=argparse.SUPPRESS)  # internal: run closed_loop / latency_leg and print them as one JSON line
     ap.add_argument("--no-latency", action="store_true", help="skip the latency sub-object (B = 1 / 15 at 384^2, B = 1 at 640^2: the reference's calls and BASELINE config 2)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed_loop sub-object (the reference's real operating point: 360 -> 384 views, 15-frame cycles)")
     ap.add_argument("--conf", type=float, default=0.1)
@@ -430,6 +442,18 @@ def main():
     from wtracker_amd import _build, hip, metrics, resmlp
     from wtracker_amd import frames as fr
     from wtracker_amd import yolo_spec as ys
+
+    if args.legs_child:
+        if not os.environ.get("WTK_HIP_LIB"):
+            _build.ensure_built(verbose=False)
+        w = ys.synthetic_weights("s", 1, seed=0)
+        legs = {}
+        if not args.no_closed_loop:
+            legs["closed_loop"] = closed_loop(w, "s", 1, local_rank, args.conf)
+        if not args.no_latency:
+            legs["latency"] = latency_leg(w, "s", 1, local_rank, args.conf)
+        print(json.dumps(_finite(legs), allow_nan=False), flush=True)
+        return
 
     # The library is (re)built BEFORE any rendezvous, serialised over the ranks of the node by a file lock (_build.ensure_built): a
     # stale or missing .so is compiled by the first rank through the lock, a compiler error makes every rank exit non-zero, and
@@ -748,12 +772,25 @@ def main():
     else:  # no CPU leg: the device-side check alone (fp32 IS the reference's arithmetic; --no-check: nothing was verified)
         verified = bool(head_check and head_check["verified"]) if head_dtype != "fp32" else True
 
-    closed = None
-    if world == 1 and not args.no_closed_loop and not args.no_fp32:
-        closed = closed_loop(weights, scale, nc, local_rank, args.conf)
-    lat = None
-    if world == 1 and not args.no_latency and not args.no_fp32 and args.size == 640:
-        lat = latency_leg(weights, scale, nc, local_rank, args.conf)
+    # The two small-batch legs run in a CHILD process with the environment a controller user has: this process asked the HIP runtime for eight hardware
+    # queues (its two throughput lanes need them) and has created and destroyed a dozen handles and their streams by now — both change what a chain of
+    # ~60 short dependent launches costs (profiles/r05_notes.md section 4: the same call 0.53 ms in a fresh process, 1-2 ms here).
+    closed = lat = None
+    want_closed = world == 1 and not args.no_closed_loop and not args.no_fp32
+    want_lat = world == 1 and not args.no_latency and not args.no_fp32 and args.size == 640
+    if want_closed or want_lat:
+        import subprocess
+
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        cmd = [sys.executable, os.path.abspath(__file__), "--legs-child", "--conf", str(args.conf)] + ([] if want_closed else ["--no-closed-loop"]) + ([] if want_lat else ["--no-latency"])
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            legs = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-800:]}
+        except Exception as e:  # the headline must not depend on a side leg
+            legs = {"error": repr(e)}
+        closed, lat = legs.get("closed_loop"), legs.get("latency")
+        if "error" in legs:
+            closed = {"error": legs["error"]}
 
     out = {
         "metric": f"frames/sec YOLOv8s+ResMLP sim loop @{args.size}x{args.size}",
@@ -786,7 +823,8 @@ def main():
     out["end_to_end"] = head["end_to_end"]
     if closed is not None:
         out["closed_loop"] = closed
-        out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_auto"]["frames_per_s"]
+        if "f16x3_auto" in closed:
+            out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_auto"]["frames_per_s"]
     if lat is not None:
         out["latency"] = lat
         for r in lat["rows"]:  # two scalars per reference-precision mode in the main line: the reference's two calls

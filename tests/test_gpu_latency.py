@@ -300,3 +300,39 @@ def test_controller_raises_on_overflow(hip_lib, tmp_path):
         ctrl.predict(frames)
     ok = HipYoloController(tc, YoloConfig(model_path=path, pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="fp32", max_batch=4))
     assert ok.predict(frames).shape == (2, 4)
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_small_throughput_handle_runs_its_smallest_maps_on_the_split_k_kernel(hip_lib, dtype, monkeypatch):
+    """A throughput-plan handle of max_batch <= 16 (the controller's cycle batch: 9 / 15 frames at imgsz 384) runs the layers whose whole batch is at most
+    4 096 output pixels — the 12 x 12 maps — on conv_sk_kernel (csrc/wtk_api.hip: sk_mixed).  Same bars as every reference-precision path: logits 2e-3,
+    boxes 2e-2 px, survivors equal to the restatement's; a frame's logits do not depend on its batch; and the plain throughput handle
+    (WTK_NO_SK_MIXED=1) picks the same survivors."""
+    size, B = 384, 15
+    depth, width, maxch = ys.SCALES["s"]
+    w = ys.synthetic_weights("s", 1, seed=0)
+    oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
+    mk = lambda: hip.HipYolo(w, (size, size), 16, dtype=dtype, width=width, depth=depth, max_channels=maxch, plan="throughput")
+    monkeypatch.setenv("WTK_NO_SK_MIXED", "1")
+    plain = mk()
+    monkeypatch.delenv("WTK_NO_SK_MIXED")
+    mixed = mk()
+    assert mixed.plan == plain.plan == "throughput"
+    frames = fr.diverse_frames(16, size, seed=808)[:B]
+    box_o, cls_o, (xywh_o, conf_o, anchor_o) = _oracle(oracle, frames, size)
+    xm, cm, am = mixed.predict_host(frames, conf=0.1)
+    bm, km = mixed.debug_head(B)
+    np.testing.assert_allclose(km, cls_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(bm, box_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_array_equal(am, anchor_o)
+    np.testing.assert_allclose(xm, xywh_o, rtol=0, atol=BOX_ATOL)
+    xp, cp, ap = plain.predict_host(frames, conf=0.1)
+    bp, kp = plain.debug_head(B)
+    np.testing.assert_array_equal(ap, am)
+    assert not np.array_equal(kp, km)  # the two really are different kernels on some layers (K summed in another order)
+    np.testing.assert_allclose(kp, km, rtol=1e-3, atol=LOGIT_ATOL)
+    x1, c1, a1 = mixed.predict_host(frames[6:7], conf=0.1)
+    b1, k1 = mixed.debug_head(1)
+    np.testing.assert_array_equal(k1, km[6:7])
+    np.testing.assert_array_equal(b1, bm[6:7])
+    plain.close(), mixed.close()

@@ -378,7 +378,9 @@ class _YoloModel:
             if det is not None:
                 det.close()
             width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
-            cap = max(batch, 16 if plan == "latency" else self.cfg.max_batch)
+            # a handle for the reference's own calls (<= 16 frames) is sized for 16: the library then runs the 12 x 12-map layers of such a handle on
+            # its split-K kernel whatever the plan (csrc/wtk_api.hip: sk_mixed)
+            cap = 16 if batch <= 16 else max(batch, self.cfg.max_batch)
             det = hip.HipYolo(self.weights, net_hw, cap, dtype=dtype, nc=self.nc, width=width, depth=depth, max_channels=maxch,
                               device=self.cfg.device_index(), plan=plan)
             self._dets[key] = det

@@ -569,7 +569,7 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned
     switch (best_tile) {
     case 0: e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st); break;
     case 1: e = split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st); break;
-    case 2: e = split ? sk_launch_t<true, 64, 64, 2, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 2, 2, 8>(k, st); break;
+    case 2: e = split ? sk_launch_t<true, 64, 64, 4, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 4, 2, 8>(k, st); break;
     default: e = split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st); break;
     }
     if (e != hipSuccess || k.S == 1 || k.tickets) return e;

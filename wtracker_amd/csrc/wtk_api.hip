@@ -1193,11 +1193,20 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     }
     h->anchors = h8 * w8 + h16 * w16 + h32 * w32;
     for (const Op &op : h->ops) h->macs_per_frame += op.macs_per_image;
-    if (h->latency) { // which convs the split-K kernel takes (everything with rows of 32 input channels), and their slab scratch
+    // Which convs the split-K kernel (conv_sk.hip) takes, and their slab scratch.  Latency plan: everything with rows of 32 input channels.
+    // Throughput plan of a SMALL handle (max_batch <= 16, fp32 / f16x3: what a controller's cycle batch of 9 / 15 frames runs on, yolo_controller.py:108-109):
+    // the layers whose whole batch is at most 4 096 output pixels — the 12 x 12 maps of imgsz 384 — where the window / implicit-GEMM kernels run ~40-block
+    // grids that walk K serially (model.8's bottlenecks 40 us, split over K 24 us: profiles/r05_notes.md section 5); the choice is fixed per handle, so a
+    // frame's result still does not depend on its batch.  WTK_NO_SK_MIXED=1 switches the second rule off (A/B).
+    const bool sk_mixed = !h->latency && !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_NO_SK_MIXED") && std::getenv("WTK_NO_SK_MIXED")[0] == '1');
+    const long long sk_mixed_max_px = std::getenv("WTK_SK_MIXED_MAX_PX") ? std::atoll(std::getenv("WTK_SK_MIXED_MAX_PX")) : 10000; // (tuning switch)
+    if (h->latency || sk_mixed) {
         for (size_t i = 3; i < h->ops.size(); ++i) { // ops[0..2] stay the fused front's
             Op &op = h->ops[i];
             if (op.kind != OP_CONV || op.folded || op.tail_op >= 0 || op.out2_buf >= 0 || op.cin % 32 || (op.k != 1 && op.k != 3) || op.cout_pad % 32 || op.cout % 8) continue;
             if (op.in2_buf >= 0 && (op.k != 1 || op.in2_split % 32)) continue;
+            if (sk_mixed && (long long)h->max_batch * h->bufs[op.out_buf].h * h->bufs[op.out_buf].w > sk_mixed_max_px) continue;
+            if (sk_mixed && h->use_c2f && i <= 5) continue; // (model.2's fused tail: never this small, but the indices must stay its own)
             op.sk = 1;
             const int S = conv_sk_slices(op.k * op.k * op.cin / 32);
             const Buf &ob = h->bufs[op.out_buf];
