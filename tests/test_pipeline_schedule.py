@@ -168,3 +168,45 @@ def test_warning_when_more_streams_than_default_hardware_queues(monkeypatch):
     monkeypatch.setattr(hip, "_warned_queues", False)
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     assert hip.warn_if_streams_exceed_hw_queues(5) is False
+
+
+def test_controller_picks_the_plan_by_call_size(monkeypatch, tmp_path):
+    """HipYoloController's handle selection (no GPU: hip.HipYolo is replaced by a recorder).  plan "auto": the reference's single-frame call
+    (provide_movement_vector, yolo_controller.py:96-98) -> a latency-plan handle, its cycle batch (_cycle_predict_all, :108-109) -> a throughput-plan
+    handle, both sized for 16 frames; larger batches -> a throughput handle of YoloConfig.max_batch; fp16 never gets the latency plan; explicit plans keep
+    every call of up to 16 frames on ONE handle."""
+    import numpy as np
+
+    from wtracker_amd import controllers, hip
+    from wtracker_amd import yolo_spec as ys
+
+    made = []
+
+    class FakeYolo:
+        def __init__(self, weights, imgsz, max_batch, dtype="fp16", plan="auto", **kw):
+            self.max_batch, self.dtype, self.plan = max_batch, dtype, plan
+            made.append((imgsz, max_batch, dtype, plan))
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(hip, "HipYolo", FakeYolo)
+    monkeypatch.delenv("WTK_LATENCY_PLAN", raising=False)
+    path = str(tmp_path / "w.wtk")
+    ys.save_weights(path, ys.synthetic_weights("n", 1, seed=0), "n", 1)
+    mk = lambda **kw: controllers.YoloConfig(model_path=path, scale="n", **kw).load_model()
+    m = mk(dtype="f16x3")
+    a, b, c = m.detector((384, 384), 1), m.detector((384, 384), 15), m.detector((384, 384), 4)
+    assert (a.plan, a.max_batch) == ("latency", 16) and (b.plan, b.max_batch) == ("throughput", 16) and c is a and m.detector((384, 384), 9) is b
+    big = m.detector((384, 384), 40)
+    assert (big.plan, big.max_batch) == ("throughput", 64) and big is not b
+    m = mk(dtype="fp16")
+    assert m.detector((384, 384), 1).plan == "throughput"
+    m = mk(dtype="fp32", plan="latency")
+    one = m.detector((384, 384), 1)
+    assert one.plan == "latency" and m.detector((384, 384), 15) is one
+    m = mk(dtype="fp32", plan="throughput")
+    one = m.detector((384, 384), 15)
+    assert one.plan == "throughput" and m.detector((384, 384), 1) is one
+    monkeypatch.setenv("WTK_LATENCY_PLAN", "0")  # the variable turns AUTO's latency choice off
+    assert mk(dtype="f16x3").detector((384, 384), 1).plan == "throughput"

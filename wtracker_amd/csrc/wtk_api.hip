@@ -557,7 +557,8 @@ struct wtk_yolo {
     // and NOT per call: every conv behind the fused front then runs on conv_sk_kernel whatever the batch of the call, so a frame's logits do not
     // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
     int latency = 0;
-    int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status)
+    int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status); a slot of the process-wide page
+    int *status_dev = nullptr;  // ... and the device's address of the same word
     int status_static = 0;      // flags fixed at create time (none today)
     int profiling = 0;
     // kernel ids of the profile: 0 stem, 1 conv_igemm, 2 pool, 3 head, 4 conv3x3_halo (+ fused tails), 5 fused front / C2f tail,
@@ -895,6 +896,38 @@ struct Planner {
 };
 } // namespace
 
+// Status words live in ONE pinned, device-mapped page per process, handed out by slot and never freed (a handle is a few hundred allocations already; pinning
+// and unpinning host memory per handle — hundreds of times in a test run — is a driver operation that has no business on that path).
+namespace {
+std::mutex g_status_mu;
+int *g_status_page = nullptr, *g_status_page_dev = nullptr;
+std::vector<int> g_status_free;
+constexpr int kStatusSlots = 4096;
+int acquire_status_word(int **host, int **dev) {
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    if (!g_status_page) {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, kStatusSlots * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return 1;
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            (void)hipHostFree(hp);
+            return 1;
+        }
+        g_status_page = reinterpret_cast<int *>(hp), g_status_page_dev = reinterpret_cast<int *>(dp);
+        for (int i = kStatusSlots - 1; i >= 0; --i) g_status_free.push_back(i);
+    }
+    if (g_status_free.empty()) return 1;
+    const int slot = g_status_free.back();
+    g_status_free.pop_back();
+    g_status_page[slot] = 0;
+    *host = g_status_page + slot, *dev = g_status_page_dev + slot;
+    return 0;
+}
+void release_status_word(int *host, int *) {
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    if (g_status_page && host >= g_status_page && host < g_status_page + kStatusSlots) g_status_free.push_back((int)(host - g_status_page));
+}
+} // namespace
+
 extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     if (!h) return;
     DeviceGuard guard(h->device); // the synchronise and the releases below are about the HANDLE's device, whatever the caller's current device is
@@ -905,7 +938,7 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     (void)hipFree(h->nms_score);
     (void)hipFree(h->nms_box);
     (void)hipFree(h->nms_cls);
-    if (h->status_host) (void)hipHostFree(h->status_host);
+    if (h->status_host) release_status_word(h->status_host, h->status_dev);
     for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; ++i)
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
@@ -1264,12 +1297,11 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
         wtk_yolo_destroy(h);
         return 1;
     }
-    if (hipHostMalloc((void **)&h->status_host, 64, hipHostMallocMapped) != hipSuccess) {
+    if (acquire_status_word(&h->status_host, &h->status_dev)) {
         h->status_host = nullptr;
         wtk_yolo_destroy(h);
-        return fail("wtk_yolo_create: hipHostMalloc failed");
+        return fail("wtk_yolo_create: no pinned status word (hipHostMalloc failed, or more than 4096 live handles)");
     }
-    *h->status_host = 0;
     if (dev_alloc(h, &h->zero_page, 256)) {
         wtk_yolo_destroy(h);
         return 1;
@@ -1372,11 +1404,7 @@ static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xyw
     a.out_conf = out_conf;
     a.out_anchor = out_anchor;
     a.out_margin = h->o_margin;
-    a.status = nullptr;
-    if (h->status_host) {
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, h->status_host, 0) == hipSuccess) a.status = reinterpret_cast<int *>(dp);
-    }
+    a.status = h->status_dev;
     a.conf_logit = conf > 0.f && conf < 1.f ? std::log(conf / (1.f - conf)) : (conf <= 0.f ? -INFINITY : INFINITY);
     if (nms) {
         NmsArgs q;
