@@ -319,8 +319,9 @@ def emit(detail: dict) -> str:
 
 def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     """The reference's two detector calls per cycle — one batch of cycle_frame_num = 15 frames and ONE frame (yolo_controller.py:96-98,108-109), imgsz 384
-    (initialize_experiment.ipynb cell 9) — and BASELINE config 2 (640 x 640, B = 1), on a latency-plan handle (wtk_yolo_create_planned: split-K convs +
-    replayed hipGraph) and, beside it, on a throughput-plan handle of the same model.  Per shape:
+    (initialize_experiment.ipynb cell 9) — and BASELINE config 2 (640 x 640, B = 1), on handles of max_batch 16 of three kinds: latency plan
+    (wtk_yolo_create_planned: every conv on the split-K kernel), throughput plan (such a small handle runs its maps of <= 10 000 pixels on the split-K
+    kernel too) and the large-batch kernels alone (what every call ran on before round 5).  Per shape:
       device_ms  HIP events on the call's stream around 40 back-to-back calls / 40 (frames resident in HBM: what the device needs per call)
       host_ms    median wall time of one call + stream synchronisation seen from the host (launch / replay cost included, no PCIe traffic)
       pcie_ms    median of wtk_yolo_predict_host: upload of the frames, the call, download of the rows (what a host-frame controller call costs)."""
@@ -333,9 +334,16 @@ def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     st = torch.cuda.Stream(device=dev)
     rows = []
     for dtype in ("f16x3", "fp32"):
-        for plan in ("latency", "throughput"):
+        # "large_batch_kernels" = the throughput plan WITHOUT the small-map rule of small handles (WTK_NO_SK_MIXED=1): what every call ran on before round 5
+        for plan in ("latency", "throughput", "large_batch_kernels"):
             for size, B in ((384, 1), (384, 15), (640, 1)):
-                det = hip.HipYolo(weights, (size, size), 16, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=device, plan=plan)
+                prev = os.environ.get("WTK_NO_SK_MIXED")
+                if plan == "large_batch_kernels":
+                    os.environ["WTK_NO_SK_MIXED"] = "1"
+                det = hip.HipYolo(weights, (size, size), 16, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=device,
+                                  plan="throughput" if plan == "large_batch_kernels" else plan)
+                if plan == "large_batch_kernels":
+                    os.environ.pop("WTK_NO_SK_MIXED") if prev is None else os.environ.__setitem__("WTK_NO_SK_MIXED", prev)
                 f_np = fr.diverse_frames(16, size, seed=4242)[:B]
                 f = torch.from_numpy(f_np).to(dev)
                 x = torch.empty((B, 4), dtype=torch.float32, device=dev)
@@ -365,7 +373,7 @@ def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
                     det.predict_host(f_np, conf=conf)
                     pcie.append(time.perf_counter() - t0)
                 gflop = 2.0 * det.macs_per_frame * B / 1e9
-                rows.append({"dtype": dtype, "plan": det.plan, "size": size, "batch": B, "device_ms": device_ms, "host_ms": float(np.median(host)) * 1e3,
+                rows.append({"dtype": dtype, "plan": plan, "size": size, "batch": B, "device_ms": device_ms, "host_ms": float(np.median(host)) * 1e3,
                              "pcie_ms": float(np.median(pcie[3:])) * 1e3, "gflop": gflop, "achieved_tflops": gflop / device_ms, "frac_of_peak": gflop / device_ms / PEAK_TFLOPS[dtype]})
                 det.close()
     return {"what": latency_leg.__doc__.split("Per shape:")[0].strip().replace("\n", " "), "rows": rows}
