@@ -336,3 +336,20 @@ def test_small_throughput_handle_runs_its_smallest_maps_on_the_split_k_kernel(hi
     np.testing.assert_array_equal(k1, km[6:7])
     np.testing.assert_array_equal(b1, bm[6:7])
     plain.close(), mixed.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_latency_plan_with_a_stock_80_class_head(hip_lib, dtype):
+    """nc = 80 (a stock YOLOv8 head): the class towers' last 1x1 stores 80 of 96 padded couts, the class logits are [A, 80] fp32 rows."""
+    size, B, nc = 128, 2, 80
+    _, det, oracle = _handle(size, dtype, max_batch=4, nc=nc)
+    frames = fr.diverse_frames(4, size, seed=17)[:B]
+    box_o, cls_o, (xywh_o, conf_o, anchor_o) = _oracle(oracle, frames, size)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+    box_g, cls_g = det.debug_head(B)
+    assert cls_g.shape == cls_o.shape == (B, det.anchors, nc)
+    np.testing.assert_allclose(cls_g, cls_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(box_g, box_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=BOX_ATOL)
+    det.close()

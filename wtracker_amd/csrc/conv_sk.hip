@@ -154,6 +154,8 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(BM % RPP == 0 && BN % RPP == 0 && TP >= 1 && TC >= 2 && NV % 8 == 0, "tile shape");
     static_assert((NS & (NS - 1)) == 0 && NS >= 2 && NS <= 8 && NS * STAGE <= 160 * 1024, "ring");
+    // the slab hand-off below is the form MI355X_MICROARCH.md measured for ONE workgroup per CU: more than half of the LDS per block guarantees it
+    static_assert(NS * STAGE > 80 * 1024, "one block per CU");
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
     const int tid = threadIdx.x;
@@ -548,14 +550,16 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned
             const double rounds = std::ceil(blocks / cus);
             const double steps = std::ceil((double)k.nk / S);
             const double stage_kb = (c.bm + c.bn) * 128.0 / 1024.0;
-            // (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU's four waves get ~40 KB/us of operands through their
-            // LDS-DMA requests whether the chip is full or not — the requests' issue cost, not the memory system, is the limit at one block per CU —;
-            // the in-kernel hand-off costs ~4 us + the combining block's slab reads at ~60 KB/us; a second launch ~4.7 us + the slabs through L2)
-            double t = rounds * (1.9 + steps * stage_kb / 40.0);
+            // (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU gets ~40 KB/us of operands through its LDS-DMA requests
+            // whether the chip is full or not, and with one block per CU nothing overlaps the multiply that follows — 16 cycles per v_mfma_f32_16x16x32_f16,
+            // three per tile pair in split mode, eight 32-cycle v_mfma_f32_16x16x4_f32 in fp32 mode, four SIMDs, ~2.2 GHz —; the in-kernel hand-off costs
+            // ~4 us + the combining block's slab reads at ~60 KB/us; a second launch ~3 us + the slabs at ~5 MB/us)
+            const double mfma_us = (c.bm / 16) * (c.bn / 16) * (split ? 3.0 * 16.0 : 8.0 * 32.0) / 4.0 / 2200.0;
+            double t = rounds * (1.9 + steps * (stage_kb / 40.0 + mfma_us));
             if (S > 1) {
                 const double slab_bytes = (double)S * a.M * a.CoutPad * 4.0;
                 const double tile_kb = c.bm * c.bn * 4.0 / 1024.0;
-                t += slab_bytes <= (double)inkernel_max ? 4.0 + S * tile_kb / 60.0 : 4.7 + 2.0 * slab_bytes / 3.0e6;
+                t += slab_bytes <= (double)inkernel_max ? 4.0 + S * tile_kb / 60.0 : 3.0 + slab_bytes / 5.0e6;
             }
             if (t < best_t) best_t = t, best_tile = c.id, best_S = S;
             if (k.NA == 1) break;

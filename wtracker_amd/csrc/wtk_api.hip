@@ -1239,7 +1239,6 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
             if (op.kind != OP_CONV || op.folded || op.tail_op >= 0 || op.out2_buf >= 0 || op.cin % 32 || (op.k != 1 && op.k != 3) || op.cout_pad % 32 || op.cout % 8) continue;
             if (op.in2_buf >= 0 && (op.k != 1 || op.in2_split % 32)) continue;
             if (sk_mixed && (long long)h->max_batch * h->bufs[op.out_buf].h * h->bufs[op.out_buf].w > sk_mixed_max_px) continue;
-            if (sk_mixed && h->use_c2f && i <= 5) continue; // (model.2's fused tail: never this small, but the indices must stay its own)
             op.sk = 1;
             const int S = conv_sk_slices(op.k * op.k * op.cin / 32);
             const Buf &ob = h->bufs[op.out_buf];
