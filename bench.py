@@ -320,8 +320,8 @@ def emit(detail: dict) -> str:
 def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     """The reference's two detector calls per cycle — one batch of cycle_frame_num = 15 frames and ONE frame (yolo_controller.py:96-98,108-109), imgsz 384
     (initialize_experiment.ipynb cell 9) — and BASELINE config 2 (640 x 640, B = 1), on handles of max_batch 16 of three kinds: latency plan
-    (wtk_yolo_create_planned: every conv on the split-K kernel), throughput plan (such a small handle runs its maps of <= 10 000 pixels on the split-K
-    kernel too) and the large-batch kernels alone (what every call ran on before round 5).  Per shape:
+    (wtk_yolo_create_planned: every conv on the split-K kernel), throughput plan (such a small handle runs its maps of <= 4 096 pixels — the 12 x 12 maps — on the
+    split-K kernel and the under-filled window layers on 64-cout tiles) and the large-batch kernels alone (what every call ran on before round 5).  Per shape:
       device_ms  HIP events on the call's stream around 40 back-to-back calls / 40 (frames resident in HBM: what the device needs per call)
       host_ms    median wall time of one call + stream synchronisation seen from the host (launch / replay cost included, no PCIe traffic)
       pcie_ms    median of wtk_yolo_predict_host: upload of the frames, the call, download of the rows (what a host-frame controller call costs)."""

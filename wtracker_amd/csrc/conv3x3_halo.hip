@@ -1841,7 +1841,7 @@ int split_halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 
 
 // Every channel count / offset of `a` but Cout / CoutPad in pseudo-channels (2 x real); three weight slabs, one tile per block
 hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
-    const int bn = split_halo_cout_tile(a.Cout);
+    const int bn = (a.narrow && !a.tail_w) ? 64 : split_halo_cout_tile(a.Cout);
     if (a.Cin % 64 != 0 || a.CoutPad % bn != 0 || a.Cout != a.CoutPad || a.slabs == 2) return hipErrorInvalidValue;
     // fused 1x1 tail: 64 -> 64 couts (box towers), split weights [64][tail_kpad = 128 pseudo-channels]; 128 -> <= 32 stored couts with fp32 output
     // (class towers), split weights [32][tail_kpad = 256 pseudo-channels]
