@@ -353,3 +353,19 @@ def test_latency_plan_with_a_stock_80_class_head(hip_lib, dtype):
     np.testing.assert_array_equal(anchor, anchor_o)
     np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=BOX_ATOL)
     det.close()
+
+
+def test_latency_plan_at_1280(hip_lib):
+    """BASELINE config 5's frame size on a latency-plan handle (one frame): 160 x 160 / 80 x 80 / 40 x 40 maps, the largest buffers the kernel's 32-bit
+    lane offsets see."""
+    size, B = 1280, 1
+    _, det, oracle = _handle(size, "f16x3", max_batch=2)
+    frames = fr.diverse_frames(4, size, seed=1280)[:B]
+    box_o, cls_o, (xywh_o, conf_o, anchor_o) = _oracle(oracle, frames, size)
+    xywh, conf, anchor = det.predict_host(frames, conf=0.1)
+    box_g, cls_g = det.debug_head(B)
+    np.testing.assert_allclose(cls_g, cls_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(box_g, box_o, rtol=1e-3, atol=LOGIT_ATOL)
+    np.testing.assert_array_equal(anchor, anchor_o)
+    np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=BOX_ATOL)
+    det.close()

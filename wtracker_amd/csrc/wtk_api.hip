@@ -1238,6 +1238,10 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
             Op &op = h->ops[i];
             if (op.kind != OP_CONV || op.folded || op.tail_op >= 0 || op.out2_buf >= 0 || op.cin % 32 || (op.k != 1 && op.k != 3) || op.cout_pad % 32 || op.cout % 8) continue;
             if (op.in2_buf >= 0 && (op.k != 1 || op.in2_split % 32)) continue;
+            {
+                const Buf &ibx = h->bufs[op.in_buf]; // conv_sk_kernel addresses a tile's pixels by 32-bit lane offsets from its first image: two images inside 31 bits
+                if (2LL * ibx.h * ibx.w * ibx.C * 4 > 0x7fffffffLL) continue;
+            }
             if (sk_mixed && (long long)h->max_batch * h->bufs[op.out_buf].h * h->bufs[op.out_buf].w > sk_mixed_max_px) continue;
             op.sk = 1;
             const int S = conv_sk_slices(op.k * op.k * op.cin / 32);
