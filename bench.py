@@ -334,16 +334,18 @@ def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     st = torch.cuda.Stream(device=dev)
     rows = []
     for dtype in ("f16x3", "fp32"):
-        # "large_batch_kernels" = the throughput plan WITHOUT the small-map rule of small handles (WTK_NO_SK_MIXED=1): what every call ran on before round 5
+        # "large_batch_kernels" = the throughput plan WITHOUT the rules of small handles (WTK_NO_SK_MIXED=1, WTK_SMALL_NARROW=0): what every call ran on before round 5
         for plan in ("latency", "throughput", "large_batch_kernels"):
             for size, B in ((384, 1), (384, 15), (640, 1)):
                 prev = os.environ.get("WTK_NO_SK_MIXED")
                 if plan == "large_batch_kernels":
                     os.environ["WTK_NO_SK_MIXED"] = "1"
+                    os.environ["WTK_SMALL_NARROW"] = "0"
                 det = hip.HipYolo(weights, (size, size), 16, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=device,
                                   plan="throughput" if plan == "large_batch_kernels" else plan)
                 if plan == "large_batch_kernels":
                     os.environ.pop("WTK_NO_SK_MIXED") if prev is None else os.environ.__setitem__("WTK_NO_SK_MIXED", prev)
+                    os.environ.pop("WTK_SMALL_NARROW", None)
                 f_np = fr.diverse_frames(16, size, seed=4242)[:B]
                 f = torch.from_numpy(f_np).to(dev)
                 x = torch.empty((B, 4), dtype=torch.float32, device=dev)

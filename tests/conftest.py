@@ -19,6 +19,7 @@ os.environ.setdefault("WTK_LATENCY_PLAN", "0")
 # ... and (same reason) off the split-K kernel that small throughput-plan handles (max_batch <= 16) use for their smallest maps; test_gpu_latency.py
 # removes the variable where it tests that rule
 os.environ.setdefault("WTK_NO_SK_MIXED", "1")
+os.environ.setdefault("WTK_SMALL_NARROW", "0")
 
 
 def pytest_configure(config):

@@ -307,15 +307,17 @@ def test_small_throughput_handle_runs_its_smallest_maps_on_the_split_k_kernel(hi
     """A throughput-plan handle of max_batch <= 16 (the controller's cycle batch: 9 / 15 frames at imgsz 384) runs the layers whose whole batch is at most
     4 096 output pixels — the 12 x 12 maps — on conv_sk_kernel (csrc/wtk_api.hip: sk_mixed).  Same bars as every reference-precision path: logits 2e-3,
     boxes 2e-2 px, survivors equal to the restatement's; a frame's logits do not depend on its batch; and the plain throughput handle
-    (WTK_NO_SK_MIXED=1) picks the same survivors."""
+    (WTK_NO_SK_MIXED=1, WTK_SMALL_NARROW=0) picks the same survivors."""
     size, B = 384, 15
     depth, width, maxch = ys.SCALES["s"]
     w = ys.synthetic_weights("s", 1, seed=0)
     oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
     mk = lambda: hip.HipYolo(w, (size, size), 16, dtype=dtype, width=width, depth=depth, max_channels=maxch, plan="throughput")
     monkeypatch.setenv("WTK_NO_SK_MIXED", "1")
+    monkeypatch.setenv("WTK_SMALL_NARROW", "0")
     plain = mk()
     monkeypatch.delenv("WTK_NO_SK_MIXED")
+    monkeypatch.delenv("WTK_SMALL_NARROW")
     mixed = mk()
     assert mixed.plan == plain.plan == "throughput"
     frames = fr.diverse_frames(16, size, seed=808)[:B]

@@ -557,6 +557,7 @@ struct wtk_yolo {
     // and NOT per call: every conv behind the fused front then runs on conv_sk_kernel whatever the batch of the call, so a frame's logits do not
     // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
     int latency = 0;
+    int small_narrow = 0; // a small handle (max_batch <= 16, f16x3) runs window / implicit-GEMM layers whose grid leaves most CUs idle on 64-cout tiles (WTK_SMALL_NARROW=0: off)
     int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status); a slot of the process-wide page
     int *status_dev = nullptr;  // ... and the device's address of the same word
     int status_static = 0;      // flags fixed at create time (none today)
@@ -1232,7 +1233,9 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     // grids that walk K serially (model.8's bottlenecks 40 us, split over K 24 us: profiles/r05_notes.md section 5); the choice is fixed per handle, so a
     // frame's result still does not depend on its batch.  WTK_NO_SK_MIXED=1 switches the second rule off (A/B).
     const bool sk_mixed = !h->latency && !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_NO_SK_MIXED") && std::getenv("WTK_NO_SK_MIXED")[0] == '1');
-    const long long sk_mixed_max_px = std::getenv("WTK_SK_MIXED_MAX_PX") ? std::atoll(std::getenv("WTK_SK_MIXED_MAX_PX")) : 4096; // (tuning switch)
+    // (f16x3: the 12 x 12 maps of imgsz 384; fp32, whose window kernels are 2.5 x slower per tap, gains on the 24 x 24 maps too — profiles/r05_notes.md section 5)
+    const long long sk_mixed_max_px = std::getenv("WTK_SK_MIXED_MAX_PX") ? std::atoll(std::getenv("WTK_SK_MIXED_MAX_PX")) : (h->split ? 4096 : 10000);
+    h->small_narrow = h->split && h->max_batch <= 16 && !(std::getenv("WTK_SMALL_NARROW") && std::getenv("WTK_SMALL_NARROW")[0] == '0');
     if (h->latency || sk_mixed) {
         for (size_t i = 3; i < h->ops.size(); ++i) { // ops[0..2] stay the fused front's
             Op &op = h->ops[i];
@@ -1696,8 +1699,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             } else if (h->split && !op.halo) {
                 int cfg = op.cfg;
                 // a small handle's 128 x 128-tile layer whose grid leaves a third of the CUs idle: 64-cout tiles, twice the blocks (same K order: same bits)
-                static const int narrow_igemm = std::getenv("WTK_IGEMM_NARROW") ? std::atoi(std::getenv("WTK_IGEMM_NARROW")) : 1;
-                if (narrow_igemm && h->max_batch <= 16 && cfg == CFG_128x128 && !a.in2 && !a.tile_w &&
+                if (h->small_narrow && cfg == CFG_128x128 && !a.in2 && !a.tile_w &&
                     3 * ((a.M + 127) / 128) * (a.CoutPad / 128) <= 2LL * h->num_cus)
                     cfg = CFG_128x64;
                 HIP_TRY(launch_conv_split(a, cfg, st));
@@ -1757,9 +1759,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                             g.bm = 128;
                             halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
                             // still under half of the CUs with 128-pixel blocks (a small handle's cycle batch on the 24 x 24 maps): 64-cout tiles as well —
-                            // each block then walks the same taps over half the couts (WTK_HALO_NARROW=0 switches it off)
-                            static const bool narrow_on = !(std::getenv("WTK_HALO_NARROW") && std::getenv("WTK_HALO_NARROW")[0] == '0');
-                            if (narrow_on && h->split && h->max_batch <= 16 && op.tail_op < 0 && op.cout_pad % 128 == 0 &&
+                            // each block then walks the same taps over half the couts
+                            if (h->small_narrow && op.tail_op < 0 && op.cout_pad % 128 == 0 &&
                                 2LL * g.strips * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus)
                                 g.narrow = 1;
                         }
