@@ -371,3 +371,54 @@ def test_latency_plan_at_1280(hip_lib):
     np.testing.assert_array_equal(anchor, anchor_o)
     np.testing.assert_allclose(xywh, xywh_o, rtol=0, atol=BOX_ATOL)
     det.close()
+
+
+@pytest.mark.parametrize("plan,n_handles", [("auto", 2), ("latency", 1), ("throughput", 1)])
+def test_closed_loop_controller_on_every_plan_equals_the_oracle_controller(hip_lib, tmp_path, monkeypatch, plan, n_handles):
+    """The closed loop (camera views depend on the previous cycle's movement) through HipYoloController as a user gets it — none of the suite's plan
+    switches set: plan "auto" = the single-frame call on a latency-plan handle and the 9-frame cycle batch on a small throughput-plan handle (split-K
+    kernel on its smallest maps, 64-cout tiles on thin grids); "latency" / "throughput" = one handle for both.  Integer platform moves and logged boxes
+    must be the CPU-restatement controller's, for host crops and for device-resident frames."""
+    from harness.sim_harness import ArrayReader, Simulator
+    from oracle.controllers_oracle import OracleYoloController
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig, TrackLogger
+
+    for v in ("WTK_LATENCY_PLAN", "WTK_NO_SK_MIXED", "WTK_SMALL_NARROW"):
+        monkeypatch.delenv(v, raising=False)
+    w = ys.synthetic_weights("s", 1, seed=0)
+    path = str(tmp_path / "s.wtk")
+    ys.save_weights(path, w, "s", 1)
+    depth, width, maxch = ys.SCALES["s"]
+    frames, _ = fr.synthetic_frames(40, 256, seed=8)
+    ec = ExperimentConfig("synthetic", 40, 60, (256, 256), 32, (128, 128))
+
+    def run(make):
+        tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.5, 0.5))
+        ctrl = make(tc)
+        moves = []
+        inner = ctrl.provide_movement_vector
+
+        def wrapped(sim):
+            m = inner(sim)
+            moves.append((int(m[0]), int(m[1])))
+            return m
+
+        ctrl.provide_movement_vector = wrapped
+        log = TrackLogger(ctrl)
+        Simulator(tc, ec, log, reader=ArrayReader(frames)).run()
+        return moves, log.rows, ctrl
+
+    cfg = YoloConfig(model_path=path, device="cuda", pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="f16x3", scale="s", plan=plan)
+    oracle = yo.YoloOracle(w, ys.model_dims(width, depth, maxch, 1))
+    m_g, rows_g, ctrl = run(lambda tc: HipYoloController(tc, cfg))
+    plans = sorted(d.plan for d in ctrl._model._dets.values())
+    assert len(plans) == n_handles and plans == (["latency", "throughput"] if plan == "auto" else [plan]) and all(d.max_batch == 16 for d in ctrl._model._dets.values())
+    m_o, rows_o, _ = run(lambda tc: OracleYoloController(tc, oracle, imgsz=128, conf=0.1))
+    assert m_g == m_o and len(m_g) == 4
+    m_d, rows_d, _ = run(lambda tc: HipYoloController(tc, cfg, device_frames=torch.from_numpy(frames).cuda()))
+    assert m_d == m_g and rows_d == rows_g
+    assert len(rows_g) == len(rows_o) == 36
+    for a, b in zip(rows_g, rows_o):
+        assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
+        np.testing.assert_allclose([a["wrm_x"], a["wrm_y"], a["wrm_w"], a["wrm_h"]], [b["wrm_x"], b["wrm_y"], b["wrm_w"], b["wrm_h"]], atol=BOX_ATOL)
