@@ -207,7 +207,8 @@ __device__ __forceinline__ int lane_fetch(int src_lane, int v) { return __builti
 // three MFMAs (hi*hi into acc, hi*lo + lo*hi into acc1); a.Cin / in_ld / out_ld / ... are pseudo-channel counts (2 x real), a.Cout is real.
 template <typename T, int BN, int NHALO, int MINW, int NWB, int HROWS, int BMT = 256, bool TAIL = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs a) {
-    static_assert(!SPLIT || (sizeof(T) == 2 && BN != 192 && MINW <= 2), "split mode: fp16 storage, 64 / 128 couts, 256-register budget");
+    static_assert(!SPLIT || (sizeof(T) == 2 && BN != 192 && (MINW <= 2 || (BN == 64 && BMT == 128 && NHALO == 1))),
+                  "split mode: fp16 storage, 64 / 128 couts, 256-register budget (128 for the two-blocks-per-CU form: 64 couts x 128 pixels, one window buffer)");
 #ifdef WTK_HALO_STAMPS // diagnostic builds only: block start / main-loop start / main-loop end / block end, 100 MHz clock
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -475,6 +476,17 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #endif
+                if constexpr (NHALO == 1) {
+                    // ONE window buffer and more than one chunk (the two-blocks-per-CU form of the split kernel): the next chunk's window is requested when
+                    // everybody is done with this one, and waited for on the spot — the OTHER block of the CU is what runs meanwhile
+                    if (tap == 8 && more) {
+#pragma unroll
+                        for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_halo_piece(halo0, q, c + 1);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                }
             }
         }
     };
@@ -1841,7 +1853,7 @@ int split_halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 
 
 // Every channel count / offset of `a` but Cout / CoutPad in pseudo-channels (2 x real); three weight slabs, one tile per block
 hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
-    const int bn = (a.narrow && !a.tail_w) ? 64 : split_halo_cout_tile(a.Cout);
+    const int bn = ((a.narrow || a.two_per_cu) && !a.tail_w) ? 64 : split_halo_cout_tile(a.Cout);
     if (a.Cin % 64 != 0 || a.CoutPad % bn != 0 || a.Cout != a.CoutPad || a.slabs == 2) return hipErrorInvalidValue;
     // fused 1x1 tail: 64 -> 64 couts (box towers), split weights [64][tail_kpad = 128 pseudo-channels]; 128 -> <= 32 stored couts with fp32 output
     // (class towers), split weights [32][tail_kpad = 256 pseudo-channels]
@@ -1856,6 +1868,10 @@ hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
     if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % 64 || a.res_coff % 64)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % 64 || a.out2_coff % 64)) return hipErrorInvalidValue;
+    if (a.two_per_cu && !a.tail_w) { // 64 couts x 128 pixels, one window buffer, 78 KB of LDS and <= 128 VGPRs: two blocks per CU
+        if (bm != 128) return hipErrorInvalidValue;
+        return launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax, 128, false, true>(a, stream);
+    }
     if (bn == 128 && a.tail_w) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);
     if (bn == 128) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
     if (a.tail_w) return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);

@@ -5,7 +5,7 @@
 // run every layer on a handful of blocks, each of which walks the whole K of its tile one staged step at a time: a step costs a full
 // memory latency when nothing else is resident on the CU, so a layer takes 10-45 us whatever its arithmetic (profiles/r05_notes.md:
 // B = 1 at 384^2, B = 15 at 384^2 and B = 1 at 640^2 take the same time per layer).  Here a layer is cut along K as well:
-//   block = (pixel tile, cout tile, K slice of <= 8 steps);  a step = one 128-byte operand row = 32 channels of one tap
+//   block = (pixel tile, cout tile, K atom — or all atoms, see below);  a step = one 128-byte operand row = 32 channels of one tap
 // and a block requests its slice's operands through an NS-deep LDS ring with NS - 1 stages in flight from the first instruction
 // (for a slice of <= NS - 1 steps: everything at once, ONE latency), multiplies, and leaves either the finished tile (S = 1) or an
 // fp32 partial tile in its slice's slab.  The slabs of a tile are combined by the block of that tile that ARRIVES LAST (one ticket per tile: write-through

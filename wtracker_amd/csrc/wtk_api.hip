@@ -1766,6 +1766,12 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                         }
                     }
                 }
+                // WTK_HALO_2CU=1 (experiment): the split window layers on maps of at most 40 x 40 as two blocks per CU
+                static const bool halo_2cu = std::getenv("WTK_HALO_2CU") && std::getenv("WTK_HALO_2CU")[0] == '1';
+                if (halo_2cu && h->split && op.halo == 1 && op.tail_op < 0 && ib.h <= 40 && !ws64) {
+                    g.bm = 128, g.two_per_cu = 1, g.narrow = 0;
+                    halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
+                }
                 g.zeros = h->zero_page;
                 if (ws64) {
                 } else if (h->split && op.halo == 2)
