@@ -422,3 +422,40 @@ def test_closed_loop_controller_on_every_plan_equals_the_oracle_controller(hip_l
     for a, b in zip(rows_g, rows_o):
         assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])
         np.testing.assert_allclose([a["wrm_x"], a["wrm_y"], a["wrm_w"], a["wrm_h"]], [b["wrm_x"], b["wrm_y"], b["wrm_w"], b["wrm_h"]], atol=BOX_ATOL)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16x3", 2e-5), ("fp32", 2e-5)])
+def test_every_conv_tensor_of_the_latency_plan_against_the_large_batch_kernels(hip_lib, dtype, tol, monkeypatch):
+    """Layer by layer: the output tensor of every conv blob (wtk_yolo_debug_tensor) on a latency-plan handle against the same model on the large-batch
+    kernels (Detect tails unfused there so that their inputs exist as tensors): 3x3 / 1x1, stride 1 / 2, residual, two-source upsample loader, fp32
+    Detect outputs — every variant conv_sk_kernel serves, each within 2e-5 of the tensor's scale (K is summed in another order, nothing else differs)."""
+    size, B = 384, 3
+    monkeypatch.setenv("WTK_NO_FUSED_TAIL", "1")
+    monkeypatch.setenv("WTK_FRONT_DEBUG", "1")
+    monkeypatch.setenv("WTK_NO_SK_MIXED", "1")
+    monkeypatch.setenv("WTK_SMALL_NARROW", "0")
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    frames = fr.diverse_frames(4, size, seed=4242)[:B]
+    outs = {}
+    for plan in ("throughput", "latency"):
+        det = hip.HipYolo(w, (size, size), 4, dtype=dtype, width=width, depth=depth, max_channels=maxch, plan=plan)
+        det.predict_host(frames, conf=0.1)
+        tensors = {}
+        for i, t in enumerate(ys.conv_table("s", 1)):
+            try:
+                tensors[t["name"]] = det.debug_tensor(i, B)
+            except hip.WtkError:
+                pass  # a conv computed inside another op (concatenated Detect stems report under their first blob)
+        outs[plan] = tensors
+        det.close()
+    a, b = outs["throughput"], outs["latency"]
+    assert set(a) == set(b) and len(a) >= 50
+    worst = ("", 0.0)
+    for nm in a:
+        scale = max(1.0, float(np.abs(a[nm]).max()))
+        err = float(np.abs(a[nm] - b[nm]).max()) / scale
+        if err > worst[1]:
+            worst = (nm, err)
+        assert err < tol, (nm, err, scale)
+    print(f"\nlatency plan vs large-batch kernels, {dtype}: worst conv tensor {worst[0]} differs by {worst[1]:.2e} of its scale ({len(a)} tensors)")
