@@ -137,7 +137,7 @@ void wtk_yolo_destroy(wtk_yolo *h);
  *                        few thousand pixels still runs on every CU, and calls with a repeating argument set replay a captured
  *                        hipGraph.  WTK_F32 and WTK_F16X3 only (WTK_F16 handles stay on the throughput plan).
  *   WTK_PLAN_AUTO        (= wtk_yolo_create) latency when max_batch <= 4 and the dtype allows it, else throughput (measured on MI355X at imgsz 384:
- *                        B = 1 0.53 ms against 1.00 ms on the throughput plan, B = 15 1.7 ms against 1.3 ms — the cross-over lies near B = 6); the
+ *                        B = 1 0.53 ms against 0.67-1.00 ms on the throughput plan, B = 15 1.5 ms against 1.2 ms — the cross-over lies near B = 6); the
  *                        environment variable WTK_LATENCY_PLAN=0 / 1 overrides AUTO only.
  * The plan never changes per call: within a handle a frame's logits do not depend on the batch it arrives in.  Both plans meet the
  * same tolerances against the fp32 restatement; they are not bit-identical to each other (K is summed in a different order). */

@@ -319,7 +319,7 @@ class YoloConfig:
     # launch plan of the detector handles (include/wtk_hip.h: wtk_yolo_create_planned).  The reference calls the detector twice per cycle: one single frame
     # (provide_movement_vector, yolo_controller.py:96-98) and one cycle batch of 9 / 15 frames (_cycle_predict_all, :108-109).  "auto": calls of up to
     # LATENCY_MAX_BATCH frames go to a handle on the latency plan (split-K convs, replayed captures: 0.53 ms instead of 1.0 ms for the single frame), larger
-    # ones to a throughput-plan handle (1.3 ms instead of 1.7 ms for 15 frames): each call on the plan that is faster for it; the two handles agree within
+    # ones to a throughput-plan handle (1.2 ms instead of 1.5 ms for 15 frames): each call on the plan that is faster for it; the two handles agree within
     # the tolerance both meet against the fp32 restatement, not bit for bit.  "latency": every call up to 16 frames on ONE latency-plan handle — a frame's
     # result is then bit-identical whichever of the two calls sees it; "throughput": every call on the large-batch kernels.  fp16: always throughput.
     plan: str = "auto"
