@@ -1946,7 +1946,7 @@ int halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 : (cou
 hipError_t launch_conv3x3_halo(const HaloArgs &a, int is_f16, hipStream_t stream) {
     const int ce = is_f16 ? 8 : 4;
     const int cch = 8 * ce;
-    const int bn = halo_cout_tile(a.Cout);
+    const int bn = (a.narrow && !a.tail_w && a.CoutPad % 64 == 0) ? 64 : halo_cout_tile(a.Cout); // narrow: 64-cout tiles for a thin grid (small handles)
     if (a.Cin % cch != 0 || a.CoutPad % bn != 0 || a.Cout > a.CoutPad || a.Cout % (bn == 192 ? 24 : 16) != 0) return hipErrorInvalidValue;
     if (a.in_ld % ce || a.in_coff % ce || a.out_ld % ce || a.out_coff % ce || a.Kpad % cch || a.Kpad < 9 * a.Cin) return hipErrorInvalidValue;
     if (a.pitch != (a.strips == 1 ? a.S + 1 : a.S + 2) || kBM + 2 * a.pitch + 2 > kHaloRowsMax || a.strips * a.S < a.W || (a.strips == 1 && a.S != a.W))

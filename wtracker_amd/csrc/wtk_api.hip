@@ -1235,7 +1235,7 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     const bool sk_mixed = !h->latency && !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_NO_SK_MIXED") && std::getenv("WTK_NO_SK_MIXED")[0] == '1');
     // (f16x3: the 12 x 12 maps of imgsz 384; fp32, whose window kernels are 2.5 x slower per tap, gains on the 24 x 24 maps too — profiles/r05_notes.md section 5)
     const long long sk_mixed_max_px = std::getenv("WTK_SK_MIXED_MAX_PX") ? std::atoll(std::getenv("WTK_SK_MIXED_MAX_PX")) : (h->split ? 4096 : 10000);
-    h->small_narrow = h->split && h->max_batch <= 16 && !(std::getenv("WTK_SMALL_NARROW") && std::getenv("WTK_SMALL_NARROW")[0] == '0');
+    h->small_narrow = !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_SMALL_NARROW") && std::getenv("WTK_SMALL_NARROW")[0] == '0');
     if (h->latency || sk_mixed) {
         for (size_t i = 3; i < h->ops.size(); ++i) { // ops[0..2] stay the fused front's
             Op &op = h->ops[i];
@@ -1699,7 +1699,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             } else if (h->split && !op.halo) {
                 int cfg = op.cfg;
                 // a small handle's 128 x 128-tile layer whose grid leaves a third of the CUs idle: 64-cout tiles, twice the blocks (same K order: same bits)
-                if (h->small_narrow && cfg == CFG_128x128 && !a.in2 && !a.tile_w &&
+                if (h->small_narrow && h->split && cfg == CFG_128x128 && !a.in2 && !a.tile_w &&
                     3 * ((a.M + 127) / 128) * (a.CoutPad / 128) <= 2LL * h->num_cus)
                     cfg = CFG_128x64;
                 HIP_TRY(launch_conv_split(a, cfg, st));
@@ -1760,12 +1760,17 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                             halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
                             // still under half of the CUs with 128-pixel blocks (a small handle's cycle batch on the 24 x 24 maps): 64-cout tiles as well —
                             // each block then walks the same taps over half the couts
-                            if (h->small_narrow && op.tail_op < 0 && op.cout_pad % 128 == 0 &&
+                            if (h->small_narrow && h->split && op.tail_op < 0 && op.cout_pad % 128 == 0 &&
                                 2LL * g.strips * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus)
                                 g.narrow = 1;
                         }
                     }
                 }
+                // fp32 handles: the exact-fp32 matrix instructions make these layers arithmetic bound, so a grid on under three quarters of the CUs (a small
+                // handle's 48 x 48 maps: 141-150 blocks of 128 / 192 couts) is cut into 64-cout tiles (Detect P3 first convs 205 us, class tower 139 us before)
+                if (h->small_narrow && !h->split && !ws64 && op.halo == 1 && op.tail_op < 0 && op.cout_pad % 64 == 0 && halo_cout_tile(op.cout) != 64 &&
+                    4LL * g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout)) <= 3LL * h->num_cus)
+                    g.narrow = 1;
                 // WTK_HALO_2CU=1 (experiment): the split window layers on maps of at most 40 x 40 as two blocks per CU
                 static const bool halo_2cu = std::getenv("WTK_HALO_2CU") && std::getenv("WTK_HALO_2CU")[0] == '1';
                 if (halo_2cu && h->split && op.halo == 1 && op.tail_op < 0 && ib.h <= 40 && !ws64) {
