@@ -340,6 +340,33 @@ def test_small_throughput_handle_runs_its_smallest_maps_on_the_split_k_kernel(hi
     plain.close(), mixed.close()
 
 
+@pytest.mark.parametrize("size,B", [(384, 15), (640, 7), (128, 3)])
+def test_six_slab_window_ring_is_bit_identical_to_the_three_slab_kernel(hip_lib, size, B, monkeypatch):
+    """A small f16x3 handle runs its 64-cout x 128-pixel window tiles on the six-slab ring with fragment prefetch (conv3x3_halo.hip, NWB = 6): the same
+    taps in the same order, so raw head tensors, survivors and boxes equal the three-slab kernel's (WTK_HALO_DEEP=0) bit for bit — for a full call and
+    for one frame of it."""
+    depth, width, maxch = ys.SCALES["s"]
+    w = ys.synthetic_weights("s", 1, seed=2)
+    mk = lambda: hip.HipYolo(w, (size, size), 16, dtype="f16x3", width=width, depth=depth, max_channels=maxch, plan="throughput")
+    for v in ("WTK_NO_SK_MIXED", "WTK_SMALL_NARROW", "WTK_HALO_DEEP"):
+        monkeypatch.delenv(v, raising=False)  # the rules as a user gets them: narrow tiles are what the six-slab ring serves
+    deep = mk()
+    monkeypatch.setenv("WTK_HALO_DEEP", "0")
+    three = mk()
+    frames = fr.diverse_frames(16, size, seed=99)[:B]
+    xd, cd, ad = deep.predict_host(frames, conf=0.1)
+    bd, kd = deep.debug_head(B)
+    xt, ct, at = three.predict_host(frames, conf=0.1)
+    bt, kt = three.debug_head(B)
+    for got, want in ((xd, xt), (cd, ct), (ad, at), (bd, bt), (kd, kt)):
+        np.testing.assert_array_equal(got, want)
+    x1, c1, a1 = deep.predict_host(frames[B - 1:B], conf=0.1)
+    b1, k1 = deep.debug_head(1)
+    np.testing.assert_array_equal(k1, kd[B - 1:B])
+    np.testing.assert_array_equal(b1, bd[B - 1:B])
+    deep.close(), three.close()
+
+
 @pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
 def test_latency_plan_with_a_stock_80_class_head(hip_lib, dtype):
     """nc = 80 (a stock YOLOv8 head): the class towers' last 1x1 stores 80 of 96 padded couts, the class logits are [A, 80] fp32 rows."""

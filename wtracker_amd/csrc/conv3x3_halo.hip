@@ -139,6 +139,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -228,9 +236,12 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     constexpr int kHaloBytesT = HROWS * 128;
     __shared__ __attribute__((aligned(16))) char halo0[kHaloBytesT];
     __shared__ __attribute__((aligned(16))) char halo1[NHALO == 2 ? kHaloBytesT : 16];
-    __shared__ __attribute__((aligned(16))) char wbuf0[BN * 128];
-    __shared__ __attribute__((aligned(16))) char wbuf1[BN * 128];
+    static_assert(NWB == 2 || NWB == 3 || (NWB == 6 && NHALO == 2 && !TAIL && SPLIT), "slab ring: 2, 3 or 6 (split tiles, two window buffers, no fused tail)");
+    constexpr bool kRing = NWB >= 3; // counted waits, raw LDS-DMA requests
+    __shared__ __attribute__((aligned(16))) char wbuf0[NWB > 3 ? 16 : BN * 128];
+    __shared__ __attribute__((aligned(16))) char wbuf1[NWB > 3 ? 16 : BN * 128];
     __shared__ __attribute__((aligned(16))) char wbuf2[NWB == 3 ? BN * 128 : 16];
+    __shared__ __attribute__((aligned(16))) char wring[NWB > 3 ? NWB * BN * 128 : 16]; // the six-slab ring: slot = global tap index % 6
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -285,11 +296,11 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     auto issue_halo_piece = [&](char *buf, int q, int c) { // q static after unrolling
         const int piece = wave + 8 * q;
         if (piece >= halo_pieces) return; // wave-uniform
-        if constexpr (NWB == 3 && WTK_HALO_BUFFER_DMA) {
+        if constexpr (kRing && WTK_HALO_BUFFER_DMA) {
             lds_dma16_buf(make_rsrc(img), ((hvalid >> q) & 1u) ? hoff[q] : 0xffffffffu, (unsigned)(c * (CCH * (int)sizeof(T))), buf + piece * 1024);
         } else {
             const char *src = ((hvalid >> q) & 1u) ? img + (size_t)c * (CCH * sizeof(T)) + hoff[q] : zero_page;
-            lds_dma16<NWB == 3>(src, buf + piece * 1024);
+            lds_dma16<kRing>(src, buf + piece * 1024);
         }
     };
     // Same, but never skipped (see the three-slab schedule below).  Pieces past the window rows carry zeros into unused
@@ -301,11 +312,11 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         const int piece = back ? wave + 8 * (q - 1) : wave + 8 * q;
         const unsigned off = back ? hoff[q > 0 ? q - 1 : 0] : hoff[q];
         const bool ok = back ? ((hvalid >> (q > 0 ? q - 1 : 0)) & 1u) : ((hvalid >> q) & 1u);
-        if constexpr (NWB == 3 && WTK_HALO_BUFFER_DMA) {
+        if constexpr (kRing && WTK_HALO_BUFFER_DMA) {
             lds_dma16_buf(make_rsrc(img), ok ? off : 0xffffffffu, (unsigned)(c * (CCH * (int)sizeof(T))), buf + piece * 1024);
         } else {
             const char *src = ok ? img + (size_t)c * (CCH * sizeof(T)) + off : zero_page;
-            lds_dma16<NWB == 3>(src, buf + piece * 1024);
+            lds_dma16<kRing>(src, buf + piece * 1024);
         }
     };
     // Weight slab of (tap, chunk c): rows = couts n0 .. n0+BN, 128 bytes each.  Uniform base + invariant
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     }
     const char *wtile = reinterpret_cast<const char *>(wgt + (long long)n0 * a.Kpad);
     auto issue_weights = [&](char *buf, int tap, int c) {
-        if constexpr (NWB == 3 && WTK_HALO_BUFFER_DMA) {
+        if constexpr (kRing && WTK_HALO_BUFFER_DMA) {
             const rsrc_t rs = make_rsrc(wtile);
             const unsigned so = (unsigned)((tap * a.Cin + c * CCH) * (int)sizeof(T)); // wave-uniform
 #pragma unroll
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         } else {
             const char *ub = wtile + ((size_t)tap * a.Cin + (size_t)c * CCH) * sizeof(T); // wave-uniform
 #pragma unroll
-            for (int i = 0; i < WR; ++i) lds_dma16<NWB == 3>(ub + wvoff[i], buf + (64 * i + 8 * wave) * 128);
+            for (int i = 0; i < WR; ++i) lds_dma16<kRing>(ub + wvoff[i], buf + (64 * i + 8 * wave) * 128);
         }
     };
 
@@ -391,6 +402,41 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
         }
     };
 
+    // Six-slab ring (split tiles): the fragments of tap g + 1 are read from LDS BEFORE the MFMAs of tap g are issued, into the second of two register
+    // sets (g & 1): with one barrier per tap and all eight waves in step, the ds_read phase (8 waves x 10-12 b128 reads = 80-96 KB per tap through a
+    // 128 B/clk port) and the MFMA phase (two waves per SIMD) otherwise run one after the other.  Same MFMAs in the same order per accumulator.
+    constexpr int kFr = (NWB > 3 && SPLIT) ? 2 * TP + 2 * TC : 1;
+    uint4 fr[NWB > 3 ? 2 : 1][kFr];
+    auto load_frags = [&](uint4(&f)[kFr], const char *halo, const char *wb, int tapoff) __attribute__((always_inline)) {
+        if constexpr (NWB > 3 && SPLIT) {
+            const int base = prow0 + tapoff;
+            const unsigned pfrag0 = base * 128 + ((lg ^ (base & 7)) << 4);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) f[j] = *reinterpret_cast<const uint4 *>(halo + pfrag0 + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) f[2 * TP + i] = *reinterpret_cast<const uint4 *>(wb + wfrag0 + i * 512);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) f[2 * TP + TC + i] = *reinterpret_cast<const uint4 *>(wb + (wfrag0 ^ 64u) + i * 512);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) f[TP + j] = *reinterpret_cast<const uint4 *>(halo + (pfrag0 ^ 64u) + j * 2048);
+        }
+    };
+    auto mma_frags = [&](const uint4(&f)[kFr]) __attribute__((always_inline)) { // the order of compute_tap's split branch
+        if constexpr (NWB > 3 && SPLIT) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    mma_h(f[2 * TP + i], f[j], acc[i][j], (T *)nullptr);
+                    mma_h(f[2 * TP + TC + i], f[j], acc1[i][j], (T *)nullptr);
+                }
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_h(f[2 * TP + i], f[TP + j], acc1[i][j], (T *)nullptr);
+        }
+    };
+
     const int nchunks = a.Cin / CCH;
     const int cb = n0 + wave_c * WC + lg * NV; // first of the NV consecutive couts this lane owns
     // the accumulators start at the bias (rows exist up to CoutPad): no v_add per output value in the epilogue
@@ -407,12 +453,26 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
     // ---- prologue: whole window of chunk 0 + weights of tap 0 (and tap 1 with the three-slab ring)
 #pragma unroll
     for (int q = 0; q < kMaxPiecesPerWave; ++q) issue_halo_piece(halo0, q, 0);
-    issue_weights(wbuf0, 0, 0);
-    if (NWB == 3) {
-        issue_weights(wbuf1, 1, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the raw requests are invisible to the compiler's own wait insertion
+    if constexpr (NWB > 3) { // six-slab ring: the slabs of taps 0..4 (a layer has at least 9 taps)
+#pragma unroll
+        for (int t0 = 0; t0 < NWB - 1; ++t0) issue_weights(wring + t0 * (BN * 128), t0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        issue_weights(wbuf0, 0, 0);
+        if (NWB == 3) {
+            issue_weights(wbuf1, 1, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the raw requests are invisible to the compiler's own wait insertion
+        }
     }
     __syncthreads();
+    // The bias values above come from ordinary loads: without a use in front of the loop hipcc waits for them at their first use INSIDE it, and —
+    // not knowing how many raw LDS-DMA requests are younger — does so with a vmcnt(0) on every trip (found in the 64-cout x 128-pixel variants:
+    // one full drain per two chunks; tools/asm_loop_waits.py lists such waits).  Here the queue is empty anyway.
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) asm volatile("" : "+v"(acc[i][j]));
+    if constexpr (NWB > 3) load_frags(fr[0], halo0, wring, 0);
 
 #ifdef WTK_HALO_TAP_STAMPS // diagnostic builds: per-wave cycle totals of (issue + ds_read + MFMA), vmcnt wait, barrier wait
     unsigned long long tap_sum[3] = {0, 0, 0};
@@ -441,6 +501,38 @@ __global__ __launch_bounds__(512, MINW) void conv3x3_halo_kernel(const HaloArgs 
                     issue_halo_piece(hnext, tap, c + 1);           // tap, underneath the MFMAs
                 compute_tap(hcur, wcur, (tap / 3) * pitch + (tap % 3));
                 __syncthreads(); // vmcnt(0): everything issued above has landed; everyone is done reading wcur
+            } else if constexpr (NWB > 3) {
+                // Six-slab ring (64-cout split tiles: 2 x 54 + 6 x 8 = 156 KB).  The slab of global tap g = 9 c + tap lives in slot g % 6 = (3 CP + tap) % 6;
+                // tap g requests the slab of tap g + 5 into the slot tap g - 1 was read from, so a slab has four taps to arrive (the three-slab ring:
+                // one) and is there one tap BEFORE its tap: tap g reads the fragments of tap g + 1 first and multiplies its own — read during tap g - 1 —
+                // underneath.  The next chunk's window goes out two pieces per tap at taps 0..3: it has landed by the wait of tap 7, in front of the
+                // fragment reads of the next chunk's tap 0.  Write-after-read: the slot of tap g - 1 and the window of chunk c - 1 were last read one tap
+                // before their last tap, a barrier earlier than the first request into them.  Same taps in the same order: bit-identical.
+                constexpr int kSlab = BN * 128;
+                static_assert(kMaxPiecesPerWave <= 8, "window pieces are requested at taps 0..3, two per tap");
+                auto pcs = [](int t) constexpr { t = (t + 9) % 9; const int left = kMaxPiecesPerWave - 2 * t; return left < 0 ? 0 : (left > 2 ? 2 : left); };
+                const int par = (CP + tap) & 1; // parity of the global tap index (a constant once the tap loop is unrolled)
+                const char *wnext1 = wring + ((3 * CP + tap + 1) % NWB) * kSlab;
+                char *wnext5 = wring + ((3 * CP + tap + 5) % NWB) * kSlab;
+                if (tap < 8)
+                    load_frags(fr[par ^ 1], hcur, wnext1, ((tap + 1) / 3) * pitch + ((tap + 1) % 3));
+                else
+                    load_frags(fr[par ^ 1], hnext, wnext1, 0); // (last chunk: values nobody uses)
+                mma_frags(fr[par]);
+                if (tap < 4)
+                    issue_weights(wnext5, tap + 5, c);
+                else
+                    issue_weights(wnext5, tap - 4, more ? c + 1 : c); // last chunk: a slab nobody reads again (constant request count per tap)
+                if (2 * tap < kMaxPiecesPerWave) issue_halo_piece_always(hnext, 2 * tap, more ? c + 1 : c);
+                if (2 * tap + 1 < kMaxPiecesPerWave) issue_halo_piece_always(hnext, 2 * tap + 1, more ? c + 1 : c);
+                // landed after this wait: the slab of tap g + 2 (requested at tap g - 3) and everything older; in flight: the window pieces of tap g - 3
+                // and all requests of taps g - 2 .. g
+                constexpr int WRc = BN / 64;
+                const int in_flight = pcs(tap - 3) + (WRc + pcs(tap - 2)) + (WRc + pcs(tap - 1)) + (WRc + pcs(tap));
+                wait_vmcnt(in_flight);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             } else {
                 const char *wcur = tap % 3 == 0 ? wbuf0 : (tap % 3 == 1 ? wbuf1 : wbuf2);
                 char *wnext2 = (tap + 2) % 3 == 0 ? wbuf0 : ((tap + 2) % 3 == 1 ? wbuf1 : wbuf2);
@@ -1875,6 +1967,8 @@ hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
     if (bn == 128 && a.tail_w) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);
     if (bn == 128) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
     if (a.tail_w) return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);
+    // six-slab ring: the 128-pixel tile only (the 256-pixel tile, 24 MFMAs per wave and tap, measured the same with either ring)
+    if (a.deep && bm == 128) return launch_h<_Float16, 64, 2, 1, 6, kHaloRowsMax, 128, false, true>(a, stream);
     return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
 }
 

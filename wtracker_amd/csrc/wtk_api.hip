@@ -558,6 +558,7 @@ struct wtk_yolo {
     // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
     int latency = 0;
     int small_narrow = 0; // a small handle (max_batch <= 16, f16x3) runs window / implicit-GEMM layers whose grid leaves most CUs idle on 64-cout tiles (WTK_SMALL_NARROW=0: off)
+    int halo_deep = 0;    // f16x3: the 64-cout x 128-pixel window tiles on the six-slab ring (small handles; WTK_HALO_DEEP)
     int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status); a slot of the process-wide page
     int *status_dev = nullptr;  // ... and the device's address of the same word
     int status_static = 0;      // flags fixed at create time (none today)
@@ -1236,6 +1237,10 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     // (f16x3: the 12 x 12 maps of imgsz 384; fp32, whose window kernels are 2.5 x slower per tap, gains on the 24 x 24 maps too — profiles/r05_notes.md section 5)
     const long long sk_mixed_max_px = std::getenv("WTK_SK_MIXED_MAX_PX") ? std::atoll(std::getenv("WTK_SK_MIXED_MAX_PX")) : (h->split ? 4096 : 10000);
     h->small_narrow = !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_SMALL_NARROW") && std::getenv("WTK_SMALL_NARROW")[0] == '0');
+    {
+        const int deep = std::getenv("WTK_HALO_DEEP") ? std::atoi(std::getenv("WTK_HALO_DEEP")) : 1;
+        h->halo_deep = h->split && (deep == 2 || (deep == 1 && h->max_batch <= 16));
+    }
     if (h->latency || sk_mixed) {
         for (size_t i = 3; i < h->ops.size(); ++i) { // ops[0..2] stay the fused front's
             Op &op = h->ops[i];
@@ -1777,6 +1782,11 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                     g.bm = 128, g.two_per_cu = 1, g.narrow = 0;
                     halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
                 }
+                // Small f16x3 handles: the 64-cout window tiles on the six-slab ring with fragment prefetch (conv3x3_halo.hip; bit-identical to the
+                // three-slab kernel).  A cycle batch's 24 x 24 layers 19.4 -> 15.9 us each; the 256-pixel tiles and the large handles measure the
+                // same either way (profiles/r05_notes.md section 7), so those keep the three-slab kernel.  WTK_HALO_DEEP: 0 off, 1 small handles
+                // (default), 2 every handle; read when the handle is created.
+                if (h->halo_deep && op.halo == 1 && !ws64) g.deep = 1;
                 g.zeros = h->zero_page;
                 if (ws64) {
                 } else if (h->split && op.halo == 2)

@@ -246,6 +246,7 @@ struct HaloArgs {
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
     int two_per_cu; // split window kernel: 1 = 64 couts x 128 pixels with ONE window buffer (78 KB, <= 128 VGPRs): two blocks per CU (bm must be 128)
+    int deep;       // split window kernel, 64-cout x 128-pixel tiles without a fused tail: 1 = six-slab weight ring + fragment prefetch (156 KB of LDS)
     int narrow; // split window kernel: 1 = 64-cout tiles for a layer of 128-multiple couts (twice the blocks; for grids that leave most CUs idle)
     int grid; // blocks of the launch (filled by the launchers: reading gridDim.x costs the set-up one more scalar-load round trip)
     const int *n_dyn; // nullable: device-side image count <= N (conv3x3_halo_kernel, conv3x3_s2_kernel): blocks whose tile starts beyond its last image exit at once
