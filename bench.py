@@ -837,9 +837,12 @@ def main():
             out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_auto"]["frames_per_s"]
     if lat is not None:
         out["latency"] = lat
-        for r in lat["rows"]:  # two scalars per reference-precision mode in the main line: the reference's two calls
-            if r["plan"] == "latency" and r["size"] == 384:
+        # two scalars per reference-precision mode in the main line: the reference's two calls, each on the plan the controller's default ("auto":
+        # controllers._YoloModel.detector) gives it — the single frame on a latency-plan handle, the cycle batch on a small throughput-plan handle
+        for r in lat["rows"]:
+            if r["size"] == 384 and r["plan"] == ("latency" if r["batch"] <= 4 else "throughput"):
                 out[f"latency_b{r['batch']}_384_{r['dtype']}_ms"] = r["device_ms"]
+        lat["main_line"] = "latency_b1_* = the latency-plan row, latency_b15_* = the throughput-plan row (the plan YoloConfig.plan = 'auto' picks per call)"
     # flat per-mode keys (a record that keeps only top-level scalars still carries every mode and its exactness)
     for dt, m in modes.items():
         out[f"value_{dt}"] = m["value"]

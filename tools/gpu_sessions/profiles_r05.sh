@@ -22,4 +22,6 @@ for cfg in "f16x3 1 384" "fp32 1 384" "f16x3 1 640" "f16x3 15 384"; do
   N=${DT}_b${BB}_${S}
   WTK_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5pf_lat_$N -o lat -- python3 $R/tools/gpu_sessions/time_mode.py --dtype $DT --steps 20 --batch $BB --size $S --plan latency > $R/gpurun_out/r5pf_lat_$N.log 2>&1 || echo "latency trace $N failed"
 done
+# 5. the cycle batch on the plan the controller gives it: a throughput-plan handle of 15 frames (small-handle rules: split-K on the 12x12 maps, 64-cout tiles, six-slab ring)
+WTK_NO_SIDE_STREAM=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5pf_thr_f16x3_b15_384 -o lat -- python3 $R/tools/gpu_sessions/time_mode.py --dtype f16x3 --steps 20 --batch 15 --size 384 --plan throughput > $R/gpurun_out/r5pf_thr_f16x3_b15_384.log 2>&1 || echo "cycle batch trace failed"
 ls $R/gpurun_out | grep r5pf_ | head -40

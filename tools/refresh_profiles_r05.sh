@@ -24,4 +24,6 @@ for N in f16x3_b1_384 fp32_b1_384 f16x3_b1_640 f16x3_b15_384; do
   python tools/trace_timeline.py "$(f r5pf_lat_$N lat_kernel_trace.csv)" > profiles/${R}_timeline_latency_${N}.txt
 done
 cp profiles/${R}_kernel_stats_latency_f16x3_b1_384.csv profiles/${R}_kernel_stats_b1_f16x3.csv
+cp "$(f r5pf_thr_f16x3_b15_384 lat_kernel_stats.csv)" profiles/${R}_kernel_stats_cycle_batch_f16x3_b15_384.csv
+python tools/trace_timeline.py "$(f r5pf_thr_f16x3_b15_384 lat_kernel_trace.csv)" > profiles/${R}_timeline_cycle_batch_f16x3_b15_384.txt
 ls -la profiles | grep $R
