@@ -26,6 +26,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--pass", dest="which", type=int, default=-1)
     ap.add_argument("--summary", action="store_true", help="totals per kernel only")
+    ap.add_argument("--queues", action="store_true", help="append the hardware queue id of every dispatch (concurrent side-stream runs)")
     args = ap.parse_args()
     rows = list(csv.DictReader(open(args.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -49,7 +50,8 @@ def main():
         gx = int(r.get("Grid_Size", r.get("Grid_Size_X", "0")) or 0)
         nm = short(r["Kernel_Name"])
         if not args.summary:
-            print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.2f}  gap {(s - prev_end) / 1e3:6.2f}  blocks {gx // max(wg, 1):6d}  {nm}")
+            q = f"  q{r['Queue_Id']}" if args.queues and "Queue_Id" in r else ""
+            print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.2f}  gap {(s - prev_end) / 1e3:6.2f}  blocks {gx // max(wg, 1):6d}  {nm}{q}")
         d = tot.setdefault(nm, [0, 0.0])
         d[0] += 1
         d[1] += (e - s) / 1e3
