@@ -471,6 +471,68 @@ int conv_sk_slices(int nk) {
     return s < 2 ? 2 : (s > 8 ? 8 : s);
 }
 
+// Form and tile of one launch.  A small cost model in microseconds, calibrated on profiles/r05_notes.md's forced-tile timelines: blocks run one per
+// CU (96-128 KB of LDS) in rounds; a block costs a fixed latency chain, its operand bytes at what a CU's memory path delivers, and — split
+// form — the hand-off (write-through slabs, ticket, slab reads) or the second launch.
+static long long sk_inkernel_max() {
+    static const long long v = (long long)sk_env("WTK_SK_INKERNEL_MAX_KB", 4096) * 1024;
+    return v;
+}
+static double sk_choose(long long M, int cout_pad, int nk, int NA, int num_cus, int split, int *tile, int *form) {
+    const int force_tile = sk_env("WTK_SK_TILE", -1); // tuning switches: 0 128x128, 1 128x64, 2 64x64, 3 64x32 (where the couts allow)
+    const int force_form = sk_env("WTK_SK_FORM", -1); // 0: always S = NA, 1: always S = 1
+    struct Cand {
+        int bm, bn, id;
+    };
+    const Cand cands[4] = {{128, 128, 0}, {128, 64, 1}, {64, 64, 2}, {64, 32, 3}};
+    const double cus = (double)num_cus;
+    double best_t = 1e30;
+    int best_tile = 3, best_S = NA;
+    for (const Cand &c : cands) {
+        if (cout_pad % c.bn) continue;
+        if (force_tile >= 0 && c.id != force_tile && !(cout_pad % cands[force_tile].bn)) continue;
+        for (int S : {1, NA}) {
+            if (force_form == 0 && S != NA) continue;
+            if (force_form == 1 && S != 1) continue;
+            const double tiles = (double)((M + c.bm - 1) / c.bm) * (cout_pad / c.bn);
+            const double blocks = tiles * S;
+            const double rounds = std::ceil(blocks / cus);
+            const double steps = std::ceil((double)nk / S);
+            const double stage_kb = (c.bm + c.bn) * 128.0 / 1024.0;
+            // (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU gets ~40 KB/us of operands through its LDS-DMA requests
+            // whether the chip is full or not, and with one block per CU nothing overlaps the multiply that follows — 16 cycles per v_mfma_f32_16x16x32_f16,
+            // three per tile pair in split mode, eight 32-cycle v_mfma_f32_16x16x4_f32 in fp32 mode, four SIMDs, ~2.2 GHz —; the in-kernel hand-off costs
+            // ~4 us + the combining block's slab reads at ~60 KB/us; a second launch ~3 us + the slabs at ~5 MB/us)
+            const double mfma_us = (c.bm / 16) * (c.bn / 16) * (split ? 3.0 * 16.0 : 8.0 * 32.0) / 4.0 / 2200.0;
+            double t = rounds * (1.9 + steps * (stage_kb / 40.0 + mfma_us));
+            if (S > 1) {
+                const double slab_bytes = (double)S * M * cout_pad * 4.0;
+                const double tile_kb = c.bm * c.bn * 4.0 / 1024.0;
+                t += slab_bytes <= (double)sk_inkernel_max() ? 4.0 + S * tile_kb / 60.0 : 3.0 + slab_bytes / 5.0e6;
+            }
+            if (t < best_t) best_t = t, best_tile = c.id, best_S = S;
+            if (NA == 1) break;
+        }
+    }
+    *tile = best_tile, *form = best_S;
+    return best_t;
+}
+
+// K atoms of a layer on a handle whose calls bring up to M output pixels: the count (1..8, atoms of at least four steps) the cost model likes best at M — 272
+// blocks on 256 CUs are two rounds, 238 are one.  A function of the layer and the HANDLE (its max_batch), never of the call: batch invariance holds.
+int conv_sk_plan_atoms(long long M, int cout_pad, int nk, int num_cus, int split) {
+    const int dflt = conv_sk_slices(nk);
+    int tile, form;
+    double best_t = sk_choose(M, cout_pad, nk, dflt, num_cus, split, &tile, &form);
+    int best = dflt;
+    for (int na = 1; na <= 8; ++na) {
+        if (na == dflt || (na > 1 && nk / na < 4)) continue;
+        const double t = sk_choose(M, cout_pad, nk, na, num_cus, split, &tile, &form);
+        if (t < best_t - 0.5) best_t = t, best = na; // (the default unless clearly better)
+    }
+    return best;
+}
+
 bool conv_sk_eligible(const ConvArgs &a, int split) {
     const int esz = split ? 2 : 4;
     const int cin_real = split ? a.Cin / 2 : a.Cin;
@@ -484,17 +546,17 @@ bool conv_sk_eligible(const ConvArgs &a, int split) {
     return true;
 }
 
-size_t conv_sk_partial_bytes(const ConvArgs &a, int split) {
+size_t conv_sk_partial_bytes(const ConvArgs &a, int split, int atoms) {
     const int esz = split ? 2 : 4;
     const int nk = (int)((long long)a.Kpad * esz / 128);
-    const int S = conv_sk_slices(nk);
+    const int S = atoms > 0 ? atoms : conv_sk_slices(nk);
     return S > 1 ? (size_t)S * (size_t)a.M * a.CoutPad * sizeof(float) : 0;
 }
 
 size_t conv_sk_ticket_count(long long M, int cout_pad) { return (size_t)((M + 63) / 64) * (size_t)(cout_pad / 32); } // the smallest tile: 64 px x 32 couts
 
 // `a` as the implicit-GEMM launchers take it (split: pseudo-channel arguments); `partial` = conv_sk_partial_bytes(a, split) bytes of scratch of this op
-hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
+hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
     if (!conv_sk_eligible(a, split)) return hipErrorInvalidValue;
     const int esz = split ? 2 : 4;
     SkArgs k;
@@ -508,7 +570,8 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned
     k.cpb = a.Cin * esz / 128;
     k.KW = a.KW, k.stride = a.stride, k.pad = a.pad;
     k.nk = (int)((long long)a.Kpad * esz / 128);
-    k.NA = conv_sk_slices(k.nk);
+    k.NA = atoms > 0 ? atoms : conv_sk_slices(k.nk);
+    if (k.NA > 8 || k.NA > k.nk) return hipErrorInvalidValue;
     k.S = k.NA;
     k.w = reinterpret_cast<const char *>(a.w), k.w_rowb = (unsigned)k.nk * 128u;
     k.bias = a.bias;
@@ -526,49 +589,13 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned
     if (k.NA > 1 && !partial) return hipErrorInvalidValue;
     if ((k.in2 != nullptr) != (k.in2_blocks > 0) || k.in2_blocks > k.cpb) return hipErrorInvalidValue;
     // ---- form (S = 1: one block per tile walks every atom; S = NA: one block per atom + slab combination) and tile, per launch: neither enters the
-    // arithmetic (see the header).  A small cost model in microseconds, calibrated on profiles/r05_notes.md's forced-tile timelines: blocks run one per
-    // CU (96-128 KB of LDS) in rounds; a block costs a fixed latency chain, its operand bytes at what a CU's memory path delivers, and — split
-    // form — the hand-off (write-through slabs, ticket, slab reads) or the second launch.
-    const int force_tile = sk_env("WTK_SK_TILE", -1); // tuning switches: 0 128x128, 1 128x64, 2 64x64, 3 64x32 (where the couts allow)
-    const int force_form = sk_env("WTK_SK_FORM", -1); // 0: always S = NA, 1: always S = 1
-    static const long long inkernel_max = (long long)sk_env("WTK_SK_INKERNEL_MAX_KB", 4096) * 1024;
-    struct Cand {
-        int bm, bn, id;
-    };
-    const Cand cands[4] = {{128, 128, 0}, {128, 64, 1}, {64, 64, 2}, {64, 32, 3}};
-    const double cus = (double)num_cus;
-    double best_t = 1e30;
+    // arithmetic (see the header).  sk_choose() is the cost model.
     int best_tile = 3, best_S = k.NA;
-    for (const Cand &c : cands) {
-        if (a.CoutPad % c.bn) continue;
-        if (force_tile >= 0 && c.id != force_tile && !(a.CoutPad % cands[force_tile].bn)) continue;
-        for (int S : {1, k.NA}) {
-            if (force_form == 0 && S != k.NA) continue;
-            if (force_form == 1 && S != 1) continue;
-            const double tiles = (double)((a.M + c.bm - 1) / c.bm) * (a.CoutPad / c.bn);
-            const double blocks = tiles * S;
-            const double rounds = std::ceil(blocks / cus);
-            const double steps = std::ceil((double)k.nk / S);
-            const double stage_kb = (c.bm + c.bn) * 128.0 / 1024.0;
-            // (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU gets ~40 KB/us of operands through its LDS-DMA requests
-            // whether the chip is full or not, and with one block per CU nothing overlaps the multiply that follows — 16 cycles per v_mfma_f32_16x16x32_f16,
-            // three per tile pair in split mode, eight 32-cycle v_mfma_f32_16x16x4_f32 in fp32 mode, four SIMDs, ~2.2 GHz —; the in-kernel hand-off costs
-            // ~4 us + the combining block's slab reads at ~60 KB/us; a second launch ~3 us + the slabs at ~5 MB/us)
-            const double mfma_us = (c.bm / 16) * (c.bn / 16) * (split ? 3.0 * 16.0 : 8.0 * 32.0) / 4.0 / 2200.0;
-            double t = rounds * (1.9 + steps * (stage_kb / 40.0 + mfma_us));
-            if (S > 1) {
-                const double slab_bytes = (double)S * a.M * a.CoutPad * 4.0;
-                const double tile_kb = c.bm * c.bn * 4.0 / 1024.0;
-                t += slab_bytes <= (double)inkernel_max ? 4.0 + S * tile_kb / 60.0 : 3.0 + slab_bytes / 5.0e6;
-            }
-            if (t < best_t) best_t = t, best_tile = c.id, best_S = S;
-            if (k.NA == 1) break;
-        }
-    }
+    const double best_t = sk_choose(a.M, a.CoutPad, k.nk, k.NA, num_cus, split, &best_tile, &best_S);
     k.S = best_S;
     if (sk_env("WTK_SK_VERBOSE", 0))
         std::fprintf(stderr, "conv_sk: M %lld cout %d nk %d atoms %d -> tile %d form S=%d (est %.1f us)\n", a.M, a.CoutPad, k.nk, k.NA, best_tile, best_S, best_t);
-    k.tickets = (k.S > 1 && (long long)k.S * a.M * a.CoutPad * 4 <= inkernel_max) ? tickets : nullptr;
+    k.tickets = (k.S > 1 && (long long)k.S * a.M * a.CoutPad * 4 <= sk_inkernel_max()) ? tickets : nullptr;
     hipError_t e;
     switch (best_tile) {
     case 0: e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st); break;

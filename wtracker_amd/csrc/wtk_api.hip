@@ -1,5 +1,8 @@
 // C ABI of libwtk_hip.so (see include/wtk_hip.h): handle management, YOLOv8 graph planning
 // (channel-slice views instead of concat/upsample tensors), weight packing and kernel launches.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "../../include/wtk_hip.h"
 #include "wtk_kernels.h"
 
@@ -499,6 +502,7 @@ struct Op {
     double macs_per_image = 0;
     int spec = -1; // index of the (first) conv blob this op computes, for wtk_yolo_debug_tensor
     int sk = 0;                  // latency plan: this conv runs on conv_sk_kernel (split-K implicit GEMM, conv_sk.hip)
+    int sk_atoms = 0;            // ... with this many K atoms (conv_sk_slices(nk), or conv_sk_plan_atoms on a small throughput-plan handle)
     float *sk_partial = nullptr; // ... and this is its slab scratch ([slices][max_batch * ho * wo][cout_pad] fp32; null: one slice)
     unsigned *sk_tickets = nullptr; // ... and the arrival counters of its tiles (zero between launches; null: one slice, or WTK_SK_FINISH=1)
 };
@@ -595,6 +599,7 @@ struct wtk_yolo {
     std::vector<GraphEntry> graphs;
     std::vector<GraphEntry> seen_once; // caller-buffer argument sets met once (exec == nullptr): captured when they come back
     int graph_max_batch = 16; // WTK_GRAPH_MAX_BATCH; 0 disables
+    int graph_host = 0;       // WTK_GRAPH_HOST=1: a throughput-plan handle replays captures for its host entry points too (latency-plan handles always do)
     int graph_views = 0;      // WTK_GRAPH_VIEWS=1: wtk_yolo_predict_views replays captures too (measured in round 4: no gain, so off by default)
     hipStream_t host_stream = nullptr; // stream of the *_host entry points (graph capture needs a non-null stream)
     int ev_created = 0;
@@ -898,6 +903,35 @@ struct Planner {
 };
 } // namespace
 
+// WTK_SEGV_BACKTRACE=1 (tests/conftest.py sets it): a SIGSEGV prints the native frames to stderr before the handler that was installed before this
+// library was loaded runs (under pytest: Python's faulthandler, which adds the Python stack and re-raises).  Diagnostic only; off by default.
+namespace {
+struct sigaction g_old_segv;
+void segv_backtrace(int sig, siginfo_t *info, void *ctx) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "\nwtracker_amd: SIGSEGV, native frames:\n";
+    if (write(2, msg, sizeof(msg) - 1) < 0) {}
+    backtrace_symbols_fd(frames, n, 2);
+    if ((g_old_segv.sa_flags & SA_SIGINFO) && g_old_segv.sa_sigaction)
+        g_old_segv.sa_sigaction(sig, info, ctx);
+    else if (!(g_old_segv.sa_flags & SA_SIGINFO) && g_old_segv.sa_handler != SIG_DFL && g_old_segv.sa_handler != SIG_IGN)
+        g_old_segv.sa_handler(sig);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+__attribute__((constructor)) void install_segv_backtrace() {
+    const char *e = std::getenv("WTK_SEGV_BACKTRACE");
+    if (!e || e[0] != '1') return;
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = segv_backtrace;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    (void)sigaction(SIGSEGV, &sa, &g_old_segv);
+}
+} // namespace
+
 // Status words live in ONE pinned, device-mapped page per process, handed out by slot and never freed (a handle is a few hundred allocations already; pinning
 // and unpinning host memory per handle — hundreds of times in a test run — is a driver operation that has no business on that path).
 namespace {
@@ -1029,6 +1063,7 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     }
     if (h->latency) h->use_tail = 0;
     if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
+    if (const char *e = std::getenv("WTK_GRAPH_HOST")) h->graph_host = e[0] == '1';
     if (const char *e = std::getenv("WTK_GRAPH_VIEWS")) h->graph_views = e[0] == '1';
 
     Planner P{h, specs, d->convs};
@@ -1252,8 +1287,14 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
             }
             if (sk_mixed && (long long)h->max_batch * h->bufs[op.out_buf].h * h->bufs[op.out_buf].w > sk_mixed_max_px) continue;
             op.sk = 1;
-            const int S = conv_sk_slices(op.k * op.k * op.cin / 32);
             const Buf &ob = h->bufs[op.out_buf];
+            // K atoms: the layer's default — or, on a small throughput-plan handle, the count the launcher's cost model likes best for this handle's
+            // largest call (a cycle batch's 12 x 12 maps: eight atoms x 34 tiles are 272 blocks = two rounds on 256 CUs, seven are one round).  Fixed per
+            // handle.  WTK_SK_PLAN_ATOMS=0: the default everywhere.
+            const int nk_op = op.k * op.k * op.cin / 32;
+            const bool plan_atoms = sk_mixed && !(std::getenv("WTK_SK_PLAN_ATOMS") && std::getenv("WTK_SK_PLAN_ATOMS")[0] == '0');
+            op.sk_atoms = plan_atoms ? conv_sk_plan_atoms((long long)h->max_batch * ob.h * ob.w, op.cout_pad, nk_op, h->num_cus, h->split) : conv_sk_slices(nk_op);
+            const int S = op.sk_atoms;
             if (S > 1 && dev_alloc(h, (void **)&op.sk_partial, (size_t)S * h->max_batch * ob.h * ob.w * op.cout_pad * sizeof(float))) {
                 wtk_yolo_destroy(h);
                 return 1;
@@ -1679,7 +1720,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             if (op.sk) {
                 a.tile_w = 0;
                 if (!conv_sk_eligible(a, h->split)) return fail("internal: conv " + std::to_string(oi) + " of the latency plan does not fit conv_sk_kernel");
-                HIP_TRY(launch_conv_sk(a, h->split, op.sk_partial, op.sk_tickets, h->num_cus, st));
+                HIP_TRY(launch_conv_sk(a, h->split, op.sk_atoms, op.sk_partial, op.sk_tickets, h->num_cus, st));
             } else if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
                 split_s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0 && !ob.f32)) {
                 // strided 3x3, split operands: the parity-plane window kernel on pseudo-channels
@@ -1931,7 +1972,10 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
     // With WTK_GRAPH_VIEWS=1 a latency-plan handle also replays for caller buffers: an argument set is captured the second time it is met, so a caller
     // that rotates its buffers never pays for a capture.
-    const bool use_graph = (own_buffers || (h->latency && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
+XX
+    // graph code: hundreds per test run); WTK_GRAPH_HOST=1 brings the replay back for their host entry points.
+    const bool use_graph = ((own_buffers && (h->latency || h->graph_host)) || (h->latency && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 &&
+                           B <= h->graph_max_batch;
     if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
     wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
     if (!own_buffers) {

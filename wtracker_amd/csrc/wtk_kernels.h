@@ -203,10 +203,12 @@ hipError_t conv_init_attributes();
 // Small-batch (latency) plan: split-K implicit GEMM, split-fp16 or fp32 operands (conv_sk.hip).  `a` as launch_conv_split / launch_conv take it.
 int conv_sk_slices(int nk); // K slices of a layer of nk steps (32 channels of one tap each): a function of the layer alone
 bool conv_sk_eligible(const ConvArgs &a, int split);
-size_t conv_sk_partial_bytes(const ConvArgs &a, int split); // scratch of the op: [slices][M][CoutPad] fp32 (0: one slice)
+// K atoms of a layer for a handle whose calls bring up to M output pixels (cost model at M; the default conv_sk_slices(nk) unless clearly better)
+int conv_sk_plan_atoms(long long M, int cout_pad, int nk, int num_cus, int split);
+size_t conv_sk_partial_bytes(const ConvArgs &a, int split, int atoms = 0); // scratch of the op: [atoms][M][CoutPad] fp32 (0: one atom); atoms = 0: conv_sk_slices
 // tickets: conv_sk_ticket_count(a) zero-initialised counters of this op (the last block of a tile combines the slabs in-kernel), or null (second launch: sk_finish_kernel)
 size_t conv_sk_ticket_count(long long M, int cout_pad);
-hipError_t launch_conv_sk(const ConvArgs &a, int split, float *partial, unsigned *tickets, int num_cus, hipStream_t stream);
+hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t stream); // atoms = 0: conv_sk_slices(nk)
 // fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
 hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream);
