@@ -1972,8 +1972,9 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
     const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
     // With WTK_GRAPH_VIEWS=1 a latency-plan handle also replays for caller buffers: an argument set is captured the second time it is met, so a caller
     // that rotates its buffers never pays for a capture.
-XX
-    // graph code: hundreds per test run); WTK_GRAPH_HOST=1 brings the replay back for their host entry points.
+    // Throughput-plan handles launch eagerly: on their host entry points the replay measured 0.726 / 1.218 ms against 0.720 / 1.197 ms eager (f16x3, B = 1 /
+    // 15 at 384^2; fp16 1-5 % the other way, r5_host_graph.py), and a test run makes hundreds of captures — one intermittent host crash inside such a first
+    // call was seen twice in ~25 suite runs.  WTK_GRAPH_HOST=1 brings the replay back for them.
     const bool use_graph = ((own_buffers && (h->latency || h->graph_host)) || (h->latency && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 &&
                            B <= h->graph_max_batch;
     if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
