@@ -1288,12 +1288,14 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
             if (sk_mixed && (long long)h->max_batch * h->bufs[op.out_buf].h * h->bufs[op.out_buf].w > sk_mixed_max_px) continue;
             op.sk = 1;
             const Buf &ob = h->bufs[op.out_buf];
-            // K atoms: the layer's default — or, on a small throughput-plan handle, the count the launcher's cost model likes best for this handle's
-            // largest call (a cycle batch's 12 x 12 maps: eight atoms x 34 tiles are 272 blocks = two rounds on 256 CUs, seven are one round).  Fixed per
-            // handle.  WTK_SK_PLAN_ATOMS=0: the default everywhere.
+            // K atoms: the count the launcher's cost model likes best for what this handle is for — a small throughput-plan handle's largest call (a cycle
+            // batch's 12 x 12 maps: eight atoms x 34 tiles are 272 blocks = two rounds on 256 CUs, seven are one round), a latency-plan handle's single frame
+            // (0.529 -> 0.515 ms at 384 x 384) — and the layer's default where the model sees no difference.  Fixed per handle, so a frame's result does not
+            // depend on its batch.  WTK_SK_PLAN_ATOMS=0: the default count everywhere.
             const int nk_op = op.k * op.k * op.cin / 32;
-            const bool plan_atoms = sk_mixed && !(std::getenv("WTK_SK_PLAN_ATOMS") && std::getenv("WTK_SK_PLAN_ATOMS")[0] == '0');
-            op.sk_atoms = plan_atoms ? conv_sk_plan_atoms((long long)h->max_batch * ob.h * ob.w, op.cout_pad, nk_op, h->num_cus, h->split) : conv_sk_slices(nk_op);
+            const bool plan_atoms = !(std::getenv("WTK_SK_PLAN_ATOMS") && std::getenv("WTK_SK_PLAN_ATOMS")[0] == '0');
+            const long long plan_px = (long long)(h->latency ? 1 : h->max_batch) * ob.h * ob.w;
+            op.sk_atoms = plan_atoms ? conv_sk_plan_atoms(plan_px, op.cout_pad, nk_op, h->num_cus, h->split) : conv_sk_slices(nk_op);
             const int S = op.sk_atoms;
             if (S > 1 && dev_alloc(h, (void **)&op.sk_partial, (size_t)S * h->max_batch * ob.h * ob.w * op.cout_pad * sizeof(float))) {
                 wtk_yolo_destroy(h);
