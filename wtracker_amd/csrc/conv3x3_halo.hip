@@ -203,7 +203,8 @@ __device__ __forceinline__ void halo_out_pixel(const HaloArgs &a, int o_first, i
 }
 __device__ __forceinline__ int lane_fetch(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane * 4, v); }
 
-// HROWS: window rows one LDS buffer holds.  NWB: weight slabs in the ring.  With NWB == 3 the slab of tap g+2 is
+// HROWS: window rows one LDS buffer holds.  NWB: weight slabs in the ring (2, 3, or 6: the split 64-cout x 128-pixel tile of small handles, see the
+// tap loop).  With NWB == 3 the slab of tap g+2 is
 // requested while tap g is multiplied and a COUNTED s_waitcnt vmcnt leaves it in flight across the tap barrier
 // (raw s_barrier): a slab has two full taps to arrive instead of one.  PMC on the two-slab kernel showed every wave
 // waiting ~1/3 of its life in the vmcnt(0) that __syncthreads puts in front of each tap barrier (1 block per CU:

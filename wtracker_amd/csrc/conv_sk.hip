@@ -14,8 +14,8 @@
 // store; it also re-arms the ticket).  sk_finish_kernel is the same combination as a second launch (WTK_SK_FINISH=1): a dependent launch costs
 // ~4.7 us here, which is what a small layer's whole convolution costs.  Both forms add the slabs in the same order: bit-identical.
 //
-// Determinism and batch invariance.  K is cut into ATOMS — a function of the LAYER alone (conv_sk_slices: <= 12 steps: one atom; else atoms of ~8
-// steps, at most 8) — and an output value is DEFINED as ((A_0 + A_1) + A_2) + ..., A_i = the MFMA chain over atom i's steps started from zero
+// Determinism and batch invariance.  K is cut into ATOMS — fixed per layer and HANDLE, never per call (conv_sk_slices: <= 12 steps: one atom; else atoms
+// of ~8 steps, at most 8; conv_sk_plan_atoms: the count the cost model below likes best for the handle's typical call) — and an output value is DEFINED as ((A_0 + A_1) + A_2) + ..., A_i = the MFMA chain over atom i's steps started from zero
 // (split mode: acc + 2^-11 acc1 of that chain).  Two launch forms produce exactly that value:
 //   S = NA  one block per (tile, atom): A_i goes to slab i, the combining block adds the slabs in atom order;
 //   S = 1   one block walks all atoms through one continuous ring and folds A_i into its running total at every atom boundary
@@ -450,7 +450,7 @@ template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS> hipError
 
 } // namespace
 
-// K slices of a layer with nk steps of 32 channels: a function of the layer alone (see the header: batch invariance)
+// Default K atoms of a layer with nk steps of 32 channels: a function of the layer alone (see the header: batch invariance; conv_sk_plan_atoms refines it per handle)
 // nk <= sk_single_max(): one block walks the whole K through the ring (no slabs, no hand-off); above it slices of ~sk_slice_steps() steps, at most 8
 // slices (the combining block reads all slabs in ONE round trip).  WTK_SK_SINGLE_MAX / WTK_SK_SLICE_STEPS: tuning switches, read once per process.
 static int sk_env(const char *name, int dflt) {

@@ -201,7 +201,7 @@ hipError_t launch_conv(const ConvArgs &a, int cfg, int is_f16, hipStream_t strea
 hipError_t launch_conv_split(const ConvArgs &a, int cfg, hipStream_t stream); // split-fp16 operands (see kSplitScale above)
 hipError_t conv_init_attributes();
 // Small-batch (latency) plan: split-K implicit GEMM, split-fp16 or fp32 operands (conv_sk.hip).  `a` as launch_conv_split / launch_conv take it.
-int conv_sk_slices(int nk); // K slices of a layer of nk steps (32 channels of one tap each): a function of the layer alone
+int conv_sk_slices(int nk); // default K atoms of a layer of nk steps (32 channels of one tap each): a function of the layer alone
 bool conv_sk_eligible(const ConvArgs &a, int split);
 // K atoms of a layer for a handle whose calls bring up to M output pixels (cost model at M; the default conv_sk_slices(nk) unless clearly better)
 int conv_sk_plan_atoms(long long M, int cout_pad, int nk, int num_cus, int split);
