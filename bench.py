@@ -157,7 +157,7 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     tmp.close()
     ys.save_weights(tmp.name, weights, scale, nc)
 
-    def drive(make):
+    def drive(make, deferred=False):
         tc = TimingConfig(ec, 200, 40, 50, (4, 4), (0.32, 0.32))
         assert (tc.imaging_frame_num, tc.pred_frame_num, tc.moving_frame_num, tc.cycle_frame_num, tc.camera_size_px) == (12, 3, 3, 15, (360, 360))
         ctrl = make(tc)
@@ -189,7 +189,7 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
             ends.append(time.perf_counter())
 
         ctrl.on_cycle_end = cycle_end
-        log = TrackLogger(ctrl)
+        log = TrackLogger(ctrl, deferred=deferred)
         t0 = time.perf_counter()
         Simulator(tc, ec, log, reader=ArrayReader(frames_np)).run()
         dt = time.perf_counter() - t0
@@ -203,10 +203,12 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
            "frames": f"{ec.num_frames} synthetic {size}x{size} uint8 gray frames resident in HBM, camera view 360x360 -> imgsz 384, conf {conf}",
            "timing_ms": [200, 40, 50], "cycle_frames": 15, "cycles": cycles, "calls_per_cycle": "one B=15 _cycle_predict_all + one B=1 provide_movement_vector"}
     ref_moves = None
-    for dtype, plan in (("f16x3", "auto"), ("fp32", "auto"), ("f16x3", "latency"), ("f16x3", "throughput")):
+    rows_of = {}
+    for dtype, plan, deferred in (("f16x3", "auto", False), ("fp32", "auto", False), ("f16x3", "latency", False), ("f16x3", "throughput", False), ("f16x3", "auto", True),
+                                  ("fp32", "auto", True)):
         cfg = YoloConfig(model_path=tmp.name, device=f"cuda:{device}", pred_kwargs={"imgsz": 384, "conf": conf}, dtype=dtype, scale=scale, max_batch=16, plan=plan)
-        drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))  # warm-up pass: handle creation, captures
-        res, moves, _ = drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames))
+        drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames), deferred)  # warm-up pass: handle creation, captures
+        res, moves, rows = drive(lambda tc: HipYoloController(tc, cfg, device_frames=dev_frames), deferred)
         for det in cfg.model._dets.values():
             det.close()
         cfg.model = None
@@ -214,7 +216,14 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
         if ref_moves is None:
             ref_moves = moves
         res["moves_equal_first_mode"] = moves == ref_moves
-        out[f"{dtype}_{plan}"] = res
+        if deferred:
+            res["rows_equal_immediate_log"] = rows == rows_of[(dtype, plan)]
+        else:
+            rows_of[(dtype, plan)] = rows
+        out[f"{dtype}_{plan}" + ("_deferred_log" if deferred else "")] = res
+    out["deferred_log"] = ("*_deferred_log = the same loop under TrackLogger(deferred=True): the cycle batch — which feeds nothing back into the loop — is enqueued at the "
+                           "cycle's end on the controller's second lane and its rows are written one cycle later, so it runs on the GPU beside the next cycle's single-frame "
+                           "call (a handle each under plan 'auto'); same moves, same rows, the last batch collected inside the timed run")
     out["plans"] = ("*_auto = YoloConfig.plan 'auto' (the default): the single-frame call on a latency-plan handle (split-K convs, conv_sk.hip, replayed hipGraph), the "
                     "15-frame call on a throughput-plan handle — each call on the plan that is faster for it; f16x3_latency = both calls on ONE latency-plan handle (a frame's "
                     "result is bit-identical whichever call sees it); f16x3_throughput = both calls on the large-batch kernels (what every call ran on before round 5)")
@@ -286,7 +295,7 @@ def compact_line(detail: dict) -> dict:
     if hc:
         line["headline_check"] = {k: _r(hc[k]) for k in ("frames", "index_mismatches", "box_abs_diff_max_px", "verified")}
     for k, v in detail.items():
-        if k.startswith("value_") or k.startswith("latency_") or k == "closed_loop_f16x3_frames_per_s":
+        if k.startswith("value_") or k.startswith("latency_") or k in ("closed_loop_f16x3_frames_per_s", "closed_loop_f16x3_deferred_log_frames_per_s"):
             line[k] = _r(v)
     if "dist" in detail:
         d = detail["dist"]
@@ -835,6 +844,8 @@ def main():
         out["closed_loop"] = closed
         if "f16x3_auto" in closed:
             out["closed_loop_f16x3_frames_per_s"] = closed["f16x3_auto"]["frames_per_s"]
+        if "f16x3_auto_deferred_log" in closed:
+            out["closed_loop_f16x3_deferred_log_frames_per_s"] = closed["f16x3_auto_deferred_log"]["frames_per_s"]
     if lat is not None:
         out["latency"] = lat
         # two scalars per reference-precision mode in the main line: the reference's two calls, each on the plan the controller's default ("auto":

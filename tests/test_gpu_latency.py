@@ -420,7 +420,7 @@ def test_closed_loop_controller_on_every_plan_equals_the_oracle_controller(hip_l
     frames, _ = fr.synthetic_frames(40, 256, seed=8)
     ec = ExperimentConfig("synthetic", 40, 60, (256, 256), 32, (128, 128))
 
-    def run(make):
+    def run(make, deferred=False):
         tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.5, 0.5))
         ctrl = make(tc)
         moves = []
@@ -432,7 +432,7 @@ def test_closed_loop_controller_on_every_plan_equals_the_oracle_controller(hip_l
             return m
 
         ctrl.provide_movement_vector = wrapped
-        log = TrackLogger(ctrl)
+        log = TrackLogger(ctrl, deferred=deferred)
         Simulator(tc, ec, log, reader=ArrayReader(frames)).run()
         return moves, log.rows, ctrl
 
@@ -445,6 +445,11 @@ def test_closed_loop_controller_on_every_plan_equals_the_oracle_controller(hip_l
     assert m_g == m_o and len(m_g) == 4
     m_d, rows_d, _ = run(lambda tc: HipYoloController(tc, cfg, device_frames=torch.from_numpy(frames).cuda()))
     assert m_d == m_g and rows_d == rows_g
+    # the deferred track log: the cycle batch enqueued on the controller's second lane and collected a cycle later (plan "auto": it runs beside the next
+    # single-frame call on a handle of its own; one shared handle: the lanes take turns) — same moves, same rows
+    m_p, rows_p, ctrl_p = run(lambda tc: HipYoloController(tc, cfg, device_frames=torch.from_numpy(frames).cuda()), deferred=True)
+    assert m_p == m_g and rows_p == rows_g
+    assert sorted(k[0] for k in ctrl_p._view_bufs) == [0, 1] and not ctrl_p._inflight
     assert len(rows_g) == len(rows_o) == 36
     for a, b in zip(rows_g, rows_o):
         assert (a["frame"], a["cycle"], a["phase"], a["plt_x"], a["plt_y"]) == (b["frame"], b["cycle"], b["phase"], b["plt_x"], b["plt_y"])

@@ -176,3 +176,44 @@ def test_polyfit_at_the_highest_admitted_degree_matches_reference(golden_dir):
             warnings.simplefilter("ignore")  # numpy's RankWarning on the under-determined first cycles (the reference gets it too)
             _, moves = run(lambda tc: PolyfitController(tc, cfg, init))
         assert moves == c["moves"], name
+
+
+def test_deferred_track_log_writes_the_same_rows(golden_dir, tmp_path):
+    """TrackLogger(deferred=True) with a controller that offers the asynchronous cycle batch (here: CsvController behind a token that is only
+    evaluated at collection time) writes the rows of the reference's log, one cycle late and the last batch at on_sim_end; without the
+    asynchronous pair it behaves as the immediate logger."""
+    init = os.path.join(golden_dir, "sim_init_bboxes.csv")
+    golden = read_log(os.path.join(golden_dir, "sim_csv_bboxes.csv"))
+    ec = ExperimentConfig(**EXP0)
+    tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.32, 0.32))
+
+    class AsyncCsv(CsvController):
+        launched = collected = 0
+
+        def _cycle_predict_all_async(self, sim):
+            AsyncCsv.launched += 1
+            return {"rows": CsvController._cycle_predict_all(self, sim)}  # a real controller would only enqueue here
+
+        def _cycle_collect(self, token):
+            AsyncCsv.collected += 1
+            return token["rows"]
+
+    path = tmp_path / "deferred.csv"
+    log = TrackLogger(AsyncCsv(tc, init), csv_path=str(path), deferred=True)
+    seen = []
+    inner = log.on_cycle_end
+
+    def spy(sim):
+        inner(sim)
+        seen.append(len(log.rows))
+
+    log.on_cycle_end = spy
+    Simulator(tc, ec, log).run()
+    n = tc.cycle_frame_num
+    assert seen[:3] == [0, n, 2 * n]  # a cycle's rows appear at the NEXT cycle's end
+    assert AsyncCsv.launched == AsyncCsv.collected and AsyncCsv.launched >= 3
+    assert_rows_equal(log.rows, golden)
+    assert_rows_equal(read_log(str(path)), golden)
+    plain = TrackLogger(CsvController(tc, init), deferred=True)  # no asynchronous pair: immediate rows
+    Simulator(tc, ec, plain).run()
+    assert_rows_equal(plain.rows, golden)

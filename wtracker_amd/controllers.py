@@ -403,8 +403,9 @@ class HipYoloController(SimController):
         self._model = yolo_config.load_model()
         self._device_frames = device_frames
         self.last_rechecked = 0  # frames of the last predict call that were detected again at full precision (YoloConfig.recheck_margin)
-        self._view_stream = None  # device-resident path: the controller's own stream + per-batch-size buffers (predict_views)
+        self._view_streams: dict = {}  # device-resident path: the controller's own stream per lane + buffers per (lane, batch size) (launch_views)
         self._view_bufs: dict = {}
+        self._inflight: dict = {}  # id(detector handle) -> token of the call that may still run on it
         if device_frames is not None:
             if not getattr(device_frames, "is_cuda", False) or str(device_frames.dtype) != "torch.uint8" or device_frames.dim() not in (3, 4):
                 raise hip.WtkError("device_frames must be a CUDA uint8 tensor [F,H,W] or [F,H,W,3]")
@@ -459,6 +460,12 @@ class HipYoloController(SimController):
     def predict_views(self, entries) -> np.ndarray:
         """`entries`: (frame number, position x, position y, (view_w, view_h)) tuples recorded by on_camera_frame.  Same return
         convention as predict(): [N,4] xywh in VIEW pixels, NaN rows for frames without a detection."""
+        return self.collect_views(self.launch_views(entries))
+
+    def launch_views(self, entries, lane: int = 0) -> dict:
+        """First half of predict_views: enqueue the view cut + letterbox + detector for `entries` on the controller's stream of `lane` and return a
+        token for collect_views().  Nothing is waited for.  Lane 1 is what the deferred track log uses for the cycle batch: it runs beside the next
+        cycle's single-frame call (lane 0) instead of in front of it.  Tokens of one lane must be collected before that lane launches again."""
         import torch
 
         assert len(entries) > 0
@@ -469,25 +476,33 @@ class HipYoloController(SimController):
             raise TypeError("predict() got multiple values for keyword argument 'max_det'")
         vw, vh = entries[0][3]
         n = len(entries)
-        det = self._model.detector(yolo_spec.letterbox_shape(vw, vh, imgsz), n)  # the view's shape is (rows = w, cols = h)
+        net_hw = yolo_spec.letterbox_shape(vw, vh, imgsz)  # the view's shape is (rows = w, cols = h)
+        det = self._model.detector(net_hw, n)
         dev = fr.device
-        # One set of device buffers per batch size, kept for the controller's life: the view table (frame numbers + positions, one small upload
+        # One set of device buffers per (lane, batch size), kept for the controller's life: the view table (frame numbers + positions, one small upload
         # per call from pinned memory) and the output rows.  The library replays a captured forward pass for a call that comes back with the same
         # device addresses (wtk_yolo_predict_views: the reference's operating point — one cycle batch and one single-frame call per cycle — is
         # launch bound), which needs a stream of the controller's own: the legacy default stream cannot be captured.
-        if self._view_stream is None:
-            self._view_stream = torch.cuda.Stream(device=dev)
+        stream = self._view_streams.get(lane)
+        if stream is None:
+            # (a high-priority stream for lane 0 — the call the loop waits for — measured 2-4 x SLOWER cycles: one more hardware queue, profiles/r05_notes.md)
+            stream = self._view_streams[lane] = torch.cuda.Stream(device=dev)
+        # A detector handle has ONE set of activation buffers: a call on another lane that still runs on the same handle (plan "latency" / "throughput":
+        # both calls of a cycle share a handle) is waited for first; with plan "auto" the two calls have a handle each and overlap.
+        busy = self._inflight.get(id(det))
+        if busy is not None and busy["lane"] != lane:
+            busy["stream"].synchronize()
         # EVERY call is ordered behind the caller's current stream (an event wait, microseconds): a caller that refills or extends `device_frames` in
         # place between cycles has its writes on that stream, and the crop / letterbox kernel must not read frames that are still being written
-        self._view_stream.wait_stream(torch.cuda.current_stream(dev))
-        bufs = self._view_bufs.get(n)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        bufs = self._view_bufs.get((lane, n))
         if bufs is None:
-            bufs = self._view_bufs[n] = dict(meta=torch.empty((3 * n,), dtype=torch.int32, device=dev), host=torch.empty((3 * n,), dtype=torch.int32).pin_memory(),
-                                             out=torch.empty((n, 4), dtype=torch.float32, device=dev), cf=torch.empty((n,), dtype=torch.float32, device=dev),
-                                             an=torch.empty((n,), dtype=torch.int32, device=dev),
-                                             # the rows come back through pinned memory: two asynchronous copies behind the forward pass on the same stream and ONE
-                                             # synchronisation (two blocking `.cpu()` calls cost ~40 us of a 0.5 ms call)
-                                             out_h=torch.empty((n, 4), dtype=torch.float32).pin_memory(), an_h=torch.empty((n,), dtype=torch.int32).pin_memory())
+            bufs = self._view_bufs[(lane, n)] = dict(meta=torch.empty((3 * n,), dtype=torch.int32, device=dev), host=torch.empty((3 * n,), dtype=torch.int32).pin_memory(),
+                                                     out=torch.empty((n, 4), dtype=torch.float32, device=dev), cf=torch.empty((n,), dtype=torch.float32, device=dev),
+                                                     an=torch.empty((n,), dtype=torch.int32, device=dev),
+                                                     # the rows come back through pinned memory: two asynchronous copies behind the forward pass on the same stream and
+                                                     # ONE synchronisation (two blocking `.cpu()` calls cost ~40 us of a 0.5 ms call)
+                                                     out_h=torch.empty((n, 4), dtype=torch.float32).pin_memory(), an_h=torch.empty((n,), dtype=torch.int32).pin_memory())
             bufs["host_np"] = bufs["host"].numpy()
         hn = bufs["host_np"]
         hn[:n] = [e[0] for e in entries]
@@ -496,26 +511,40 @@ class HipYoloController(SimController):
         meta, out, cf, an = bufs["meta"], bufs["out"], bufs["cf"], bufs["an"]
         idx, pos = meta[:n], meta[n:].view(n, 2)
         C = fr.shape[3] if fr.dim() == 4 else 1
-        net_hw = yolo_spec.letterbox_shape(vw, vh, imgsz)
-        with torch.cuda.device(dev), torch.cuda.stream(self._view_stream):
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
             meta.copy_(host, non_blocking=True)
-            det.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx, pos, n, vw, vh, out, cf, an, conf=conf, iou=iou, max_det=1,
-                              stream=self._view_stream.cuda_stream)
+            det.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx, pos, n, vw, vh, out, cf, an, conf=conf, iou=iou, max_det=1, stream=stream.cuda_stream)
             bufs["out_h"].copy_(out, non_blocking=True)
             bufs["an_h"].copy_(an, non_blocking=True)
-            self._view_stream.synchronize()
+        token = dict(lane=lane, stream=stream, det=det, bufs=bufs, n=n, view=(vw, vh), net_hw=net_hw, conf=conf, iou=iou, C=C)
+        self._inflight[id(det)] = token
+        return token
+
+    def collect_views(self, token: dict) -> np.ndarray:
+        """Second half of predict_views: wait for the token's call and return its rows."""
+        import torch
+
+        stream, det, bufs, n = token["stream"], token["det"], token["bufs"], token["n"]
+        fr = self._device_frames
+        dev = fr.device
+        stream.synchronize()
+        if self._inflight.get(id(det)) is token:
+            del self._inflight[id(det)]
         xywh, anchor = bufs["out_h"].numpy().copy(), bufs["an_h"].numpy().copy()
         _raise_on_overflow(det)
         self.last_rechecked = 0
         if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
             weak = np.nonzero(det.last_margins(n) < self.yolo_config.recheck_margin)[0]
             if len(weak):
+                vw, vh = token["view"]
+                out, cf, an = bufs["out"], bufs["cf"], bufs["an"]
+                idx, pos = bufs["meta"][:n], bufs["meta"][n:].view(n, 2)
                 wsel = torch.from_numpy(weak).to(dev)
-                det32 = self._model.detector(net_hw, len(weak), dtype=self.yolo_config.recheck_mode(self._model.nc))
+                det32 = self._model.detector(token["net_hw"], len(weak), dtype=self.yolo_config.recheck_mode(self._model.nc))
                 k = len(weak)
-                with torch.cuda.device(dev), torch.cuda.stream(self._view_stream):
-                    det32.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], C, idx[wsel].contiguous(), pos[wsel].contiguous(), k, vw, vh,
-                                        out[:k], cf[:k], an[:k], conf=conf, iou=iou, max_det=1, stream=self._view_stream.cuda_stream)
+                with torch.cuda.device(dev), torch.cuda.stream(stream):
+                    det32.predict_views(fr, fr.shape[0], fr.shape[1], fr.shape[2], token["C"], idx[wsel].contiguous(), pos[wsel].contiguous(), k, vw, vh,
+                                        out[:k], cf[:k], an[:k], conf=token["conf"], iou=token["iou"], max_det=1, stream=stream.cuda_stream)
                     xywh[weak], anchor[weak] = out[:k].cpu().numpy(), an[:k].cpu().numpy()
                 self.last_rechecked = k
         if (anchor < 0).any():
@@ -540,3 +569,13 @@ class HipYoloController(SimController):
         if self._device_frames is not None:
             return self.predict_views(list(self._camera_frames))
         return self.predict(self._camera_frames)
+
+    def _cycle_predict_all_async(self, sim):
+        """The cycle batch enqueued on lane 1 (device-resident frames only; else None): TrackLogger(deferred=True) collects it one cycle later, so the
+        batch runs on the GPU beside the next cycle's single-frame call instead of in front of it.  Same rows as _cycle_predict_all."""
+        if self._device_frames is None:
+            return None
+        return self.launch_views(list(self._camera_frames), lane=1)
+
+    def _cycle_collect(self, token) -> np.ndarray:
+        return self.collect_views(token)

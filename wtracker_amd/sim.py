@@ -113,10 +113,15 @@ class TrackLogger(SimController):
     for the whole cycle's boxes (`_cycle_predict_all` -> the batched detector call), makes them
     absolute and appends one CSV row per frame.  Rows are also kept in `self.rows`."""
 
-    def __init__(self, sim_controller: SimController, csv_path: Optional[str] = None):
+    def __init__(self, sim_controller: SimController, csv_path: Optional[str] = None, deferred: bool = False):
+        """`deferred` (extension): with a controller that offers `_cycle_predict_all_async` / `_cycle_collect` (HipYoloController on device-resident
+        frames) the cycle batch is only ENQUEUED at the cycle's end and its rows are written one cycle later (the last cycle's at on_sim_end): the
+        batch — which feeds nothing back into the loop — then runs on the GPU beside the next cycle's single-frame call.  Same rows, same file."""
         super().__init__(sim_controller.timing_config)
         self.sim_controller = sim_controller
         self.csv_path = csv_path
+        self.deferred = bool(deferred)
+        self._pending = None  # (token, cycle, platform / camera / micro positions) of the cycle batch that is still running
         n = self.timing_config.cycle_frame_num
         self._plt, self._cam, self._mic = deque(maxlen=n), deque(maxlen=n), deque(maxlen=n)
         self.rows: list = []
@@ -127,6 +132,7 @@ class TrackLogger(SimController):
         self.sim_controller.on_sim_start(sim)
         self._plt.clear(), self._cam.clear(), self._mic.clear()
         self.rows = []
+        self._pending = None
         if self.csv_path:
             self._file = open(self.csv_path, "w+", newline="")
             self._writer = csv.DictWriter(self._file, LOG_COLUMNS, escapechar=",")
@@ -140,9 +146,28 @@ class TrackLogger(SimController):
 
     def on_cycle_end(self, sim):
         cycle = sim.cycle_number - 1
+        launch = getattr(self.sim_controller, "_cycle_predict_all_async", None) if self.deferred else None
+        if launch is not None:
+            self._flush_pending()  # the previous cycle's batch has had a whole cycle to finish
+            token = launch(sim)
+            if token is not None:
+                self._pending = (token, cycle, list(self._plt), list(self._cam), list(self._mic))
+                self.sim_controller.on_cycle_end(sim)
+                self._plt.clear(), self._cam.clear(), self._mic.clear()
+                return
+        self._write_rows(self.sim_controller._cycle_predict_all(sim), cycle, self._plt, self._cam, self._mic)
+        self.sim_controller.on_cycle_end(sim)
+        self._plt.clear(), self._cam.clear(), self._mic.clear()
+
+    def _flush_pending(self):
+        if self._pending is not None:
+            token, cycle, plt, cam, mic = self._pending
+            self._pending = None
+            self._write_rows(self.sim_controller._cycle_collect(token), cycle, plt, cam, mic)
+
+    def _write_rows(self, boxes, cycle, plt, cam, mic):
         first = cycle * self.timing_config.cycle_frame_num
-        boxes = self.sim_controller._cycle_predict_all(sim)
-        cams = np.asanyarray(list(self._cam))
+        cams = np.asanyarray(list(cam))
         boxes[:, 0] += cams[:, 0]
         boxes[:, 1] += cams[:, 1]
         # The reference calls BoxUtils.discretize on this array before writing the rows, and that
@@ -151,19 +176,18 @@ class TrackLogger(SimController):
         boxes[~np.isfinite(boxes).all(axis=1)] = 0
         for i, box in enumerate(boxes):
             row = dict(frame=first + i, cycle=cycle, phase="imaging" if i < self.timing_config.imaging_frame_num else "moving")
-            row["plt_x"], row["plt_y"] = self._plt[i]
-            row["cam_x"], row["cam_y"], row["cam_w"], row["cam_h"] = self._cam[i]
-            row["mic_x"], row["mic_y"], row["mic_w"], row["mic_h"] = self._mic[i]
+            row["plt_x"], row["plt_y"] = plt[i]
+            row["cam_x"], row["cam_y"], row["cam_w"], row["cam_h"] = cam[i]
+            row["mic_x"], row["mic_y"], row["mic_w"], row["mic_h"] = mic[i]
             row["wrm_x"], row["wrm_y"], row["wrm_w"], row["wrm_h"] = box
             self.rows.append(row)
             if self._writer:
                 self._writer.writerow(row)
         if self._file:
             self._file.flush()
-        self.sim_controller.on_cycle_end(sim)
-        self._plt.clear(), self._cam.clear(), self._mic.clear()
 
     def on_sim_end(self, sim):
+        self._flush_pending()
         self.sim_controller.on_sim_end(sim)
         if self._file:
             self._file.close()
