@@ -573,7 +573,7 @@ class HipYoloController(SimController):
     def _cycle_predict_all_async(self, sim):
         """The cycle batch enqueued on lane 1 (device-resident frames only; else None): TrackLogger(deferred=True) collects it one cycle later, so the
         batch runs on the GPU beside the next cycle's single-frame call instead of in front of it.  Same rows as _cycle_predict_all."""
-        if self._device_frames is None:
+        if self._device_frames is None or self.yolo_config.recheck_margin > 0:  # (the second look reads the handle's margins of its LAST call: immediate log)
             return None
         return self.launch_views(list(self._camera_frames), lane=1)
 
