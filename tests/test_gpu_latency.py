@@ -174,15 +174,15 @@ def test_walking_all_atoms_in_one_block_equals_one_block_per_atom(hip_lib, dtype
     WTK_SK_FORM / WTK_SK_TILE force each choice for every layer: all of them must give the same logits bit for bit — that is what makes the choice
     free to depend on the batch."""
     size, B = 384, 5
-    monkeypatch.setenv("WTK_GRAPH_MAX_BATCH", "0")  # eager launches: the switches are read at launch time
-    _, det, _ = _handle(size, dtype)
     frames = fr.diverse_frames(8, size, seed=321)[:B]
     ref = None
     for form, tile in (("-1", "-1"), ("0", "-1"), ("1", "-1"), ("0", "2"), ("1", "3"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("WTK_SK_FORM", form)
+        monkeypatch.setenv("WTK_SK_FORM", form)  # read when the handle is created
         monkeypatch.setenv("WTK_SK_TILE", tile)
+        _, det, _ = _handle(size, dtype)
         x, c, a = det.predict_host(frames, conf=0.1)
         b, k = det.debug_head(B)
+        det.close()
         if ref is None:
             ref = (x, a, b, k)
             continue
@@ -190,7 +190,81 @@ def test_walking_all_atoms_in_one_block_equals_one_block_per_atom(hip_lib, dtype
         np.testing.assert_array_equal(b, ref[2], err_msg=f"form {form} tile {tile}")
         np.testing.assert_array_equal(a, ref[1])
         np.testing.assert_array_equal(x, ref[0])
-    det.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+@pytest.mark.parametrize("size,B", [(384, 1), (384, 15), (640, 2), (128, 3)])
+def test_grouped_level_launches_equal_one_launch_per_conv(hip_lib, dtype, size, B, monkeypatch):
+    """Round 6: a latency-plan handle launches the split-K convs of one dependency level (a Detect tower's box and class convs, a PAN layer next to the
+    tower of the feature map before it) as ONE grid on the caller's stream (csrc/wtk_api.hip: sk_schedule, conv_sk.hip: launch_conv_sk_group).  Grouping
+    picks one tile per launch and a form per member — neither enters the arithmetic — so EVERY conv tensor and every row must equal the
+    one-launch-per-conv handle (WTK_SK_GROUP=0) bit for bit."""
+    frames = fr.diverse_frames(max(B, 4), size, seed=77 + size)[:B]
+    _, grouped, _ = _handle(size, dtype)
+    monkeypatch.setenv("WTK_SK_GROUP", "0")
+    _, single, _ = _handle(size, dtype)
+    xg, cg, ag = grouped.predict_host(frames, conf=0.1)
+    xs, cs, as_ = single.predict_host(frames, conf=0.1)
+    np.testing.assert_array_equal(ag, as_)
+    np.testing.assert_array_equal(xg, xs)
+    np.testing.assert_array_equal(cg, cs)
+    depth, width, maxch = ys.SCALES["s"]
+    n_convs = len(hip.yolo_conv_table(width, depth, maxch, 1))
+    seen = 0
+    for ci in range(n_convs):
+        try:
+            tg = grouped.debug_tensor(ci, B)
+        except hip.WtkError:
+            continue  # (a class tower's first conv rides in the box tower's op)
+        np.testing.assert_array_equal(tg, single.debug_tensor(ci, B), err_msg=f"conv {ci}")
+        seen += 1
+    assert seen >= 57
+    grouped.close(), single.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
+def test_slab_hand_off_holds_beside_another_handles_kernels(hip_lib, dtype, monkeypatch):
+    """the in-kernel slab hand-off (sc1 stores, ticket, sc1 loads: the form MI355X_MICROARCH.md measured for one workgroup per CU) must also
+    hold when blocks of OTHER kernels share the CUs — the deferred track log runs a cycle batch on lane 1 beside the single-frame call.  A second handle
+    streams large batches on another stream (uneven load: its launches of 140-270 blocks come and go) while the handle under test runs single frames;
+    every conv tensor of every round is compared, word for word, with the two-launch form (WTK_SK_FINISH=1: plain stores, slabs combined by a second
+    launch — no in-kernel hand-off at all)."""
+    size = 384
+    frames = fr.diverse_frames(8, size, seed=11)
+    dev = torch.device("cuda", 0)
+    _, det, _ = _handle(size, dtype, max_batch=4)
+    monkeypatch.setenv("WTK_SK_FINISH", "1")
+    _, ref, _ = _handle(size, dtype, max_batch=4)
+    monkeypatch.delenv("WTK_SK_FINISH")
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    noise = hip.HipYolo(w, (size, size), 16, dtype=dtype, nc=1, width=width, depth=depth, max_channels=maxch, plan="throughput")
+    nf = torch.from_numpy(fr.diverse_frames(16, size, seed=12)).to(dev)
+    no, na = torch.empty((16, 4), dtype=torch.float32, device=dev), torch.empty((16,), dtype=torch.int32, device=dev)
+    ns = torch.cuda.Stream(device=dev)
+    n_convs = len(hip.yolo_conv_table(width, depth, maxch, 1))
+    expect = {}
+    for r in range(4):  # the reference rounds run alone
+        ref.predict_host(frames[r : r + 1], conf=0.1)
+        expect[r] = [ref.debug_tensor(ci, 1) if _has(ref, ci) else None for ci in range(n_convs)]
+    for it in range(24):
+        r = it % 4
+        for k in range(3 + it % 5):  # uneven: a different amount of foreign work in flight every round
+            noise.predict(nf, 5 + (it + k) % 11, size, size, 1, no, None, na, conf=0.1, stream=ns.cuda_stream)
+        det.predict_host(frames[r : r + 1], conf=0.1)  # host stream of the handle: runs beside the noise stream
+        for ci in range(n_convs):
+            if expect[r][ci] is not None:
+                np.testing.assert_array_equal(det.debug_tensor(ci, 1), expect[r][ci], err_msg=f"round {it} conv {ci}")
+    ns.synchronize()
+    det.close(), ref.close(), noise.close()
+
+
+def _has(det, ci):
+    try:
+        det.debug_tensor(ci, 1)
+        return True
+    except hip.WtkError:
+        return False
 
 
 def test_replayed_capture_for_caller_buffers_equals_eager(hip_lib, monkeypatch):

@@ -197,7 +197,7 @@ def test_controller_picks_the_plan_by_call_size(monkeypatch, tmp_path):
     mk = lambda **kw: controllers.YoloConfig(model_path=path, scale="n", **kw).load_model()
     m = mk(dtype="f16x3")
     a, b, c = m.detector((384, 384), 1), m.detector((384, 384), 15), m.detector((384, 384), 4)
-    assert (a.plan, a.max_batch) == ("latency", 16) and (b.plan, b.max_batch) == ("throughput", 16) and c is a and m.detector((384, 384), 9) is b
+    assert (a.plan, a.max_batch) == ("latency", 4) and (b.plan, b.max_batch) == ("throughput", 16) and c is a and m.detector((384, 384), 9) is b  # (auto: the latency handle is sized for the calls it sees)
     big = m.detector((384, 384), 40)
     assert (big.plan, big.max_batch) == ("throughput", 64) and big is not b
     m = mk(dtype="fp16")

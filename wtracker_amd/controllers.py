@@ -346,11 +346,14 @@ class YoloConfig:
         return self.model
 
 
-def _raise_on_overflow(det: hip.HipYolo) -> None:
+def _raise_on_overflow(det: hip.HipYolo, flags: Optional[int] = None) -> None:
     """The fp16-storage modes need |activation| < 65 504 (include/wtk_hip.h: wtk_yolo_status).  A trained, BatchNorm-folded checkpoint
     (yolo_controller.py:42-45 loads one) whose activations leave that range would otherwise give NaN rows or wrong survivors silently: the head
-    kernels raise a sticky flag when a head logit is inf / NaN, and the controller turns it into an error that names the way out."""
-    if det.status(clear=True) & hip.STATUS_NONFINITE:
+    kernels raise a sticky flag when a head logit is inf / NaN, and the controller turns it into an error that names the way out.
+    `flags`: the status word as it was read when the call finished (lanes that share a handle: HipYoloController.launch_views); None = read it now."""
+    if flags is None:
+        flags = det.status(clear=True)
+    if flags & hip.STATUS_NONFINITE:
         raise hip.WtkError(f"non-finite head logits in dtype '{det.dtype}': an activation of this model left the fp16 range (65 504); "
                            "use YoloConfig(dtype='fp32')" if det.dtype != "fp32" else "non-finite head logits: the model's weights or the input produce inf / NaN")
 
@@ -362,8 +365,18 @@ class _YoloModel:
         self.cfg = cfg
         self.weights, self.nc = yolo_spec.load_weights(cfg.model_path)
         self._dets: dict = {}
+        self._retired: list = []
 
     LATENCY_MAX_BATCH = 4  # measured cross-over between the plans near B = 6 at imgsz 384 (profiles/r05_notes.md)
+
+    def _retire(self, det: hip.HipYolo) -> None:
+        """A handle that is replaced by a larger one: a call launched on it (HipYoloController.launch_views, lane 1) may still be running and its token
+        still names the handle — the device drains before the handle goes, and the handle stays readable (status) until its tokens are collected."""
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(self.cfg.device_index())
+        self._retired.append(det)  # closed when the model goes: collect_views may still ask it for its status word
 
     def detector(self, net_hw: tuple, batch: int, dtype: Optional[str] = None) -> hip.HipYolo:
         dtype = dtype or self.cfg.dtype
@@ -376,11 +389,16 @@ class _YoloModel:
         det = self._dets.get(key)
         if det is None or det.max_batch < batch:
             if det is not None:
-                det.close()
+                self._retire(det)
             width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
-            # a handle for the reference's own calls (<= 16 frames) is sized for 16: the library then runs the 12 x 12-map layers of such a handle on
-            # its split-K kernel whatever the plan (csrc/wtk_api.hip: sk_mixed)
-            cap = 16 if batch <= 16 else max(batch, self.cfg.max_batch)
+            # sizes: a latency-plan handle under plan "auto" only ever sees calls of up to LATENCY_MAX_BATCH frames (its split-K slabs are sized by the
+            # capacity: 4, not 16); a throughput-plan handle for the reference's own calls (<= 16 frames) is sized for 16 — the library runs the
+            # 12 x 12-map layers of such a handle on its split-K kernel (csrc/wtk_api.hip: sk_mixed); plan "latency" keeps both calls of a cycle on one
+            # handle of 16
+            if plan == "latency" and self.cfg.plan == "auto":
+                cap = self.LATENCY_MAX_BATCH
+            else:
+                cap = 16 if batch <= 16 else max(batch, self.cfg.max_batch)
             det = hip.HipYolo(self.weights, net_hw, cap, dtype=dtype, nc=self.nc, width=width, depth=depth, max_channels=maxch,
                               device=self.cfg.device_index(), plan=plan)
             self._dets[key] = det
@@ -492,6 +510,9 @@ class HipYoloController(SimController):
         busy = self._inflight.get(id(det))
         if busy is not None and busy["lane"] != lane:
             busy["stream"].synchronize()
+            # the handle's sticky status word now holds THAT call's flags: they go into its token before this call can raise its own (a flag is
+            # reported by the call that caused it, whichever lane collects first)
+            busy["flags"] = det.status(clear=True)
         # EVERY call is ordered behind the caller's current stream (an event wait, microseconds): a caller that refills or extends `device_frames` in
         # place between cycles has its writes on that stream, and the crop / letterbox kernel must not read frames that are still being written
         stream.wait_stream(torch.cuda.current_stream(dev))
@@ -531,7 +552,7 @@ class HipYoloController(SimController):
         if self._inflight.get(id(det)) is token:
             del self._inflight[id(det)]
         xywh, anchor = bufs["out_h"].numpy().copy(), bufs["an_h"].numpy().copy()
-        _raise_on_overflow(det)
+        _raise_on_overflow(det, token.get("flags"))
         self.last_rechecked = 0
         if self.yolo_config.recheck_margin > 0 and det.dtype in ("fp16", "f16", "float16"):
             weak = np.nonzero(det.last_margins(n) < self.yolo_config.recheck_margin)[0]

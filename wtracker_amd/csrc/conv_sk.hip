@@ -76,34 +76,6 @@ __device__ __forceinline__ void sk_wait_loads(floatx4 (&x)[16]) {
                    "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])::"memory");
 }
 
-struct SkArgs {
-    const char *in;  // input tensor (slice view): byte pitch per pixel, byte offset of the first channel
-    unsigned in_ldb, in_offb;
-    const char *in2; // optional half-resolution source of the first in2_blocks 32-channel blocks (nn.Upsample(2x) + Concat, 1x1 only)
-    unsigned in2_ldb, in2_offb;
-    int in2_blocks;
-    int N, H, W, Ho, Wo;
-    int cpb;              // 32-channel blocks per tap
-    int KW, stride, pad;  // square taps: KH == KW
-    int nk, S;            // K steps in all (taps * cpb); blocks per tile along K: 1 or NA
-    int NA;               // K atoms of the layer (conv_sk_slices): the unit of summation, see the header
-    const char *w;        // [CoutPad][nk * 128 bytes]
-    unsigned w_rowb;
-    const float *bias;
-    int Cout, CoutPad, act;
-    void *out;
-    int out_ld, out_coff, out_f32; // elements of the storage type (SPLIT: pseudo-channels unless out_f32), as ConvArgs
-    const void *res;
-    int res_ld, res_coff;
-    float *partial; // S > 1: [S][M][CoutPad] fp32
-    unsigned *tickets; // S > 1, nullable: one arrival counter per (pixel tile, cout tile), zero between launches — the block that arrives LAST combines the
-                       // slabs itself (no second launch); null: sk_finish_kernel does it
-    long long M;
-    int ptiles, nct;
-    FastDiv d_ptiles, d_nct, d_howo, d_wo, d_cpb, d_cg;
-    const int *n_dyn;
-};
-
 // what becomes of a finished run of NV consecutive couts (cb ..) of output pixel `pix`; v = the K sum WITHOUT the bias
 template <int NV> __device__ __forceinline__ void sk_load_bias(const SkArgs &a, int cb, float (&b)[NV]) { // rows exist up to CoutPad
 #pragma unroll
@@ -141,8 +113,9 @@ template <bool SPLIT, int NV> __device__ __forceinline__ void sk_store(const SkA
     }
 }
 
+// One block's work on one conv: `bid` = the block's index among THIS conv's blocks (a grouped launch carries several convs, see conv_sk_kernel below)
 template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS>
-__global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const SkArgs a) {
+__device__ __forceinline__ void sk_body(const SkArgs &a, const unsigned bid, char *smem) {
     constexpr int NW = WAVES_P * WAVES_C;
     constexpr int RPP = 8 * NW; // tile rows staged per pass of the whole block (one wave instruction = 8 rows x 128 B)
     constexpr int PR = BM / RPP, WR = BN / RPP;
@@ -156,7 +129,6 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
     static_assert((NS & (NS - 1)) == 0 && NS >= 2 && NS <= 8 && NS * STAGE <= 160 * 1024, "ring");
     // the slab hand-off below is the form MI355X_MICROARCH.md measured for ONE workgroup per CU: more than half of the LDS per block guarantees it
     static_assert(NS * STAGE > 80 * 1024, "one block per CU");
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,8 +137,8 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
     const int lr = lane & 15, lg = lane >> 4;
 
     // block -> (pixel tile fastest, cout tile, K slice): the blocks that are neighbours in launch order share a weight slice
-    const unsigned bq = fdiv(blockIdx.x, a.d_ptiles);
-    const int ptile = (int)(blockIdx.x - bq * (unsigned)a.ptiles);
+    const unsigned bq = fdiv(bid, a.d_ptiles);
+    const int ptile = (int)(bid - bq * (unsigned)a.ptiles);
     const int slice = (int)fdiv(bq, a.d_nct);
     const int ctile = (int)(bq - (unsigned)slice * (unsigned)a.nct);
     // this block's atoms: all of them (S = 1) or atom `slice` (S = NA); atom i = steps [i nk / NA, (i + 1) nk / NA)
@@ -412,6 +384,18 @@ __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const
     }
 }
 
+// A launch carries up to kSkGroupMax convs that do not depend on each other (one dependency LEVEL of the latency plan: a Detect tower's box and class
+// convs, a PAN layer next to the tower of the feature map before it — csrc/wtk_api.hip: sk_schedule): the grid is the concatenation of the members'
+// grids, a block finds its member by its index.  One stream, one dispatch per level — what round 5 spread over three streams and 61 dispatches.
+template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS>
+__global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const SkGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * 128];
+    int gi = 0; // block-uniform
+#pragma unroll
+    for (int i = 1; i < kSkGroupMax; ++i) gi += blockIdx.x >= g.first[i] ? 1 : 0;
+    sk_body<SPLIT, BM, BN, WAVES_P, WAVES_C, NS>(g.p[gi], blockIdx.x - g.first[gi], smem);
+}
+
 // slabs of a split layer -> the layer's output: one thread per (pixel, run of 8 couts), slabs added in slice order
 template <bool SPLIT> __global__ __launch_bounds__(256) void sk_finish_kernel(const SkArgs a) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -437,14 +421,21 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void sk_finish_kernel(co
     sk_store<SPLIT, 8>(a, (long long)pix, cb, v, bias);
 }
 
-template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS> hipError_t sk_launch_t(SkArgs a, hipStream_t st) {
-    a.ptiles = (int)((a.M + BM - 1) / BM);
-    a.nct = a.CoutPad / BN;
-    a.d_ptiles = make_fastdiv((unsigned)a.ptiles);
-    a.d_nct = make_fastdiv((unsigned)a.nct);
-    const long long grid = (long long)a.ptiles * a.nct * a.S;
-    if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_sk_kernel<SPLIT, BM, BN, WAVES_P, WAVES_C, NS>), dim3((unsigned)grid), dim3(64 * WAVES_P * WAVES_C), 0, st, a);
+template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS> hipError_t sk_launch_t(SkGroupArgs &g, int n, hipStream_t st) {
+    long long grid = 0;
+    for (int i = 0; i < kSkGroupMax; ++i) {
+        g.first[i] = 0xffffffffu;
+        if (i >= n) continue;
+        SkArgs &a = g.p[i];
+        a.ptiles = (int)((a.M + BM - 1) / BM);
+        a.nct = a.CoutPad / BN;
+        a.d_ptiles = make_fastdiv((unsigned)a.ptiles);
+        a.d_nct = make_fastdiv((unsigned)a.nct);
+        g.first[i] = (unsigned)grid;
+        grid += (long long)a.ptiles * a.nct * a.S;
+        if (a.CoutPad % BN || grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL((conv_sk_kernel<SPLIT, BM, BN, WAVES_P, WAVES_C, NS>), dim3((unsigned)grid), dim3(64 * WAVES_P * WAVES_C), 0, st, g);
     return hipGetLastError();
 }
 
@@ -478,43 +469,69 @@ static long long sk_inkernel_max() {
     static const long long v = (long long)sk_env("WTK_SK_INKERNEL_MAX_KB", 4096) * 1024;
     return v;
 }
-static double sk_choose(long long M, int cout_pad, int nk, int NA, int num_cus, int split, int *tile, int *form) {
-    const int force_tile = sk_env("WTK_SK_TILE", -1); // tuning switches: 0 128x128, 1 128x64, 2 64x64, 3 64x32 (where the couts allow)
-    const int force_form = sk_env("WTK_SK_FORM", -1); // 0: always S = NA, 1: always S = 1
-    struct Cand {
-        int bm, bn, id;
-    };
-    const Cand cands[4] = {{128, 128, 0}, {128, 64, 1}, {64, 64, 2}, {64, 32, 3}};
-    const double cus = (double)num_cus;
+struct SkShape { // what the cost model needs to know of one conv
+    long long M;
+    int cout_pad, nk, NA;
+};
+struct SkTile {
+    int bm, bn;
+};
+static const SkTile kSkTiles[4] = {{128, 128}, {128, 64}, {64, 64}, {64, 32}};
+// (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU gets ~40 KB/us of operands through its LDS-DMA requests whether the
+// chip is full or not, and with one block per CU nothing overlaps the multiply that follows — 16 cycles per v_mfma_f32_16x16x32_f16, three per tile pair in
+// split mode, eight 32-cycle v_mfma_f32_16x16x4_f32 in fp32 mode, four SIMDs, ~2.2 GHz —; the in-kernel hand-off costs ~4 us + the combining block's slab
+// reads at ~60 KB/us; a second launch ~3 us + the slabs at ~5 MB/us)
+static void sk_member_cost(const SkShape &c, const SkTile &t, int S, int split, double *blocks, double *block_us, double *handoff_us) {
+    const double tiles = (double)((c.M + t.bm - 1) / t.bm) * (c.cout_pad / t.bn);
+    *blocks = tiles * S;
+    const double steps = std::ceil((double)c.nk / S);
+    const double stage_kb = (t.bm + t.bn) * 128.0 / 1024.0;
+    const double mfma_us = (t.bm / 16) * (t.bn / 16) * (split ? 3.0 * 16.0 : 8.0 * 32.0) / 4.0 / 2200.0;
+    *block_us = 1.9 + steps * (stage_kb / 40.0 + mfma_us);
+    *handoff_us = 0.0;
+    if (S > 1) {
+        const double slab_bytes = (double)S * c.M * c.cout_pad * 4.0;
+        const double tile_kb = t.bm * t.bn * 4.0 / 1024.0;
+        *handoff_us = slab_bytes <= (double)sk_inkernel_max() ? 4.0 + S * tile_kb / 60.0 : 3.0 + slab_bytes / 5.0e6;
+    }
+}
+// Form (per member) and tile (one per launch: the instantiation) of a launch of n independent convs: blocks run one per CU (96-128 KB of LDS) in rounds
+// over the concatenated grid; a round lasts as long as its slowest block, the hand-offs of the members run side by side.  For n = 1 this is round 5's
+// model of a single launch.  force_tile / force_form: the test hooks (0..3 / 0: always S = NA, 1: always S = 1; -1: free).
+static double sk_choose(const SkShape *c, int n, int num_cus, int split, int force_tile, int force_form, int *tile, int *S_out) {
     double best_t = 1e30;
-    int best_tile = 3, best_S = NA;
-    for (const Cand &c : cands) {
-        if (cout_pad % c.bn) continue;
-        if (force_tile >= 0 && c.id != force_tile && !(cout_pad % cands[force_tile].bn)) continue;
-        for (int S : {1, NA}) {
-            if (force_form == 0 && S != NA) continue;
-            if (force_form == 1 && S != 1) continue;
-            const double tiles = (double)((M + c.bm - 1) / c.bm) * (cout_pad / c.bn);
-            const double blocks = tiles * S;
-            const double rounds = std::ceil(blocks / cus);
-            const double steps = std::ceil((double)nk / S);
-            const double stage_kb = (c.bm + c.bn) * 128.0 / 1024.0;
-            // (constants from the forced-tile / forced-form runs of profiles/r05_notes.md: a CU gets ~40 KB/us of operands through its LDS-DMA requests
-            // whether the chip is full or not, and with one block per CU nothing overlaps the multiply that follows — 16 cycles per v_mfma_f32_16x16x32_f16,
-            // three per tile pair in split mode, eight 32-cycle v_mfma_f32_16x16x4_f32 in fp32 mode, four SIMDs, ~2.2 GHz —; the in-kernel hand-off costs
-            // ~4 us + the combining block's slab reads at ~60 KB/us; a second launch ~3 us + the slabs at ~5 MB/us)
-            const double mfma_us = (c.bm / 16) * (c.bn / 16) * (split ? 3.0 * 16.0 : 8.0 * 32.0) / 4.0 / 2200.0;
-            double t = rounds * (1.9 + steps * (stage_kb / 40.0 + mfma_us));
-            if (S > 1) {
-                const double slab_bytes = (double)S * M * cout_pad * 4.0;
-                const double tile_kb = c.bm * c.bn * 4.0 / 1024.0;
-                t += slab_bytes <= (double)sk_inkernel_max() ? 4.0 + S * tile_kb / 60.0 : 3.0 + slab_bytes / 5.0e6;
+    *tile = 3;
+    for (int i = 0; i < n; ++i) S_out[i] = c[i].NA;
+    for (int ti = 0; ti < 4; ++ti) {
+        const SkTile &t = kSkTiles[ti];
+        bool fits = true, forced_fits = force_tile >= 0 && force_tile <= 3;
+        for (int i = 0; i < n; ++i) {
+            fits = fits && c[i].cout_pad % t.bn == 0;
+            if (forced_fits) forced_fits = c[i].cout_pad % kSkTiles[force_tile].bn == 0;
+        }
+        if (!fits) continue;
+        if (forced_fits && ti != force_tile) continue;
+        for (int combo = 0; combo < (1 << n); ++combo) { // bit i: member i walks all its atoms in one block (S = 1)
+            double blocks = 0, slowest = 0, handoff = 0;
+            bool ok = true;
+            int S[kSkGroupMax];
+            for (int i = 0; i < n && ok; ++i) {
+                S[i] = (combo >> i) & 1 ? 1 : c[i].NA;
+                if (c[i].NA == 1 && ((combo >> i) & 1) == 0) ok = false; // (one atom: the two forms are the same launch — count it once)
+                if (force_form == 0 && S[i] != c[i].NA) ok = false;
+                if (force_form == 1 && S[i] != 1) ok = false;
+                double b, bu, hu;
+                sk_member_cost(c[i], t, S[i], split, &b, &bu, &hu);
+                blocks += b, slowest = std::max(slowest, bu), handoff = std::max(handoff, hu);
             }
-            if (t < best_t) best_t = t, best_tile = c.id, best_S = S;
-            if (NA == 1) break;
+            if (!ok) continue;
+            const double tt = std::ceil(blocks / (double)num_cus) * slowest + handoff;
+            if (tt < best_t) {
+                best_t = tt, *tile = ti;
+                for (int i = 0; i < n; ++i) S_out[i] = S[i];
+            }
         }
     }
-    *tile = best_tile, *form = best_S;
     return best_t;
 }
 
@@ -523,11 +540,13 @@ static double sk_choose(long long M, int cout_pad, int nk, int NA, int num_cus, 
 int conv_sk_plan_atoms(long long M, int cout_pad, int nk, int num_cus, int split) {
     const int dflt = conv_sk_slices(nk);
     int tile, form;
-    double best_t = sk_choose(M, cout_pad, nk, dflt, num_cus, split, &tile, &form);
+    SkShape c{M, cout_pad, nk, dflt};
+    double best_t = sk_choose(&c, 1, num_cus, split, -1, -1, &tile, &form);
     int best = dflt;
     for (int na = 1; na <= 8; ++na) {
         if (na == dflt || (na > 1 && nk / na < 4)) continue;
-        const double t = sk_choose(M, cout_pad, nk, na, num_cus, split, &tile, &form);
+        c.NA = na;
+        const double t = sk_choose(&c, 1, num_cus, split, -1, -1, &tile, &form);
         if (t < best_t - 0.5) best_t = t, best = na; // (the default unless clearly better)
     }
     return best;
@@ -555,11 +574,11 @@ size_t conv_sk_partial_bytes(const ConvArgs &a, int split, int atoms) {
 
 size_t conv_sk_ticket_count(long long M, int cout_pad) { return (size_t)((M + 63) / 64) * (size_t)(cout_pad / 32); } // the smallest tile: 64 px x 32 couts
 
-// `a` as the implicit-GEMM launchers take it (split: pseudo-channel arguments); `partial` = conv_sk_partial_bytes(a, split) bytes of scratch of this op
-hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
+// fills the kernel's view of one member; `a` as the implicit-GEMM launchers take it (split: pseudo-channel arguments)
+static hipError_t sk_fill(SkArgs &k, const SkMember &m, int split) {
+    const ConvArgs &a = m.a;
     if (!conv_sk_eligible(a, split)) return hipErrorInvalidValue;
     const int esz = split ? 2 : 4;
-    SkArgs k;
     std::memset(&k, 0, sizeof(k));
     k.in = reinterpret_cast<const char *>(a.in), k.in_ldb = (unsigned)a.in_ld * esz, k.in_offb = (unsigned)a.in_coff * esz;
     if (a.in2) {
@@ -570,7 +589,7 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partia
     k.cpb = a.Cin * esz / 128;
     k.KW = a.KW, k.stride = a.stride, k.pad = a.pad;
     k.nk = (int)((long long)a.Kpad * esz / 128);
-    k.NA = atoms > 0 ? atoms : conv_sk_slices(k.nk);
+    k.NA = m.atoms > 0 ? m.atoms : conv_sk_slices(k.nk);
     if (k.NA > 8 || k.NA > k.nk) return hipErrorInvalidValue;
     k.S = k.NA;
     k.w = reinterpret_cast<const char *>(a.w), k.w_rowb = (unsigned)k.nk * 128u;
@@ -578,38 +597,65 @@ hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partia
     k.Cout = a.Cout, k.CoutPad = a.CoutPad, k.act = a.act;
     k.out = a.out, k.out_ld = a.out_ld, k.out_coff = a.out_coff, k.out_f32 = a.out_f32;
     k.res = a.res, k.res_ld = a.res_ld, k.res_coff = a.res_coff;
-    k.partial = partial;
-    k.tickets = nullptr; // decided with the form below
+    k.partial = m.partial;
+    k.tickets = nullptr; // decided with the form
     k.M = a.M;
     k.n_dyn = a.n_dyn;
     k.d_howo = make_fastdiv((unsigned)(a.Ho * a.Wo));
     k.d_wo = make_fastdiv((unsigned)a.Wo);
     k.d_cpb = make_fastdiv((unsigned)k.cpb);
     k.d_cg = make_fastdiv((unsigned)(a.Cout / 8));
-    if (k.NA > 1 && !partial) return hipErrorInvalidValue;
+    if (k.NA > 1 && !m.partial) return hipErrorInvalidValue;
     if ((k.in2 != nullptr) != (k.in2_blocks > 0) || k.in2_blocks > k.cpb) return hipErrorInvalidValue;
-    // ---- form (S = 1: one block per tile walks every atom; S = NA: one block per atom + slab combination) and tile, per launch: neither enters the
-    // arithmetic (see the header).  sk_choose() is the cost model.
-    int best_tile = 3, best_S = k.NA;
-    const double best_t = sk_choose(a.M, a.CoutPad, k.nk, k.NA, num_cus, split, &best_tile, &best_S);
-    k.S = best_S;
-    if (sk_env("WTK_SK_VERBOSE", 0))
-        std::fprintf(stderr, "conv_sk: M %lld cout %d nk %d atoms %d -> tile %d form S=%d (est %.1f us)\n", a.M, a.CoutPad, k.nk, k.NA, best_tile, best_S, best_t);
-    k.tickets = (k.S > 1 && (long long)k.S * a.M * a.CoutPad * 4 <= sk_inkernel_max()) ? tickets : nullptr;
-    hipError_t e;
-    switch (best_tile) {
-    case 0: e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(k, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(k, st); break;
-    case 1: e = split ? sk_launch_t<true, 128, 64, 2, 2, 4>(k, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(k, st); break;
-    case 2: e = split ? sk_launch_t<true, 64, 64, 4, 2, 8>(k, st) : sk_launch_t<false, 64, 64, 4, 2, 8>(k, st); break;
-    default: e = split ? sk_launch_t<true, 64, 32, 4, 1, 8>(k, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(k, st); break;
+    return hipSuccess;
+}
+
+// n <= kSkGroupMax convs that do not depend on each other, as ONE launch.  Form (per member) and tile (per launch) are chosen by the cost model: neither
+// enters the arithmetic (see the header), so a grouped launch gives every member the bits its own launch would give it.
+hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t st) {
+    if (n < 1 || n > kSkGroupMax) return hipErrorInvalidValue;
+    SkGroupArgs g;
+    SkShape shapes[kSkGroupMax];
+    for (int i = 0; i < n; ++i) {
+        const hipError_t e = sk_fill(g.p[i], m[i], split);
+        if (e != hipSuccess) return e;
+        shapes[i] = {g.p[i].M, g.p[i].CoutPad, g.p[i].nk, g.p[i].NA};
     }
-    if (e != hipSuccess || k.S == 1 || k.tickets) return e;
-    const long long threads = a.M * (a.Cout / 8);
-    if (split)
-        hipLaunchKernelGGL(sk_finish_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
-    else
-        hipLaunchKernelGGL(sk_finish_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
-    return hipGetLastError();
+    for (int i = n; i < kSkGroupMax; ++i) std::memset(&g.p[i], 0, sizeof(SkArgs));
+    int tile = 3, S[kSkGroupMax];
+    const double est = sk_choose(shapes, n, num_cus, split, force_tile, force_form, &tile, S);
+    static const int verbose = sk_env("WTK_SK_VERBOSE", 0);
+    for (int i = 0; i < n; ++i) {
+        SkArgs &k = g.p[i];
+        k.S = S[i];
+        k.tickets = (k.S > 1 && (long long)k.S * k.M * k.CoutPad * 4 <= sk_inkernel_max()) ? m[i].tickets : nullptr;
+        if (verbose)
+            std::fprintf(stderr, "conv_sk%s: M %lld cout %d nk %d atoms %d -> tile %d form S=%d (launch est %.1f us)\n", n > 1 ? " (grouped)" : "", k.M, k.CoutPad, k.nk, k.NA, tile, k.S, est);
+    }
+    hipError_t e;
+    switch (tile) {
+    case 0: e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(g, n, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(g, n, st); break;
+    case 1: e = split ? sk_launch_t<true, 128, 64, 2, 2, 4>(g, n, st) : sk_launch_t<false, 128, 64, 2, 2, 4>(g, n, st); break;
+    case 2: e = split ? sk_launch_t<true, 64, 64, 4, 2, 8>(g, n, st) : sk_launch_t<false, 64, 64, 4, 2, 8>(g, n, st); break;
+    default: e = split ? sk_launch_t<true, 64, 32, 4, 1, 8>(g, n, st) : sk_launch_t<false, 64, 32, 4, 1, 8>(g, n, st); break;
+    }
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < n; ++i) { // members whose slabs are combined by a second launch (slabs above the in-kernel limit, or no tickets: WTK_SK_FINISH=1)
+        const SkArgs &k = g.p[i];
+        if (k.S == 1 || k.tickets) continue;
+        const long long threads = k.M * (k.Cout / 8);
+        if (split)
+            hipLaunchKernelGGL(sk_finish_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
+        else
+            hipLaunchKernelGGL(sk_finish_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
+    const SkMember m{a, atoms, partial, tickets};
+    return launch_conv_sk_group(&m, 1, split, num_cus, -1, -1, st);
 }
 
 } // namespace wtk

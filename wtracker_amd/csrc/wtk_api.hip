@@ -495,8 +495,6 @@ struct Op {
     int side = 0;        // 1: runs on the handle's side stream (Detect towers of P3 / P4)
     int wait_feat = -1;  // side ops: feature event (0: P3 ready, 1: P4 ready) to wait for before the first one
     int signal_feat = -1; // main ops: record this feature event after the op
-    int signal_d1 = -1;   // Detect first conv of level i: record d1_ev[i] on its stream after the op
-    int wait_d1 = -1;     // first op of a class tower: wait for d1_ev[i]
     void *w = nullptr; // packed device weights
     float *bias = nullptr;
     double macs_per_image = 0;
@@ -521,7 +519,7 @@ struct wtk_yolo {
     ModelDims dims;
     std::vector<Buf> bufs;
     std::vector<Op> ops;
-    std::vector<std::pair<void *, size_t>> dev_allocs; // (pointer, bytes) of every dev_alloc: returned to the block cache on destroy
+    std::vector<std::pair<void *, size_t>> dev_allocs; // (pointer, bytes) of every dev_alloc
     int box_buf[3] = {-1, -1, -1}, cls_buf[3] = {-1, -1, -1};
     int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
     int cls_ld = 32;
@@ -547,10 +545,8 @@ struct wtk_yolo {
     int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
     int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
     int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
-    int stem_fp32 = 0; // WTK_STEM_FP32=1: a split (f16x3) handle's stem on the fp32 matrix instructions (round 2) instead of split operands (A/B switch)
     int use_c32s = 1;  // WTK_NO_C32S=1: the 32 -> 32 channel 3x3 layers of a split (f16x3) handle through conv_igemm_kernel (A/B switch)
     int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
-    int ws64_weave = 0; // pixel tiles (of 4) of a 64-channel 3x3 tile whose epilogue rides on the next multiply phase (WTK_WS64_WEAVE=0..3; 0: the round-2 schedule)
     int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
     int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
     int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
@@ -561,6 +557,10 @@ struct wtk_yolo {
     // and NOT per call: every conv behind the fused front then runs on conv_sk_kernel whatever the batch of the call, so a frame's logits do not
     // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
     int latency = 0;
+    // latency plan, round 6: the convs of one dependency level run as ONE grouped split-K launch on the caller's stream (sk_schedule).
+    int sk_group = 1;                      // WTK_SK_GROUP=0: one launch per conv, in op order (test hook: the grouped launches must give the same bits)
+    int sk_force_tile = -1, sk_force_form = -1; // WTK_SK_TILE / WTK_SK_FORM, read when the handle is created (test hooks: every tile and form gives the same bits)
+    std::vector<std::vector<int>> lat_sched; // launches behind ops[0..2] in order: one op, or up to kSkGroupMax split-K ops that do not depend on each other
     int small_narrow = 0; // a small handle (max_batch <= 16, f16x3) runs window / implicit-GEMM layers whose grid leaves most CUs idle on 64-cout tiles (WTK_SMALL_NARROW=0: off)
     int halo_deep = 0;    // f16x3: the 64-cout x 128-pixel window tiles on the six-slab ring (small handles; WTK_HALO_DEEP)
     int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status); a slot of the process-wide page
@@ -572,14 +572,13 @@ struct wtk_yolo {
     static constexpr int kProfKernels = 7, kProfEvents = 96;
     hipEvent_t ev[kProfEvents];
     // concurrency: the P3 / P4 Detect towers run on a side stream next to the PAN path
-    // Side streams of one forward pass (op.side = index, 0 = the caller's stream): 1 / 2 = P3 / P4 Detect towers (they only need t15 / t18),
-    // 3 / 4 / 5 = the class towers of P3 / P4 / P5 (independent of the box tower behind the shared first conv)
-    static constexpr int kSideStreams = 6;
+    // Side streams of one forward pass (op.side = index, 0 = the caller's stream): 1 / 2 = P3 / P4 Detect towers (they only need t15 / t18).  The pair is
+    // process-wide (ensure_side_streams); wtk_yolo_set_side_streams(1) folds both towers onto stream 1, (0) keeps everything on the caller's stream.
+    static constexpr int kSideStreams = 3;
     hipStream_t side_stream[kSideStreams] = {};
-    hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done[kSideStreams] = {}, d1_ev[3] = {};
+    hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done[kSideStreams] = {};
     int use_side = 1;
-    int side_shared = 0;
-    int side_streams = 2; // WTK_SIDE_STREAMS (A/B switch): 1: P3 and P4 towers share one side stream; 2 (default): one each (+0.5..1.6 %); 3: + class towers on their own streams (-11 %: more streams than hardware queues)
+    int side_streams = 2;
     // launch-bound regime (small batches): the whole forward is captured once per argument set and replayed
     struct GraphEntry {
         const void *frames;
@@ -587,7 +586,8 @@ struct wtk_yolo {
         float conf;
         void *o_xywh, *o_conf, *o_anchor;
         hipGraphExec_t exec;
-        hipStream_t last_stream = nullptr; // stream of the last replay: synchronised before the exec is destroyed (a replay may still be in flight there)
+        hipEvent_t done = nullptr; // recorded behind every replay: waited for before the exec is destroyed (a replay may still be in flight; the handle's OWN event, because
+                                   // the stream of the last replay is the caller's and may be gone by then)
         // views form (wtk_yolo_predict_views): the view table's device addresses and the view shape are part of the key
         const void *idx = nullptr, *pos = nullptr;
         int vw = 0, vh = 0, nf = 0;
@@ -599,8 +599,8 @@ struct wtk_yolo {
     std::vector<GraphEntry> graphs;
     std::vector<GraphEntry> seen_once; // caller-buffer argument sets met once (exec == nullptr): captured when they come back
     int graph_max_batch = 16; // WTK_GRAPH_MAX_BATCH; 0 disables
-    int graph_host = 0;       // WTK_GRAPH_HOST=1: a throughput-plan handle replays captures for its host entry points too (latency-plan handles always do)
-    int graph_views = 0;      // WTK_GRAPH_VIEWS=1: wtk_yolo_predict_views replays captures too (measured in round 4: no gain, so off by default)
+    int graph_host = 0;       // WTK_GRAPH=1 / WTK_GRAPH_HOST=1: the *_host entry points replay captures (own staging buffers)
+    int graph_views = 0;      // WTK_GRAPH=1 / WTK_GRAPH_VIEWS=1: caller-buffer argument sets are captured when they come back, then replayed
     hipStream_t host_stream = nullptr; // stream of the *_host entry points (graph capture needs a non-null stream)
     int ev_created = 0;
     double prof_ms[kProfKernels] = {};
@@ -630,93 +630,55 @@ extern "C" int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t ma
     return 0;
 }
 
-// Optional block cache of the detector handles' device memory (WTK_ALLOC_CACHE=1; off by default).  Built while looking for the reason
-// why a workload's rate depended on what the process had run before (the reason was the stream layout, see ensure_side_streams; the
-// cache changed nothing measurable).  With it, destroyed handles keep their blocks per (device, size) for the next handle that asks
-// for exactly that size instead of paying hipFree + hipMalloc; a failed hipMalloc releases the cache and tries again;
-// wtk_release_cached_memory() gives everything back.
-namespace {
-struct CachedBlock {
-    void *p;
-    size_t bytes;
-    int device;
-};
-std::mutex g_block_mu;
-std::vector<CachedBlock> g_blocks;
-bool block_cache_on() {
-    static const bool on = std::getenv("WTK_ALLOC_CACHE") && std::getenv("WTK_ALLOC_CACHE")[0] == '1';
-    return on;
-}
-} // namespace
-
-// Side streams come from a per-process pool and go back to it (never destroyed): the HIP runtime binds a stream to one of its few hardware
+// Streams come from a per-process pool and go back to it (never destroyed): the HIP runtime binds a stream to one of its few hardware
 // queues when the stream is created, and after handles have come and gone the streams of a NEW handle can land on the queue of the
 // caller's stream — the towers then run behind the PAN path instead of next to it (the whole benefit of the side streams, 14 %, was
 // lost for the fourth workload of bench.py).  Reused streams keep the queues they got when the process was young.
+// Lifetime protocol (round 6; tests/hostsan models it): a stream enters the pool only after it has drained (hipStreamSynchronize) and is handed
+// out only when hipStreamIsCapturing says "none" — a stream that was the origin or a fork of a capture can never carry a capture state, or work
+// of a destroyed handle, into the next handle.
 namespace {
 std::mutex g_stream_mu;
 std::vector<std::pair<int, hipStream_t>> g_free_streams; // (device, stream)
-hipError_t pooled_stream(int device, hipStream_t *s) {
+int stream_idle(hipStream_t s, const char *what) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(s, &cs));
+    if (cs != hipStreamCaptureStatusNone) return fail(std::string("stream protocol violation: ") + what + " is still part of a stream capture");
+    return 0;
+}
+int pooled_stream(int device, hipStream_t *s) {
     {
         std::lock_guard<std::mutex> lk(g_stream_mu);
         for (size_t i = 0; i < g_free_streams.size(); ++i)
             if (g_free_streams[i].first == device) {
                 *s = g_free_streams[i].second;
                 g_free_streams.erase(g_free_streams.begin() + (long)i);
-                return hipSuccess;
+                return stream_idle(*s, "a stream handed out by the pool");
             }
     }
-    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    return 0;
 }
 void unpool_stream(int device, hipStream_t s) {
+    (void)hipStreamSynchronize(s); // nothing of the handle that held it is still queued on it (wtk_yolo_destroy has synchronised the device already: this returns at once)
     std::lock_guard<std::mutex> lk(g_stream_mu);
     g_free_streams.insert(g_free_streams.begin(), {device, s}); // LIFO: the next handle gets the streams of the last one destroyed
 }
 } // namespace
 
-extern "C" int wtk_release_cached_memory(void);
+// ABI v3 symbol of the block cache of destroyed handles (an experiment of round 3, removed in round 6: it changed nothing measurable): nothing is cached
+extern "C" int wtk_release_cached_memory(void) { return 0; }
+
 static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
     *p = nullptr;
-    if (block_cache_on()) {
-        std::lock_guard<std::mutex> lk(g_block_mu);
-        for (size_t i = 0; i < g_blocks.size(); ++i)
-            if (g_blocks[i].device == h->device && g_blocks[i].bytes == bytes) {
-                *p = g_blocks[i].p;
-                g_blocks.erase(g_blocks.begin() + (long)i);
-                break;
-            }
-    }
-    if (!*p && hipMalloc(p, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)wtk_release_cached_memory(); // cached blocks of other sizes may be what is in the way
-        HIP_TRY(hipMalloc(p, bytes));
-    }
+    HIP_TRY(hipMalloc(p, bytes));
     h->dev_allocs.emplace_back(*p, bytes);
     return 0;
 }
 
 static void dev_release(wtk_yolo *h) {
-    if (block_cache_on()) {
-        std::lock_guard<std::mutex> lk(g_block_mu);
-        for (auto &a : h->dev_allocs) g_blocks.push_back({a.first, a.second, h->device});
-    } else {
-        for (auto &a : h->dev_allocs) (void)hipFree(a.first);
-    }
+    for (auto &a : h->dev_allocs) (void)hipFree(a.first);
     h->dev_allocs.clear();
-}
-
-extern "C" int wtk_release_cached_memory(void) {
-    std::lock_guard<std::mutex> lk(g_block_mu);
-    int cur = -1;
-    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-    for (auto &b : g_blocks) {
-        (void)hipSetDevice(b.device);
-        (void)hipDeviceSynchronize(); // a cached block may have been released by a handle whose kernels were enqueued from another thread
-        (void)hipFree(b.p);
-    }
-    g_blocks.clear();
-    if (have_cur) (void)hipSetDevice(cur);
-    return 0;
 }
 
 static int pick_cfg(int cout, bool k1) {
@@ -923,10 +885,12 @@ void segv_backtrace(int sig, siginfo_t *info, void *ctx) {
 __attribute__((constructor)) void install_segv_backtrace() {
     const char *e = std::getenv("WTK_SEGV_BACKTRACE");
     if (!e || e[0] != '1') return;
+    void *warm[4];
+    (void)backtrace(warm, 4); // the first call loads libgcc and allocates: done here, not inside the handler
     struct sigaction sa;
     std::memset(&sa, 0, sizeof(sa));
     sa.sa_sigaction = segv_backtrace;
-    sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER; // (no SA_ONSTACK: nobody installs an alternate stack here)
     sigemptyset(&sa.sa_mask);
     (void)sigaction(SIGSEGV, &sa, &g_old_segv);
 }
@@ -964,10 +928,78 @@ void release_status_word(int *host, int *) {
 }
 } // namespace
 
+static void drop_graphs(wtk_yolo *h);
+
+// Launch schedule of a latency-plan handle.  The forward pass is a DAG: the P3 / P4 Detect towers hang off the PAN path, a tower's box and class branches
+// off its first conv.  Round 5 spread it over three streams (61 dispatches for one frame, ~45 on the critical path, the rest beside it on streams the
+// capture forks into).  Here every op gets its dependency LEVEL — one more than the deepest earlier op it conflicts with (read-after-write,
+// write-after-write, write-after-read, at whole-buffer granularity: conservative) — and the split-K convs of one level become ONE launch
+// (conv_sk.hip: launch_conv_sk_group): 48 dispatches for YOLOv8s, all on the caller's stream, nothing to fork, nothing to join.
+static void sk_schedule(wtk_yolo *h) {
+    h->lat_sched.clear();
+    const size_t n = h->ops.size();
+    if (!h->latency || n <= 3) return;
+    auto reads = [&](const Op &o, std::vector<int> &r) {
+        r.clear();
+        for (int b : {o.in_buf, o.res_buf, o.in2_buf})
+            if (b >= 0) r.push_back(b);
+    };
+    auto writes = [&](const Op &o, std::vector<int> &w) {
+        w.clear();
+        if (o.kind == OP_POOL) w.push_back(o.in_buf); // the pool reads and writes slices of the SPPF concat buffer
+        for (int b : {o.out_buf, o.out2_buf})
+            if (b >= 0) w.push_back(b);
+        if (o.tail_op >= 0 && h->ops[o.tail_op].out_buf >= 0) w.push_back(h->ops[o.tail_op].out_buf);
+    };
+    auto meets = [](const std::vector<int> &a, const std::vector<int> &b) {
+        for (int x : a)
+            for (int y : b)
+                if (x == y) return true;
+        return false;
+    };
+    std::vector<int> level(n, 0), ri, wi, rj, wj;
+    int deepest = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (h->ops[i].folded) continue;
+        reads(h->ops[i], ri), writes(h->ops[i], wi);
+        for (size_t j = 0; j < i; ++j) {
+            if (h->ops[j].folded) continue;
+            reads(h->ops[j], rj), writes(h->ops[j], wj);
+            if (meets(wj, ri) || meets(wj, wi) || meets(rj, wi)) level[i] = std::max(level[i], level[j] + 1);
+        }
+        deepest = std::max(deepest, level[i]);
+    }
+    for (int lv = 0; lv <= deepest; ++lv) {
+        std::vector<int> group;
+        for (size_t i = 3; i < n; ++i) { // ops[0 .. 2] are the (fused) front's: launched first, as before
+            const Op &o = h->ops[i];
+            if (o.folded || level[i] != lv) continue;
+            if (o.kind == OP_CONV && o.sk) {
+                group.push_back((int)i);
+                if ((int)group.size() == kSkGroupMax) h->lat_sched.push_back(group), group.clear();
+            } else {
+                h->lat_sched.push_back({(int)i});
+            }
+        }
+        if (!group.empty()) h->lat_sched.push_back(group);
+    }
+}
+
+// Order of release (round 6: one protocol, checked by tests/hostsan): (1) the device drains — no kernel, copy or graph replay of this handle is in
+// flight; (2) the graph execs go, BEFORE the events and streams they were captured through; (3) the events; (4) the streams go back to the pool,
+// idle and outside any capture; (5) device memory.
 extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     if (!h) return;
     DeviceGuard guard(h->device); // the synchronise and the releases below are about the HANDLE's device, whatever the caller's current device is
-    (void)hipDeviceSynchronize(); // as the hipFree calls did implicitly: nothing of this handle may still be running when its blocks go back to the cache
+    (void)hipDeviceSynchronize();
+    drop_graphs(h);
+    for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
+    for (int i = 0; i < wtk_yolo::kSideStreams; ++i) {
+        if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
+    }
+    if (h->host_stream) unpool_stream(h->device, h->host_stream);
     dev_release(h);
     (void)hipFree(h->frames_dev);
     (void)hipFree(h->lb_dev);
@@ -975,17 +1007,6 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     (void)hipFree(h->nms_box);
     (void)hipFree(h->nms_cls);
     if (h->status_host) release_status_word(h->status_host, h->status_dev);
-    for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
-    for (int i = 0; i < 2; ++i)
-        if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
-    for (int i = 0; i < wtk_yolo::kSideStreams; ++i) {
-        if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
-        if (h->side_stream[i] && !(h->side_shared && i <= 2)) unpool_stream(h->device, h->side_stream[i]);
-    }
-    for (int i = 0; i < 3; ++i)
-        if (h->d1_ev[i]) (void)hipEventDestroy(h->d1_ev[i]);
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (h->host_stream) unpool_stream(h->device, h->host_stream);
     delete h;
 }
 
@@ -1034,7 +1055,6 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     h->dims = dims;
     if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
     if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
-    if (const char *e = std::getenv("WTK_SIDE_STREAMS")) h->side_streams = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 3);
     if (const char *e = std::getenv("WTK_HALO_SLABS")) h->halo_slabs = e[0] == '2' ? 2 : 3;
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
@@ -1042,7 +1062,6 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     if (const char *e = std::getenv("WTK_NO_SPLIT_CLS_TAIL")) h->use_tail_cls_split = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
-    if (const char *e = std::getenv("WTK_WS64_WEAVE")) h->ws64_weave = std::min(std::max(std::atoi(e), 0), 3);
     if (const char *e = std::getenv("WTK_NO_S2WIN")) h->use_s2win = e[0] != '1';
     if (const char *e = std::getenv("WTK_NO_C32S")) h->use_c32s = e[0] != '1';
     {
@@ -1053,13 +1072,16 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     h->latency = d->max_batch <= 4 && !h->is_f16;
     if (const char *e = std::getenv("WTK_LATENCY_PLAN")) h->latency = e[0] == '1' && !h->is_f16;
     if (plan != WTK_PLAN_AUTO) h->latency = plan == WTK_PLAN_LATENCY; // the caller's word beats the rule and the environment
-    // Replayed captures on this plan (caller buffers included: an argument set is captured the second time it is met): 0.53 ms against 0.57 ms of eager
-    // launches at B = 1 — unless the process asked the runtime for more than its four default hardware queues: a capture that forks into the side streams
-    // then ran 2-4 x SLOWER for the second and third handle of the process (profiles/r05_notes.md section 4), so such a process (bench.py's throughput
-    // lanes need the eight queues) launches eagerly.  WTK_GRAPH_VIEWS=0 / 1 decides explicitly.
-    if (h->latency) {
-        const char *q = std::getenv("GPU_MAX_HW_QUEUES");
-        h->graph_views = !(q && std::atoi(q) > 4);
+    // Replayed captures (hipGraph) are OPT-IN since round 6: WTK_GRAPH=1 (every form), or WTK_GRAPH_HOST=1 (the *_host entry points) / WTK_GRAPH_VIEWS=1
+    // (caller buffers, captured the second time an argument set is met), read when the handle is created.  Round 5 replayed by default on latency-plan
+    // handles (0.53 against 0.57 ms per single-frame call); a capture of this forward pass FORKS into the side streams, a graph exec instantiated from
+    // a forked capture runs its branches on streams the runtime creates for it, and that machinery is where the two open problems of round 5 lived (an
+    // intermittent host fault in the first capturing call of a handle after > 100 handles in the process, and replays that ran 2-4 x slower for later
+    // handles of a process with eight hardware queues): profiles/r06_notes.md section 1.  The latency plan of round 6 runs on ONE stream in launches
+    // grouped per dependency level (sk_schedule), so eager launches no longer pay for the fork either.
+    {
+        const char *g = std::getenv("WTK_GRAPH");
+        h->graph_host = h->graph_views = g && g[0] == '1';
     }
     if (h->latency) h->use_tail = 0;
     if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
@@ -1101,10 +1123,8 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
         op.spec = i0;
         // repack [cout][3][3][3(RGB)] -> K = tap*4 + channel (see stem_mfma_kernel)
         const float *w0 = d->convs[i0].weight;
-        // split mode: split-fp16 operands like every other conv of the handle (pixels / 255 and the weights as hi + lo pairs); WTK_STEM_FP32=1 keeps
-        // round 2's fp32 matrix instructions with a split store (A/B switch)
-        if (const char *e = std::getenv("WTK_STEM_FP32")) h->stem_fp32 = e[0] == '1';
-        const bool stem_split = h->split && !h->stem_fp32;
+        // split mode: split-fp16 operands like every other conv of the handle (pixels / 255 and the weights as hi + lo pairs)
+        const bool stem_split = h->split;
         const int taps = (h->is_f16 || stem_split) ? 16 : 9;
         std::vector<float> wp((size_t)c[0] * taps * 4, 0.f);
         for (int co = 0; co < c[0]; ++co)
@@ -1230,11 +1250,6 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
             for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = i == 1 ? 2 : 1; // P4 tower: side stream 2 (folded onto stream 1 at launch time when the handle runs with one side stream)
             h->ops[first_op].wait_feat = i;
         }
-        if (!P.failed && h->side_streams >= 3) { // class tower (ops +2, +4) on its own stream behind the shared first conv (op +0)
-            h->ops[first_op].signal_d1 = i;
-            h->ops[first_op + 2].side = h->ops[first_op + 4].side = 3 + i;
-            h->ops[first_op + 2].wait_d1 = i;
-        }
     }
     // A strided 3x3 conv (128 couts, implicit GEMM, fp16) whose ONLY reader is the 1x1 conv 128 -> 128 right behind it (model.3 ->
     // model.4.cv1 in YOLOv8s): the 1x1 runs in the 3x3's epilogue, its input never reaches HBM.  WTK_NO_IGEMM_TAIL=1 switches it off.
@@ -1315,6 +1330,10 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
             }
         }
     }
+    if (const char *e = std::getenv("WTK_SK_GROUP")) h->sk_group = e[0] != '0';
+    if (const char *e = std::getenv("WTK_SK_TILE")) h->sk_force_tile = std::atoi(e) >= 0 && std::atoi(e) <= 3 ? std::atoi(e) : -1;
+    if (const char *e = std::getenv("WTK_SK_FORM")) h->sk_force_form = std::atoi(e) == 0 || std::atoi(e) == 1 ? std::atoi(e) : -1;
+    sk_schedule(h);
     // ops[0..2] are stem, model.1, model.2.cv1 by construction; fuse them when the widths match the kernel
     {
         const char *e = std::getenv("WTK_NO_FUSED_FRONT");
@@ -1494,16 +1513,14 @@ static std::recursive_mutex g_side_mu;
 
 // side streams and their events, taken at the first forward pass that uses them
 static int ensure_side_streams(wtk_yolo *h) {
-    const int n_side = h->side_streams >= 3 ? wtk_yolo::kSideStreams - 1 : h->side_streams;
-    // ONE pair of side streams per process and device, shared by every handle (WTK_SHARED_SIDE=0: a pair per handle from the pool).  The HIP
-    // runtime multiplexes streams onto four hardware queues; with two lanes (two caller streams) a pair per handle made six streams, and which
-    // of them shared a queue depended on the order in which streams had been created in the process: the same workload ran at 24.5 .. 27 k
-    // frames/s (fp16) or 14.8 .. 17.7 k (hybrid) depending on what had run before it (tools/gpu_sessions/order_probe.py).  Two callers + one
-    // shared pair = four streams: every stream has a queue of its own, and the rate no longer depends on the history of the process.
-    // The towers of different handles then run one after the other on a side stream; lanes are out of phase, nothing is lost (26.8 k / 17.6 k).
-    static const bool shared = !(std::getenv("WTK_SHARED_SIDE") && std::getenv("WTK_SHARED_SIDE")[0] == '0');
-    for (int i = 1; i <= n_side; ++i) {
-        if (!h->side_stream[i] && shared && i <= 2) {
+    // ONE pair of side streams per process and device, shared by every handle and never destroyed.  The HIP runtime multiplexes streams onto its
+    // hardware queues (four by default); with two lanes (two caller streams) a pair per handle made six streams, and which of them shared a queue
+    // depended on the order in which streams had been created in the process: the same workload ran at 24.5 .. 27 k frames/s (fp16) or 14.8 .. 17.7 k
+    // (hybrid) depending on what had run before it (tools/gpu_sessions/order_probe.py).  Two callers + one shared pair = four streams: every stream
+    // has a queue of its own, and the rate no longer depends on the history of the process.  The towers of different handles then run one after the
+    // other on a side stream; lanes are out of phase, nothing is lost (26.8 k / 17.6 k).
+    for (int i = 1; i <= 2; ++i) {
+        if (!h->side_stream[i]) {
             static std::mutex mu;
             static std::vector<std::pair<int, hipStream_t>> g_shared[2]; // per slot: (device, stream)
             std::lock_guard<std::mutex> lk(mu);
@@ -1513,15 +1530,11 @@ static int ensure_side_streams(wtk_yolo *h) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
                 g_shared[i - 1].emplace_back(h->device, h->side_stream[i]);
             }
-            h->side_shared = 1;
         }
-        if (!h->side_stream[i]) HIP_TRY(pooled_stream(h->device, &h->side_stream[i]));
         if (!h->side_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming));
     }
     for (int i = 0; i < 2; ++i)
         if (!h->feat_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->feat_ev[i], hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i)
-        if (h->side_streams >= 3 && !h->d1_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->d1_ev[i], hipEventDisableTiming));
     return 0;
 }
 
@@ -1576,10 +1589,12 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
     // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
     // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
-    if (h->use_side && h->side_streams > 0 && !h->profiling && ensure_side_streams(h)) return 1;
-    const bool two_lanes = h->use_side && h->side_streams > 0 && h->side_stream[1] && !h->profiling;
+    // latency-plan handles (round 6): everything on the caller's stream, independent convs grouped per dependency level into one launch each
+    const bool grouped = h->latency && h->sk_group && !h->lat_sched.empty();
+    if (!grouped && h->use_side && h->side_streams > 0 && !h->profiling && ensure_side_streams(h)) return 1;
+    const bool two_lanes = !grouped && h->use_side && h->side_streams > 0 && h->side_stream[1] && !h->profiling;
     std::unique_lock<std::recursive_mutex> side_lock;
-    if (two_lanes && h->side_shared) side_lock = std::unique_lock<std::recursive_mutex>(g_side_mu);
+    if (two_lanes) side_lock = std::unique_lock<std::recursive_mutex>(g_side_mu);
     unsigned side_used = 0; // bit i: side_stream[i] carries work of this pass
     hipStream_t main_st = st;
     size_t first_op = 0;
@@ -1600,7 +1615,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         if (h->split) { // pseudo-channels (see the conv path below)
             f.Kpad1 *= 2, f.Kpad2 *= 2, f.out_ld *= 2, f.out_coff *= 2;
             f.n_dyn = h->n_dyn;
-            f.stem_split = !h->stem_fp32;
+            f.stem_split = 1;
             HIP_TRY(launch_front_fused_split(f, h->num_cus, st));
         } else
             HIP_TRY(launch_front_fused(f, h->num_cus, st));
@@ -1608,10 +1623,68 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         flops[5] += op_flops(o0) + op_flops(o1) + op_flops(o2);
         first_op = 3;
     }
-    for (size_t oi = first_op; oi < h->ops.size(); ++oi) {
+    // the conv of `op` as the implicit-GEMM / split-K launchers take it (split handles: pseudo-channel arguments)
+    auto conv_args = [&](const Op &op) -> ConvArgs {
+        const Buf &ib = h->bufs[op.in_buf];
+        const Buf &ob = h->bufs[op.out_buf];
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.in = ib.ptr;
+        a.in_ld = ib.C;
+        a.in_coff = op.in_coff;
+        a.N = B, a.H = ib.h, a.W = ib.w, a.Cin = op.cin;
+        a.Ho = ob.h, a.Wo = ob.w, a.Cout = op.cout;
+        a.CoutPad = op.cout_pad;
+        a.KH = a.KW = op.k;
+        a.stride = op.stride;
+        a.pad = op.k / 2;
+        a.w = op.w;
+        a.bias = op.bias;
+        a.out = ob.ptr;
+        a.out_ld = ob.C;
+        a.out_coff = op.out_coff;
+        a.out_f32 = ob.f32;
+        a.n_dyn = h->n_dyn;
+        if (op.out2_buf >= 0) {
+            a.out2 = h->bufs[op.out2_buf].ptr;
+            a.out2_ld = h->bufs[op.out2_buf].C;
+            a.out2_coff = op.out2_coff;
+        }
+        if (op.in2_buf >= 0) {
+            a.in2 = h->bufs[op.in2_buf].ptr;
+            a.in2_ld = h->bufs[op.in2_buf].C;
+            a.in2_coff = op.in2_coff;
+            a.in2_split = op.in2_split;
+        }
+        if (op.res_buf >= 0) {
+            a.res = h->bufs[op.res_buf].ptr;
+            a.res_ld = h->bufs[op.res_buf].C;
+            a.res_coff = op.res_coff;
+        }
+        a.act = op.act;
+        a.K = op.K;
+        a.Kpad = op.Kpad;
+        a.M = (long long)B * ob.h * ob.w;
+        a.tile_w = op.tile_w;
+        a.zeros = h->zero_page;
+        if (op.tile_w) {
+            const int th = conv_cfg_bm(op.cfg) / op.tile_w;
+            a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;
+            a.tiles_y = (ob.h + th - 1) / th;
+        }
+        if (h->split) {
+            // pseudo-channels: every channel count / offset of a split tensor doubles (an fp32 output keeps its real layout)
+            a.in_ld *= 2, a.in_coff *= 2, a.Cin *= 2, a.K *= 2, a.Kpad *= 2;
+            a.in2_ld *= 2, a.in2_coff *= 2, a.in2_split *= 2;
+            a.res_ld *= 2, a.res_coff *= 2, a.out2_ld *= 2, a.out2_coff *= 2;
+            if (!a.out_f32) a.out_ld *= 2, a.out_coff *= 2;
+        }
+        return a;
+    };
+    auto run_op = [&](size_t oi) -> int {
         const Op &op = h->ops[oi];
-        if (h->use_c2f && (oi == 3 || oi == 4)) continue; // folded into the fused C2f tail launched at op 5
-        if (op.folded) continue;                          // runs in the epilogue of the op that names it as tail_op
+        if (h->use_c2f && (oi == 3 || oi == 4)) return 0; // folded into the fused C2f tail launched at op 5
+        if (op.folded) return 0;                          // runs in the epilogue of the op that names it as tail_op
         if (h->use_c2f && oi == 5) {
             if (mark(5)) return 1;
             const Op &m1 = h->ops[3], &m2 = h->ops[4];
@@ -1627,14 +1700,13 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             HIP_TRY(launch_c2f_fused(c, h->num_cus, main_st));
             ++launches[5];
             flops[5] += op_flops(m1) + op_flops(m2) + op_flops(op);
-            continue;
+            return 0;
         }
         st = main_st;
         if (two_lanes && op.side) {
-            const int sidx = op.side <= 2 ? std::min(op.side, h->side_streams) : op.side; // wtk_yolo_set_side_streams(1): both towers on side stream 1
+            const int sidx = std::min(op.side, h->side_streams); // wtk_yolo_set_side_streams(1): both towers on side stream 1
             st = h->side_stream[sidx];
             if (op.wait_feat >= 0) HIP_TRY(hipStreamWaitEvent(st, h->feat_ev[op.wait_feat], 0));
-            if (op.wait_d1 >= 0) HIP_TRY(hipStreamWaitEvent(st, h->d1_ev[op.wait_d1], 0));
             side_used |= 1u << sidx;
         }
         if (op.kind == OP_STEM) {
@@ -1648,7 +1720,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             a.Cout = op.cout;
             a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
             a.out_split = h->split; // split store
-            a.in_split = h->split && !h->stem_fp32; // split operands (default) or fp32 arithmetic (WTK_STEM_FP32=1)
+            a.in_split = h->split;  // split operands
             a.n_dyn = h->n_dyn;
             HIP_TRY(launch_stem(a, h->is_f16, st));
             ++launches[0];
@@ -1667,62 +1739,12 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             if (mark(kid)) return 1;
             const Buf &ib = h->bufs[op.in_buf];
             const Buf &ob = h->bufs[op.out_buf];
-            ConvArgs a;
-            std::memset(&a, 0, sizeof(a));
-            a.in = ib.ptr;
-            a.in_ld = ib.C;
-            a.in_coff = op.in_coff;
-            a.N = B, a.H = ib.h, a.W = ib.w, a.Cin = op.cin;
-            a.Ho = ob.h, a.Wo = ob.w, a.Cout = op.cout;
-            a.CoutPad = op.cout_pad;
-            a.KH = a.KW = op.k;
-            a.stride = op.stride;
-            a.pad = op.k / 2;
-            a.w = op.w;
-            a.bias = op.bias;
-            a.out = ob.ptr;
-            a.out_ld = ob.C;
-            a.out_coff = op.out_coff;
-            a.out_f32 = ob.f32;
-            a.n_dyn = h->n_dyn;
-            if (op.out2_buf >= 0) {
-                a.out2 = h->bufs[op.out2_buf].ptr;
-                a.out2_ld = h->bufs[op.out2_buf].C;
-                a.out2_coff = op.out2_coff;
-            }
-            if (op.in2_buf >= 0) {
-                a.in2 = h->bufs[op.in2_buf].ptr;
-                a.in2_ld = h->bufs[op.in2_buf].C;
-                a.in2_coff = op.in2_coff;
-                a.in2_split = op.in2_split;
-            }
-            if (op.res_buf >= 0) {
-                a.res = h->bufs[op.res_buf].ptr;
-                a.res_ld = h->bufs[op.res_buf].C;
-                a.res_coff = op.res_coff;
-            }
-            a.act = op.act;
-            a.K = op.K;
-            a.Kpad = op.Kpad;
-            a.M = (long long)B * ob.h * ob.w;
-            a.tile_w = op.tile_w;
-            a.zeros = h->zero_page;
-            if (op.tile_w) {
-                const int th = conv_cfg_bm(op.cfg) / op.tile_w;
-                a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;
-                a.tiles_y = (ob.h + th - 1) / th;
-            }
-            if (h->split) {
-                // pseudo-channels: every channel count / offset of a split tensor doubles (an fp32 output keeps its real layout)
-                a.in_ld *= 2, a.in_coff *= 2, a.Cin *= 2, a.K *= 2, a.Kpad *= 2;
-                a.in2_ld *= 2, a.in2_coff *= 2, a.in2_split *= 2;
-                a.res_ld *= 2, a.res_coff *= 2, a.out2_ld *= 2, a.out2_coff *= 2;
-                if (!a.out_f32) a.out_ld *= 2, a.out_coff *= 2;
-            }
+            ConvArgs a = conv_args(op);
             if (op.sk) {
                 a.tile_w = 0;
                 if (!conv_sk_eligible(a, h->split)) return fail("internal: conv " + std::to_string(oi) + " of the latency plan does not fit conv_sk_kernel");
-                HIP_TRY(launch_conv_sk(a, h->split, op.sk_atoms, op.sk_partial, op.sk_tickets, h->num_cus, st));
+                const SkMember one{a, op.sk_atoms, op.sk_partial, op.sk_tickets};
+                HIP_TRY(launch_conv_sk_group(&one, 1, h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, st));
             } else if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
                 split_s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0 && !ob.f32)) {
                 // strided 3x3, split operands: the parity-plane window kernel on pseudo-channels
@@ -1787,8 +1809,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 }
                 if (ws64) {
                     g.zeros = h->zero_page;
-                    g.bm = h->ws64_weave;
-                    if (const char *e = std::getenv("WTK_WS64_FLAGS")) g.slabs = std::atoi(e);  // 8: s_setprio around the multiply phase
+                    g.bm = 0; // (the weave schedules of round 3 lost: the round-2 schedule)
 #ifdef WTK_WS64_STAMPS
                     if (std::getenv("WTK_WS64_STAMPS")) {
                         if (!g_dbg_stamps) HIP_TRY(hipMalloc(&g_dbg_stamps, kDbgStampBytes));
@@ -1819,12 +1840,6 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 if (h->small_narrow && !h->split && !ws64 && op.halo == 1 && op.tail_op < 0 && op.cout_pad % 64 == 0 && halo_cout_tile(op.cout) != 64 &&
                     4LL * g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout)) <= 3LL * h->num_cus)
                     g.narrow = 1;
-                // WTK_HALO_2CU=1 (experiment): the split window layers on maps of at most 40 x 40 as two blocks per CU
-                static const bool halo_2cu = std::getenv("WTK_HALO_2CU") && std::getenv("WTK_HALO_2CU")[0] == '1';
-                if (halo_2cu && h->split && op.halo == 1 && op.tail_op < 0 && ib.h <= 40 && !ws64) {
-                    g.bm = 128, g.two_per_cu = 1, g.narrow = 0;
-                    halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
-                }
                 // Small f16x3 handles: the 64-cout window tiles on the six-slab ring with fragment prefetch (conv3x3_halo.hip; bit-identical to the
                 // three-slab kernel).  A cycle batch's 24 x 24 layers 19.4 -> 15.9 us each; the 256-pixel tiles and the large handles measure the
                 // same either way (profiles/r05_notes.md section 7), so those keep the three-slab kernel.  WTK_HALO_DEEP: 0 off, 1 small handles
@@ -1875,8 +1890,33 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             ++launches[kid];
             flops[kid] += op_flops(op) + (op.tail_op >= 0 ? op_flops(h->ops[op.tail_op]) : 0.0);
             if (two_lanes && op.signal_feat >= 0) HIP_TRY(hipEventRecord(h->feat_ev[op.signal_feat], main_st));
-            if (two_lanes && op.signal_d1 >= 0) HIP_TRY(hipEventRecord(h->d1_ev[op.signal_d1], st));
         }
+            return 0;
+    };
+    if (grouped) {
+        // latency plan: ONE stream, one launch per dependency level (sk_schedule): ops[0 .. 2] (the front, when it did not run fused) first
+        for (size_t oi = first_op; oi < 3 && oi < h->ops.size(); ++oi)
+            if (run_op(oi)) return 1;
+        for (const std::vector<int> &L : h->lat_sched) {
+            if (L.size() == 1) {
+                if (run_op((size_t)L[0])) return 1;
+                continue;
+            }
+            if (mark(1)) return 1;
+            SkMember m[kSkGroupMax];
+            for (size_t k = 0; k < L.size(); ++k) {
+                const Op &op = h->ops[L[k]];
+                m[k] = SkMember{conv_args(op), op.sk_atoms, op.sk_partial, op.sk_tickets};
+                m[k].a.tile_w = 0;
+                if (!conv_sk_eligible(m[k].a, h->split)) return fail("internal: conv " + std::to_string(L[k]) + " of the latency plan does not fit conv_sk_kernel");
+                flops[1] += op_flops(op);
+            }
+            HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st));
+            ++launches[1];
+        }
+    } else {
+        for (size_t oi = first_op; oi < h->ops.size(); ++oi)
+            if (run_op(oi)) return 1;
     }
     st = main_st;
     for (int i = 1; i < wtk_yolo::kSideStreams; ++i)
@@ -1904,14 +1944,19 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
     return 0;
 }
 
-// Captured launches carry the stream layout / dynamic-batch pointer they were captured with: drop them all.  Each exec is destroyed only after the
-// stream of its last replay has drained (no device-wide synchronise: other lanes keep running, and a global-mode capture open in another thread
-// stays legal); argument sets met once are forgotten too.
-static void drop_graphs(wtk_yolo *h) {
-    for (auto &g : h->graphs) {
-        (void)hipStreamSynchronize(g.last_stream);
-        (void)hipGraphExecDestroy(g.exec);
+// Captured launches carry the stream layout / dynamic-batch pointer they were captured with: drop them all.  Each exec is destroyed only after its last
+// replay has finished (its own event; no device-wide synchronise: other lanes keep running, and a global-mode capture open in another thread stays
+// legal); argument sets met once are forgotten too.
+static void destroy_graph_entry(wtk_yolo::GraphEntry &g) {
+    if (g.done) {
+        (void)hipEventSynchronize(g.done);
+        (void)hipEventDestroy(g.done);
     }
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    g.exec = nullptr, g.done = nullptr;
+}
+static void drop_graphs(wtk_yolo *h) {
+    for (auto &g : h->graphs) destroy_graph_entry(g);
     h->graphs.clear();
     h->seen_once.clear();
 }
@@ -1921,12 +1966,18 @@ static int graph_replay_or_capture(wtk_yolo *h, wtk_yolo::GraphEntry key, hipStr
     for (auto &g : h->graphs)
         if (g.same_args(key)) {
             HIP_TRY(hipGraphLaunch(g.exec, st));
-            g.last_stream = st;
+            HIP_TRY(hipEventRecord(g.done, st));
             return 0;
         }
     hipGraph_t graph = nullptr;
-    if (h->use_side && h->side_streams > 0 && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
+    const bool forks = !(h->latency && h->sk_group && !h->lat_sched.empty()) && h->use_side && h->side_streams > 0;
+    if (forks && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
     std::unique_lock<std::recursive_mutex> capture_lock(g_side_mu); // no other thread may touch the shared side streams while they are captured
+    // protocol: the origin and the streams the capture will fork into are outside any capture when it begins (a stream left inside one by a failed
+    // bracket, here or in the caller's code, must not be captured again: fail loudly instead)
+    if (stream_idle(st, "the stream a capture is about to begin on")) return 1;
+    for (int i = 1; i < wtk_yolo::kSideStreams; ++i)
+        if (h->side_stream[i] && stream_idle(h->side_stream[i], "a side stream")) return 1;
     HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = yolo_enqueue(h, reinterpret_cast<const uint8_t *>(key.frames), key.B, key.H, key.W, key.C, key.conf, reinterpret_cast<float *>(key.o_xywh),
                                 reinterpret_cast<float *>(key.o_conf), reinterpret_cast<int32_t *>(key.o_anchor), st, vs);
@@ -1940,15 +1991,17 @@ static int graph_replay_or_capture(wtk_yolo *h, wtk_yolo::GraphEntry key, hipStr
     const hipError_t ei = hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) return fail_hip("hipGraphInstantiate", ei);
+    if (hipEventCreateWithFlags(&key.done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGraphExecDestroy(key.exec);
+        return fail("hipEventCreateWithFlags failed");
+    }
     if (h->graphs.size() >= 16) { // bounded cache: callers that rotate buffers would otherwise grow it without limit
-        if (h->graphs.front().last_stream != st) (void)hipStreamSynchronize(h->graphs.front().last_stream); // (the same stream orders the destroy behind the replay itself)
-        else (void)hipStreamSynchronize(st);
-        (void)hipGraphExecDestroy(h->graphs.front().exec);
+        destroy_graph_entry(h->graphs.front());
         h->graphs.erase(h->graphs.begin());
     }
-    key.last_stream = st;
     h->graphs.push_back(key);
     HIP_TRY(hipGraphLaunch(key.exec, st));
+    HIP_TRY(hipEventRecord(key.done, st));
     return 0;
 }
 
@@ -1968,17 +2021,11 @@ extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t 
         HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
         h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
     }
-    // Small batches are launch bound (~62 launches of a few microseconds): replay a captured hipGraph.
-    // Only for the handle's own staging buffers (the *_host entry points): their addresses never change, so
-    // one capture per (B, H, W, C, conf) is replayed forever; arbitrary caller buffers would thrash the cache.
+    // Opt-in (WTK_GRAPH / WTK_GRAPH_HOST / WTK_GRAPH_VIEWS, see wtk_yolo_create_planned): replay a captured hipGraph of the forward pass.  The handle's own
+    // staging buffers (the *_host entry points) never change address, so one capture per (B, H, W, C, conf) is replayed forever; a caller's argument set
+    // is captured the second time it is met, so a caller that rotates its buffers never pays for a capture.
     const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
-    // With WTK_GRAPH_VIEWS=1 a latency-plan handle also replays for caller buffers: an argument set is captured the second time it is met, so a caller
-    // that rotates its buffers never pays for a capture.
-    // Throughput-plan handles launch eagerly: on their host entry points the replay measured 0.726 / 1.218 ms against 0.720 / 1.197 ms eager (f16x3, B = 1 /
-    // 15 at 384^2; fp16 1-5 % the other way, r5_host_graph.py), and a test run makes hundreds of captures — one intermittent host crash inside such a first
-    // call was seen twice in ~25 suite runs.  WTK_GRAPH_HOST=1 brings the replay back for them.
-    const bool use_graph = ((own_buffers && (h->latency || h->graph_host)) || (h->latency && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 &&
-                           B <= h->graph_max_batch;
+    const bool use_graph = ((own_buffers && h->graph_host) || (!own_buffers && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
     if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
     wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
     if (!own_buffers) {
@@ -2071,7 +2118,7 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
         HIP_TRY(hipMalloc(&h->frames_dev, cap));
         h->frames_cap = cap;
     }
-    if (!h->host_stream) HIP_TRY(pooled_stream(h->device, &h->host_stream));
+    if (!h->host_stream && pooled_stream(h->device, &h->host_stream)) return 1;
     hipStream_t st = h->host_stream;
     HIP_TRY(hipMemcpyAsync(h->frames_dev, frames_host, need, hipMemcpyHostToDevice, st));
     if (wtk_yolo_predict(h, h->frames_dev, B, H, W, C, conf, iou, max_det, h->o_xywh, h->o_conf, h->o_anchor, st)) return 1;
@@ -2084,7 +2131,6 @@ extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, in
 
 extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
     if (!h || n < 0 || n > 2) return fail("wtk_yolo_set_side_streams: n must be 0, 1 or 2");
-    if (h->side_streams >= 3) return fail("wtk_yolo_set_side_streams: the handle was planned with WTK_SIDE_STREAMS=3");
     DEVICE_GUARD(h);
     drop_graphs(h); // captured launches (host stream or a caller's) carry the old stream layout
     h->side_streams = n;

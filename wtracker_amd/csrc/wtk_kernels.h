@@ -209,6 +209,49 @@ size_t conv_sk_partial_bytes(const ConvArgs &a, int split, int atoms = 0); // sc
 // tickets: conv_sk_ticket_count(a) zero-initialised counters of this op (the last block of a tile combines the slabs in-kernel), or null (second launch: sk_finish_kernel)
 size_t conv_sk_ticket_count(long long M, int cout_pad);
 hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t stream); // atoms = 0: conv_sk_slices(nk)
+// ... and up to kSkGroupMax such convs that do not depend on each other as ONE launch (the latency plan's dependency levels, csrc/wtk_api.hip: sk_schedule).
+// force_tile 0..3 / force_form 0 (one block per atom), 1 (one block walks all atoms): test hooks, -1 = the cost model decides.  Bit-identical to n launches.
+constexpr int kSkGroupMax = 4;
+struct SkMember {
+    ConvArgs a;
+    int atoms;         // 0: conv_sk_slices(nk)
+    float *partial;    // slab scratch of this conv (null: one atom)
+    unsigned *tickets; // its arrival counters (null: sk_finish_kernel as a second launch)
+};
+hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t stream);
+// the kernel's view of one conv and of a grouped launch (here, not in conv_sk.hip, so that the host-side launch checker of tests/hostsan can read them)
+struct SkArgs {
+    const char *in;  // input tensor (slice view): byte pitch per pixel, byte offset of the first channel
+    unsigned in_ldb, in_offb;
+    const char *in2; // optional half-resolution source of the first in2_blocks 32-channel blocks (nn.Upsample(2x) + Concat, 1x1 only)
+    unsigned in2_ldb, in2_offb;
+    int in2_blocks;
+    int N, H, W, Ho, Wo;
+    int cpb;              // 32-channel blocks per tap
+    int KW, stride, pad;  // square taps: KH == KW
+    int nk, S;            // K steps in all (taps * cpb); blocks per tile along K: 1 or NA
+    int NA;               // K atoms of the layer (conv_sk_slices): the unit of summation, see the header
+    const char *w;        // [CoutPad][nk * 128 bytes]
+    unsigned w_rowb;
+    const float *bias;
+    int Cout, CoutPad, act;
+    void *out;
+    int out_ld, out_coff, out_f32; // elements of the storage type (SPLIT: pseudo-channels unless out_f32), as ConvArgs
+    const void *res;
+    int res_ld, res_coff;
+    float *partial; // S > 1: [S][M][CoutPad] fp32
+    unsigned *tickets; // S > 1, nullable: one arrival counter per (pixel tile, cout tile), zero between launches — the block that arrives LAST combines the
+                       // slabs itself (no second launch); null: sk_finish_kernel does it
+    long long M;
+    int ptiles, nct;
+    FastDiv d_ptiles, d_nct, d_howo, d_wo, d_cpb, d_cg;
+    const int *n_dyn;
+};
+
+struct SkGroupArgs {
+    SkArgs p[kSkGroupMax];
+    unsigned first[kSkGroupMax]; // first block of member i (first[0] = 0; unused members: 0xffffffff)
+};
 // fp16 1x1 / stride-1 convs with a 256 x 128 tile, 32-deep K steps and a three-stage LDS ring (conv1x1_wide.hip)
 bool conv1x1_wide_eligible(const ConvArgs &a, int is_f16);
 hipError_t launch_conv1x1_wide(ConvArgs a, hipStream_t stream);
