@@ -224,7 +224,7 @@ def closed_loop(weights, scale: str, nc: int, device: int, conf: float) -> dict:
     out["deferred_log"] = ("*_deferred_log = the same loop under TrackLogger(deferred=True): the cycle batch — which feeds nothing back into the loop — is enqueued at the "
                            "cycle's end on the controller's second lane and its rows are written one cycle later, so it runs on the GPU beside the next cycle's single-frame "
                            "call (a handle each under plan 'auto'); same moves, same rows, the last batch collected inside the timed run")
-    out["plans"] = ("*_auto = YoloConfig.plan 'auto' (the default): the single-frame call on a latency-plan handle (split-K convs, conv_sk.hip, replayed hipGraph), the "
+    out["plans"] = ("*_auto = YoloConfig.plan 'auto' (the default): the single-frame call on a latency-plan handle (split-K convs grouped per dependency level, conv_sk.hip; eager launches on one stream), the "
                     "15-frame call on a throughput-plan handle — each call on the plan that is faster for it; f16x3_latency = both calls on ONE latency-plan handle (a frame's "
                     "result is bit-identical whichever call sees it); f16x3_throughput = both calls on the large-batch kernels (what every call ran on before round 5)")
     # the CPU restatement's controller on the host cores, same frames and driver
@@ -350,8 +350,9 @@ def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
                 if plan == "large_batch_kernels":
                     os.environ["WTK_NO_SK_MIXED"] = "1"
                     os.environ["WTK_SMALL_NARROW"] = "0"
-                det = hip.HipYolo(weights, (size, size), 16, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch, device=device,
-                                  plan="throughput" if plan == "large_batch_kernels" else plan)
+                # handle sizes as the controller makes them (controllers._YoloModel.detector): the latency-plan handle of plan "auto" holds 4 frames, the others 16
+                det = hip.HipYolo(weights, (size, size), 4 if plan == "latency" and B <= 4 else 16, dtype=dtype, nc=nc, width=width, depth=depth, max_channels=maxch,
+                                  device=device, plan="throughput" if plan == "large_batch_kernels" else plan)
                 if plan == "large_batch_kernels":
                     os.environ.pop("WTK_NO_SK_MIXED") if prev is None else os.environ.__setitem__("WTK_NO_SK_MIXED", prev)
                     os.environ.pop("WTK_SMALL_NARROW", None)
@@ -361,7 +362,7 @@ def latency_leg(weights, scale: str, nc: int, device: int, conf: float) -> dict:
                 c = torch.empty((B,), dtype=torch.float32, device=dev)
                 a = torch.empty((B,), dtype=torch.int32, device=dev)
                 call = lambda: det.predict(f, B, size, size, 1, x, c, a, conf=conf, stream=st.cuda_stream)
-                for _ in range(5):  # eager, capture, replays
+                for _ in range(5):  # warm-up (eager launches since round 6; with WTK_GRAPH=1: eager, capture, replays)
                     call()
                 st.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -440,6 +441,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip headline_check (profiling passes: nothing but the timed workload's kernels in the trace)")
     ap.add_argument("--legs-child", action="store_true", help=argparse.SUPPRESS)  # internal: run closed_loop / latency_leg and print them as one JSON line
     ap.add_argument("--no-latency", action="store_true", help="skip the latency sub-object (B = 1 / 15 at 384^2, B = 1 at 640^2: the reference's calls and BASELINE config 2)")
+    ap.add_argument("--legs-subprocess", action="store_true", help="run the small-batch legs (closed_loop, latency) in a child process without GPU_MAX_HW_QUEUES (round 5's arrangement, kept for A/B: since round 6 the legs give the same device times in this process)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed_loop sub-object (the reference's real operating point: 360 -> 384 views, 15-frame cycles)")
     ap.add_argument("--conf", type=float, default=0.1)
     ap.add_argument("--defer", type=int, default=HYBRID_DEFER, help="hybrid: batches of a lane whose weak rows share one full-precision pass (1 = second look inside every step)")
@@ -791,13 +793,18 @@ def main():
     else:  # no CPU leg: the device-side check alone (fp32 IS the reference's arithmetic; --no-check: nothing was verified)
         verified = bool(head_check and head_check["verified"]) if head_dtype != "fp32" else True
 
-    # The two small-batch legs run in a CHILD process with the environment a controller user has: this process asked the HIP runtime for eight hardware
-    # queues (its two throughput lanes need them) and has created and destroyed a dozen handles and their streams by now — both change what a chain of
-    # ~60 short dependent launches costs (profiles/r05_notes.md section 4: the same call 0.53 ms in a fresh process, 1-2 ms here).
+    # The two small-batch legs run in THIS process since round 6 (round 5 needed a child process: its replayed captures forked into side streams and ran 2-4 x slower
+    # here, where eight hardware queues are requested and a dozen handles have come and gone).  Handles of <= 16 frames now run on the caller's stream alone, eagerly:
+    # same device times in either process (0.512 / 0.510 ms single frame, 1.132 / 1.134 ms cycle batch; profiles/r06_notes.md section 4); --legs-subprocess is the A/B.
     closed = lat = None
     want_closed = world == 1 and not args.no_closed_loop and not args.no_fp32
     want_lat = world == 1 and not args.no_latency and not args.no_fp32 and args.size == 640
-    if want_closed or want_lat:
+    if (want_closed or want_lat) and not args.legs_subprocess:
+        if want_closed:
+            closed = closed_loop(weights, "s", 1, local_rank, args.conf)
+        if want_lat:
+            lat = latency_leg(weights, "s", 1, local_rank, args.conf)
+    elif want_closed or want_lat:
         import subprocess
 
         env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
@@ -851,9 +858,10 @@ def main():
         # two scalars per reference-precision mode in the main line: the reference's two calls, each on the plan the controller's default ("auto":
         # controllers._YoloModel.detector) gives it — the single frame on a latency-plan handle, the cycle batch on a small throughput-plan handle
         for r in lat["rows"]:
-            if r["size"] == 384 and r["plan"] == ("latency" if r["batch"] <= 4 else "throughput"):
-                out[f"latency_b{r['batch']}_384_{r['dtype']}_ms"] = r["device_ms"]
-        lat["main_line"] = "latency_b1_* = the latency-plan row, latency_b15_* = the throughput-plan row (the plan YoloConfig.plan = 'auto' picks per call)"
+            if r["plan"] == ("latency" if r["batch"] <= 4 else "throughput"):  # 384: the reference's imgsz; 640, B = 1: BASELINE configs[1]
+                out[f"latency_b{r['batch']}_{r['size']}_{r['dtype']}_ms"] = r["device_ms"]
+        lat["main_line"] = ("latency_b1_* = the latency-plan row, latency_b15_* = the throughput-plan row (the plan YoloConfig.plan = 'auto' picks per call); "
+                            "latency_b1_640_* = BASELINE configs[1] (YoloController, 640 x 640, batch 1)")
     # flat per-mode keys (a record that keeps only top-level scalars still carries every mode and its exactness)
     for dt, m in modes.items():
         out[f"value_{dt}"] = m["value"]

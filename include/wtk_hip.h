@@ -134,11 +134,16 @@ void wtk_yolo_destroy(wtk_yolo *h);
  *   WTK_PLAN_LATENCY     the reference's own operating point — one call of cycle_frame_num (9 / 15) frames and one single-frame
  *                        call per cycle at imgsz 384 (yolo_controller.py:96-98,108-109; initialize_experiment.ipynb: imgsz 384):
  *                        every conv is cut along K as well (split-K implicit GEMM + a slab-combining pass), so that a layer of a
- *                        few thousand pixels still runs on every CU, and calls with a repeating argument set replay a captured
- *                        hipGraph.  WTK_F32 and WTK_F16X3 only (WTK_F16 handles stay on the throughput plan).
+ *                        few thousand pixels still runs on every CU, and the convs of one dependency level of the network (a Detect
+ *                        tower's box and class convs, a PAN layer and the tower of the feature map before it) run as ONE launch on
+ *                        the caller's stream: 48 dependent launches per YOLOv8s forward, no side streams.  WTK_F32 and WTK_F16X3
+ *                        only (WTK_F16 handles stay on the throughput plan).
  *   WTK_PLAN_AUTO        (= wtk_yolo_create) latency when max_batch <= 4 and the dtype allows it, else throughput (measured on MI355X at imgsz 384:
- *                        B = 1 0.53 ms against 0.67-1.00 ms on the throughput plan, B = 15 1.5 ms against 1.2 ms — the cross-over lies near B = 6); the
+ *                        B = 1 0.51 ms against 0.67-1.00 ms on the throughput plan, B = 15 1.5 ms against 1.1 ms — the cross-over lies near B = 6); the
  *                        environment variable WTK_LATENCY_PLAN=0 / 1 overrides AUTO only.
+ * Launches are eager.  Replaying a captured hipGraph of the forward pass is opt-in (environment WTK_GRAPH=1, read when the handle is created): the
+ * throughput plan's capture forks into the library's side streams, and the runtime's handling of such graphs is where round 5's two open problems
+ * lived (profiles/r06_notes.md section 1).
  * The plan never changes per call: within a handle a frame's logits do not depend on the batch it arrives in.  Both plans meet the
  * same tolerances against the fp32 restatement; they are not bit-identical to each other (K is summed in a different order). */
 typedef enum wtk_plan { WTK_PLAN_AUTO = 0, WTK_PLAN_THROUGHPUT = 1, WTK_PLAN_LATENCY = 2 } wtk_plan;
@@ -300,8 +305,7 @@ int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev);
  * (two lanes, a second-look handle) can have too many streams in flight; the side streams themselves are ONE pair per process and
  * device, shared by all handles. */
 int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n);
-/* With WTK_ALLOC_CACHE=1 destroyed detector handles keep their device memory in a per-process block cache (reused by the next
- * handle that needs a block of exactly that size) instead of returning it to the driver.  This gives the cached blocks back. */
+/* ABI v3 symbol of the (removed) block cache of destroyed handles: nothing is cached any more, the call returns 0. */
 int wtk_release_cached_memory(void);
 int wtk_recheck_merge(const float *margins_dev, const int32_t *slots_dev, int32_t B, int32_t K, float margin,
                       const float *src_xywh, const float *src_conf, const int32_t *src_anchor, float *dst_xywh,

@@ -37,7 +37,8 @@ def canned(n_kernels=20):
          "headline_check": {"against": "a" * 150, "frames": 128, "index_mismatches": 0, "box_abs_diff_max_px": 0.000823974609375, "verified": True},
          "end_to_end": {"frac": 0.37}, "closed_loop": {"what": "w" * 300, "f16x3_eager": {"frames_per_s": 5893.0}},
          "latency": {"what": "w" * 300, "rows": [{"mode": m, "shape": s, "device_ms": 0.4, "host_ms": 0.5} for m in ("f16x3", "fp32") for s in ("b1_384", "b15_384", "b1_640")]},
-         "latency_b1_384_f16x3_ms": 0.41234567, "latency_b15_384_f16x3_ms": 0.71234567, "closed_loop_f16x3_frames_per_s": 8309.536123,
+         "latency_b1_384_f16x3_ms": 0.41234567, "latency_b15_384_f16x3_ms": 0.71234567, "latency_b1_384_fp32_ms": 0.61234567, "latency_b15_384_fp32_ms": 2.21234567,
+         "latency_b1_640_f16x3_ms": 0.64234567, "latency_b1_640_fp32_ms": 0.88234567, "closed_loop_f16x3_frames_per_s": 8309.536123,
          "closed_loop_f16x3_deferred_log_frames_per_s": 11488.971456,
          "cpu_baseline": {"value": 15.374184052472774, "unit": "frames/s", "cores": 32, "kind": "port", "by_batch": {"64": {}}, "sample": "s" * 300},
          "parity": {"checker": "c" * 100, "frames": "f", "headline_gate": "g", "floors_asserted_in_tests": "t" * 300, "fp16": acc, "fp32": acc, "f16x3": acc, "hybrid": acc},
@@ -72,6 +73,8 @@ def test_final_line_is_short_strict_json_with_the_contract_keys(tmp_path, monkey
     assert line["parity"]["f16x3"] == {"index_match_rate": 1.0, "iou_matched_min": pytest.approx(0.9999976, abs=1e-6)}
     assert all(f"value_{dt}" in line for dt in ("f16x3", "fp16", "hybrid", "fp32"))
     assert line["latency_b1_384_f16x3_ms"] == pytest.approx(0.41235, rel=1e-4)
+    # BASELINE configs[1] (YoloController, 640 x 640, batch 1) travels in the line the driver parses
+    assert line["latency_b1_640_f16x3_ms"] == pytest.approx(0.64235, rel=1e-4) and line["latency_b1_640_fp32_ms"] == pytest.approx(0.88235, rel=1e-4)
     assert line["closed_loop_f16x3_frames_per_s"] == pytest.approx(8309.5, rel=1e-4) and line["closed_loop_f16x3_deferred_log_frames_per_s"] == pytest.approx(11489.0, rel=1e-4)
     assert line["config"]["workload"].startswith("BASELINE configs[2]") and "model" not in line["config"]
     for k in ("closed_loop", "latency", "hybrid_calibration", "f16x3", "fp32", "hybrid", "fp16_throughput"):

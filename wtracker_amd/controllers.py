@@ -503,7 +503,8 @@ class HipYoloController(SimController):
         # launch bound), which needs a stream of the controller's own: the legacy default stream cannot be captured.
         stream = self._view_streams.get(lane)
         if stream is None:
-            # (a high-priority stream for lane 0 — the call the loop waits for — measured 2-4 x SLOWER cycles: one more hardware queue, profiles/r05_notes.md)
+            # (a high-priority stream for lane 0 — the call the loop waits for — changes nothing once the handles run on one stream each: deferred log 11.19 k
+            # against 10.81-11.19 k frames/s, single-frame call 0.87 against 0.86 ms; with side streams it cost the cycle batch 30 %: profiles/r06_notes.md section 4)
             stream = self._view_streams[lane] = torch.cuda.Stream(device=dev)
         # A detector handle has ONE set of activation buffers: a call on another lane that still runs on the same handle (plan "latency" / "throughput":
         # both calls of a cycle share a handle) is waited for first; with plan "auto" the two calls have a handle each and overlap.

@@ -29,10 +29,12 @@
 //   fp32   32 floats per row, exact v_mfma_f32_16x16x4_f32
 #include "wtk_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace wtk {
 namespace {
@@ -495,6 +497,22 @@ static void sk_member_cost(const SkShape &c, const SkTile &t, int S, int split, 
         *handoff_us = slab_bytes <= (double)sk_inkernel_max() ? 4.0 + S * tile_kb / 60.0 : 3.0 + slab_bytes / 5.0e6;
     }
 }
+// list scheduling of a grouped launch: member i contributes b[i] blocks of u[i] microseconds each, dispatched in member order, one block per CU at a time
+static double sk_makespan(const double *b, const double *u, int n, int cus) {
+    std::vector<double> heap((size_t)std::max(cus, 1), 0.0); // min-heap of the CUs' free times
+    auto cmp = [](double x, double y) { return x > y; };
+    double end = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (long long k = 0; k < (long long)b[i]; ++k) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const double t = heap.back() + u[i];
+            heap.back() = t;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+            end = std::max(end, t);
+        }
+    return end;
+}
+
 // Form (per member) and tile (one per launch: the instantiation) of a launch of n independent convs: blocks run one per CU (96-128 KB of LDS) in rounds
 // over the concatenated grid; a round lasts as long as its slowest block, the hand-offs of the members run side by side.  For n = 1 this is round 5's
 // model of a single launch.  force_tile / force_form: the test hooks (0..3 / 0: always S = NA, 1: always S = 1; -1: free).
@@ -525,7 +543,15 @@ static double sk_choose(const SkShape *c, int n, int num_cus, int split, int for
                 blocks += b, slowest = std::max(slowest, bu), handoff = std::max(handoff, hu);
             }
             if (!ok) continue;
-            const double tt = std::ceil(blocks / (double)num_cus) * slowest + handoff;
+            double tt;
+            if (n == 1) {
+                tt = std::ceil(blocks / (double)num_cus) * slowest + handoff; // identical blocks: whole rounds
+            } else {
+                // members of different block lengths share the CUs: blocks are handed out in launch order to whichever CU frees up first
+                double b_i[kSkGroupMax], u_i[kSkGroupMax], hu;
+                for (int i = 0; i < n; ++i) sk_member_cost(c[i], t, S[i], split, &b_i[i], &u_i[i], &hu);
+                tt = sk_makespan(b_i, u_i, n, num_cus) + handoff;
+            }
             if (tt < best_t) {
                 best_t = tt, *tile = ti;
                 for (int i = 0; i < n; ++i) S_out[i] = S[i];
@@ -612,26 +638,14 @@ static hipError_t sk_fill(SkArgs &k, const SkMember &m, int split) {
 
 // n <= kSkGroupMax convs that do not depend on each other, as ONE launch.  Form (per member) and tile (per launch) are chosen by the cost model: neither
 // enters the arithmetic (see the header), so a grouped launch gives every member the bits its own launch would give it.
-hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t st) {
-    if (n < 1 || n > kSkGroupMax) return hipErrorInvalidValue;
-    SkGroupArgs g;
-    SkShape shapes[kSkGroupMax];
-    for (int i = 0; i < n; ++i) {
-        const hipError_t e = sk_fill(g.p[i], m[i], split);
-        if (e != hipSuccess) return e;
-        shapes[i] = {g.p[i].M, g.p[i].CoutPad, g.p[i].nk, g.p[i].NA};
-    }
-    for (int i = n; i < kSkGroupMax; ++i) std::memset(&g.p[i], 0, sizeof(SkArgs));
-    int tile = 3, S[kSkGroupMax];
-    const double est = sk_choose(shapes, n, num_cus, split, force_tile, force_form, &tile, S);
-    static const int verbose = sk_env("WTK_SK_VERBOSE", 0);
+// one launch of g.p[0 .. n) with the given tile and forms (+ the second launches of members whose slabs are not combined in-kernel)
+static hipError_t sk_launch_chosen(SkGroupArgs &g, const SkMember *m, int n, int tile, const int *S, int split, hipStream_t st) {
     for (int i = 0; i < n; ++i) {
         SkArgs &k = g.p[i];
         k.S = S[i];
         k.tickets = (k.S > 1 && (long long)k.S * k.M * k.CoutPad * 4 <= sk_inkernel_max()) ? m[i].tickets : nullptr;
-        if (verbose)
-            std::fprintf(stderr, "conv_sk%s: M %lld cout %d nk %d atoms %d -> tile %d form S=%d (launch est %.1f us)\n", n > 1 ? " (grouped)" : "", k.M, k.CoutPad, k.nk, k.NA, tile, k.S, est);
     }
+    for (int i = n; i < kSkGroupMax; ++i) std::memset(&g.p[i], 0, sizeof(SkArgs));
     hipError_t e;
     switch (tile) {
     case 0: e = split ? sk_launch_t<true, 128, 128, 2, 4, 4>(g, n, st) : sk_launch_t<false, 128, 128, 2, 4, 4>(g, n, st); break;
@@ -653,9 +667,57 @@ hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus
     return hipSuccess;
 }
 
+// n <= kSkGroupMax convs that do not depend on each other, as ONE launch.  Form (per member) and tile (per launch) are chosen by the cost model: neither
+// enters the arithmetic (see the header), so a grouped launch gives every member the bits its own launch would give it.
+hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t st, SkChoice *choice) {
+    if (n < 1 || n > kSkGroupMax) return hipErrorInvalidValue;
+    SkGroupArgs g;
+    SkShape shapes[kSkGroupMax];
+    for (int i = 0; i < n; ++i) {
+        const hipError_t e = sk_fill(g.p[i], m[i], split);
+        if (e != hipSuccess) return e;
+        shapes[i] = {g.p[i].M, g.p[i].CoutPad, g.p[i].nk, g.p[i].NA};
+    }
+    SkChoice local;
+    SkChoice &ch = choice ? *choice : local;
+    if (!ch.valid) { // the cost model runs once per (launch, batch size) of a handle: the caller keeps the choice
+        ch.est_us = sk_choose(shapes, n, num_cus, split, force_tile, force_form, &ch.tile, ch.S);
+        ch.separate = 0;
+        if (n > 1) { // many pixels: the members' own launches (each with the tile it likes best) can beat one grid with a common tile
+            double sum = 0.0;
+            for (int i = 0; i < n; ++i) {
+                int s1[kSkGroupMax];
+                sum += sk_choose(&shapes[i], 1, num_cus, split, force_tile, force_form, &ch.m_tile[i], s1) + 2.5; // + a dependent launch
+                ch.m_S[i] = s1[0];
+            }
+            ch.separate = sum < ch.est_us + 2.5;
+            // measured (profiles/r06_notes.md section 2): grouping gains at B = 1 .. 4 of imgsz 384 / 640 and loses 4 % at B = 15, where one member alone fills the
+            // chip several times over — such levels run as their members' own launches whatever the model says
+            for (int i = 0; i < n; ++i)
+                if (shapes[i].M > 16384) ch.separate = 1;
+        }
+        ch.valid = 1;
+        static const int verbose = sk_env("WTK_SK_VERBOSE", 0);
+        if (verbose)
+            for (int i = 0; i < n; ++i)
+                std::fprintf(stderr, "conv_sk%s: M %lld cout %d nk %d atoms %d -> tile %d form S=%d (launch est %.1f us%s)\n", n > 1 ? " (grouped)" : "", g.p[i].M, g.p[i].CoutPad,
+                             g.p[i].nk, g.p[i].NA, ch.separate ? ch.m_tile[i] : ch.tile, ch.separate ? ch.m_S[i] : ch.S[i], ch.est_us, ch.separate ? ", launched one by one" : "");
+    }
+    if (n > 1 && ch.separate) {
+        for (int i = 0; i < n; ++i) {
+            SkGroupArgs one;
+            one.p[0] = g.p[i];
+            const hipError_t e = sk_launch_chosen(one, &m[i], 1, ch.m_tile[i], &ch.m_S[i], split, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    return sk_launch_chosen(g, m, n, ch.tile, ch.S, split, st);
+}
+
 hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
     const SkMember m{a, atoms, partial, tickets};
-    return launch_conv_sk_group(&m, 1, split, num_cus, -1, -1, st);
+    return launch_conv_sk_group(&m, 1, split, num_cus, -1, -1, st, nullptr);
 }
 
 } // namespace wtk

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -560,6 +561,7 @@ struct wtk_yolo {
     // latency plan, round 6: the convs of one dependency level run as ONE grouped split-K launch on the caller's stream (sk_schedule).
     int sk_group = 1;                      // WTK_SK_GROUP=0: one launch per conv, in op order (test hook: the grouped launches must give the same bits)
     int sk_force_tile = -1, sk_force_form = -1; // WTK_SK_TILE / WTK_SK_FORM, read when the handle is created (test hooks: every tile and form gives the same bits)
+    std::map<long long, SkChoice> sk_choices; // (launch or op, batch) -> what the split-K cost model chose (it runs once per key, not per call)
     std::vector<std::vector<int>> lat_sched; // launches behind ops[0..2] in order: one op, or up to kSkGroupMax split-K ops that do not depend on each other
     int small_narrow = 0; // a small handle (max_batch <= 16, f16x3) runs window / implicit-GEMM layers whose grid leaves most CUs idle on 64-cout tiles (WTK_SMALL_NARROW=0: off)
     int halo_deep = 0;    // f16x3: the 64-cout x 128-pixel window tiles on the six-slab ring (small handles; WTK_HALO_DEEP)
@@ -1054,7 +1056,13 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
     h->max_batch = d->max_batch;
     h->dims = dims;
     if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
-    if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = !(e[0] == '1');
+    // Side streams are for LARGE batches.  A handle for the reference's own calls (max_batch <= 16: one frame, one cycle batch) runs on the caller's stream
+    // alone: its launches last 5-50 us, and a dependency between two streams costs microseconds when the runtime has put them on different hardware
+    // queues, nothing when they share one — so with side streams the same controller loop ran at 7.6 k or 4.4 k frames/s (throughput plan), 9.0 k or
+    // 11.2 k (deferred log) depending on GPU_MAX_HW_QUEUES and on which streams the process had created before; on one stream it runs at the same rate
+    // in every such environment (profiles/r06_notes.md section 4).  wtk_yolo_set_side_streams(h, 2) turns them on for such a handle explicitly.
+    if (d->max_batch <= 16) h->use_side = 0, h->side_streams = 0;
+    if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = h->use_side && !(e[0] == '1');
     if (const char *e = std::getenv("WTK_HALO_SLABS")) h->halo_slabs = e[0] == '2' ? 2 : 3;
     if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
     if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
@@ -1744,7 +1752,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 a.tile_w = 0;
                 if (!conv_sk_eligible(a, h->split)) return fail("internal: conv " + std::to_string(oi) + " of the latency plan does not fit conv_sk_kernel");
                 const SkMember one{a, op.sk_atoms, op.sk_partial, op.sk_tickets};
-                HIP_TRY(launch_conv_sk_group(&one, 1, h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, st));
+                HIP_TRY(launch_conv_sk_group(&one, 1, h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, st, &h->sk_choices[((long long)(oi + 100000) << 24) | (long long)B]));
             } else if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
                 split_s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0 && !ob.f32)) {
                 // strided 3x3, split operands: the parity-plane window kernel on pseudo-channels
@@ -1897,7 +1905,8 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         // latency plan: ONE stream, one launch per dependency level (sk_schedule): ops[0 .. 2] (the front, when it did not run fused) first
         for (size_t oi = first_op; oi < 3 && oi < h->ops.size(); ++oi)
             if (run_op(oi)) return 1;
-        for (const std::vector<int> &L : h->lat_sched) {
+        for (size_t li = 0; li < h->lat_sched.size(); ++li) {
+            const std::vector<int> &L = h->lat_sched[li];
             if (L.size() == 1) {
                 if (run_op((size_t)L[0])) return 1;
                 continue;
@@ -1911,7 +1920,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 if (!conv_sk_eligible(m[k].a, h->split)) return fail("internal: conv " + std::to_string(L[k]) + " of the latency plan does not fit conv_sk_kernel");
                 flops[1] += op_flops(op);
             }
-            HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st));
+            HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st, &h->sk_choices[((long long)li << 24) | (long long)B]));
             ++launches[1];
         }
     } else {

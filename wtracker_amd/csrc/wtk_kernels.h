@@ -218,7 +218,16 @@ struct SkMember {
     float *partial;    // slab scratch of this conv (null: one atom)
     unsigned *tickets; // its arrival counters (null: sk_finish_kernel as a second launch)
 };
-hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t stream);
+// what the cost model decided for one launch at one batch size (kept by the caller: the model runs once, not per call)
+struct SkChoice {
+    int valid = 0;
+    int separate = 0; // 1: the members' own launches, each with its own tile (many pixels: a common tile costs more than the launches)
+    int tile = 3;     // the grouped launch's tile ...
+    int S[kSkGroupMax] = {1, 1, 1, 1}; // ... and every member's form
+    int m_tile[kSkGroupMax] = {3, 3, 3, 3}, m_S[kSkGroupMax] = {1, 1, 1, 1}; // separate launches
+    double est_us = 0.0;
+};
+hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t stream, struct SkChoice *choice);
 // the kernel's view of one conv and of a grouped launch (here, not in conv_sk.hip, so that the host-side launch checker of tests/hostsan can read them)
 struct SkArgs {
     const char *in;  // input tensor (slice view): byte pitch per pixel, byte offset of the first channel
