@@ -82,7 +82,7 @@ HYBRID_CAL_FRAMES, HYBRID_CAL_SEED = 512, 40000
 # HYBRID_DEFER batches); queue of HYBRID_QUEUE rows per lane = 40 % of the frames it can receive — a fuller queue is COUNTED (overflow) and demotes the mode.
 HYBRID_DEFER, HYBRID_QUEUE_PER_64 = 5, 128
 HYBRID_EXACT_MEM_GB = 48.0  # f16x3 workspace of one lane's second-look handle
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 # The headline is a REFERENCE-PRECISION mode (the reference computes in fp32: yolo/yolo_train_config.yaml:51 `half: False`): the fastest of these whose
 # survivor index equals the fp32 restatement's on every parity frame of the run AND whose boxes pass BASELINE.md section 4's gate (matched IoU >= 0.999).
 # fp16 (throughput) and hybrid (fp16 rows + a full-precision second look at weak decisions: index-exact by a calibrated margin, boxes of the

@@ -18,6 +18,6 @@ for cfg in "f16x3 1 384" "f16x3 1 640" "fp32 1 384" "f16x3 4 384"; do
 done
 # untraced device time per call, grouped against one launch per conv (same box, same process order)
 cd $R
-for G in 1 0 graph; do for cfg in "f16x3 1 384" "f16x3 1 640" "fp32 1 384" "f16x3 15 384"; do set -- $cfg; GE="WTK_SK_GROUP=$G"; [ "$G" = graph ] && GE="WTK_GRAPH=1"; echo "$GE $cfg: $(env $GE python3 tools/gpu_sessions/time_mode.py --dtype $1 --steps 200 --batch $2 --size $3 --plan latency 2>&1 | grep 'ms per step')"; done; done
-# in-kernel combination limit (slabs above it are combined by a second launch)
-for KB in 4096 16384 65536; do for cfg in "f16x3 1 640" "f16x3 4 384" "f16x3 15 384"; do set -- $cfg; echo "WTK_SK_INKERNEL_MAX_KB=$KB $cfg: $(WTK_SK_INKERNEL_MAX_KB=$KB python3 tools/gpu_sessions/time_mode.py --dtype $1 --steps 200 --batch $2 --size $3 --plan latency 2>&1 | grep 'ms per step')"; done; done
+for G in 1 graph; do for cfg in "f16x3 1 384" "f16x3 15 384"; do set -- $cfg; GE="WTK_SK_GROUP=$G"; [ "$G" = graph ] && GE="WTK_GRAPH=1"; echo "$GE $cfg: $(env $GE python3 tools/gpu_sessions/time_mode.py --dtype $1 --steps 200 --batch $2 --size $3 --plan latency 2>&1 | grep 'ms per step')"; done; done
+# the 32 x 32 tile against the four tiles of round 5
+for T in 4 3; do for cfg in "f16x3 1 384" "f16x3 1 640" "fp32 1 384" "f16x3 4 384" "fp32 1 640"; do set -- $cfg; echo "WTK_SK_MAX_TILE=$T $cfg: $(WTK_SK_MAX_TILE=$T python3 tools/gpu_sessions/time_mode.py --dtype $1 --steps 200 --batch $2 --size $3 --plan latency 2>&1 | grep 'ms per step')"; done; done

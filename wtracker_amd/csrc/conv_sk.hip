@@ -14,6 +14,17 @@
 // store; it also re-arms the ticket).  sk_finish_kernel is the same combination as a second launch (WTK_SK_FINISH=1): a dependent launch costs
 // ~4.7 us here, which is what a small layer's whole convolution costs.  Both forms add the slabs in the same order: bit-identical.
 //
+// Where the hand-off has been checked beyond that row's "one workgroup per CU" (ADVICE r05): a block of this kernel owns its CU against other blocks of
+// this kernel (96-128 KB of LDS), not against blocks of OTHER kernels — the deferred track log runs a cycle batch on a second lane beside the single-frame
+// call.  tests/test_gpu_latency.py::test_slab_hand_off_holds_beside_another_handles_kernels compares every conv tensor of 24 rounds, word for word, with
+// the two-launch form while a second handle streams uneven batches on another stream: equal.  The loads are sc1 (served by L2, never by this CU's L1), the
+// stores write through, every storing wave drains before the one ticket add — none of which depends on who else is resident; an agent acquire in the
+// combining block (buffer_inv sc1 + vmcnt(0): ~1.5 us on each of the ~33 split layers of a forward, +10 %) would buy nothing that test can see.
+//
+// Grouped launches (round 6).  A launch carries up to kSkGroupMax convs that do not depend on each other — one dependency LEVEL of the latency plan
+// (csrc/wtk_api.hip: sk_schedule) — as one grid on the caller's stream: a block finds its conv by its index (SkGroupArgs::first).  One tile per launch,
+// a form per member, both chosen by the cost model; neither enters the arithmetic.
+//
 // Determinism and batch invariance.  K is cut into ATOMS — fixed per layer and HANDLE, never per call (conv_sk_slices: <= 12 steps: one atom; else atoms
 // of ~8 steps, at most 8; conv_sk_plan_atoms: the count the cost model below likes best for the handle's typical call) — and an output value is DEFINED as ((A_0 + A_1) + A_2) + ..., A_i = the MFMA chain over atom i's steps started from zero
 // (split mode: acc + 2^-11 acc1 of that chain).  Two launch forms produce exactly that value:
