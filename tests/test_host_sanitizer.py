@@ -39,3 +39,10 @@ def test_host_side_is_clean_over_the_shape_matrix(env):
     r = hostsan.run("quick", env)
     _ok(r)
     assert "violations 0; driver failures 0" in r.stdout, r.stdout[-3000:]
+
+
+def test_host_side_is_clean_over_the_full_matrix():
+    """`full` mode: 120 handles up to 1280 x 1280 and B = 256 (large device regions are address-space reservations: nothing is touched), ~50 s."""
+    r = hostsan.run("full", timeout=1500)
+    _ok(r)
+    assert "violations 0; driver failures 0" in r.stdout, r.stdout[-3000:]
