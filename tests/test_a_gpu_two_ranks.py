@@ -134,3 +134,20 @@ def test_two_rank_pipeline_equals_single_rank(hip_lib, tmp_path):
             np.testing.assert_array_equal(z["moves"], hyb["moves"], err_msg=tag)
             replaced += int(z["replaced"][0])
         assert replaced == int(hyb["replaced"][0]), tag  # every rank replaces the weak rows of its own share
+
+
+def test_rccl_collectives_in_a_one_rank_world(hip_lib):
+    """The N > 1 path's torch.distributed calls against the REAL RCCL on the one visible GPU (world size 1): `device_id=` eager init, barrier,
+    all_reduce of CUDA tensors, all_gather_into_tensor into track views from two lane streams — tests/rccl_one_rank.py, a fresh child process.
+    (Two ranks on one device are refused by RCCL; two devices are what tests/test_a_gpu_multi_device.py waits for.)"""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank.py"), str(port)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl one-rank world ok" in r.stdout, r.stdout[-3000:]
