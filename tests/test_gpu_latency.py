@@ -297,6 +297,41 @@ def test_replayed_capture_for_caller_buffers_equals_eager(hip_lib, monkeypatch):
     det.close()
 
 
+def test_opt_in_forked_capture_on_a_large_handle_equals_eager(hip_lib, monkeypatch):
+    """Replayed captures are opt-in since round 6 (WTK_GRAPH=1).  A handle of more than 16 frames keeps its P3 / P4 towers on the process-wide side streams,
+    so its capture FORKS (the form round 5 replayed by default): captured the second time an argument set is met, replayed afterwards — rows and head
+    logits must equal the eager handle's, and the handle must come apart cleanly (execs before events before streams: csrc/wtk_api.hip)."""
+    size, B = 256, 8
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    mk = lambda: hip.HipYolo(w, (size, size), 32, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch, plan="throughput")
+    eager = mk()
+    monkeypatch.setenv("WTK_GRAPH", "1")
+    graph = mk()
+    dev = torch.device("cuda", 0)
+    f = torch.from_numpy(fr.diverse_frames(8, size, seed=9)[:B]).to(dev)
+    out = [torch.empty((B, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    an = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(2)]
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        for _ in range(4):  # eager, captured, replayed, replayed
+            graph.predict(f, B, size, size, 1, out[0], None, an[0], conf=0.1, stream=st.cuda_stream)
+        st.synchronize()
+        bg, kg = graph.debug_head(B)
+        eager.predict(f, B, size, size, 1, out[1], None, an[1], conf=0.1, stream=st.cuda_stream)
+        st.synchronize()
+        be, ke = eager.debug_head(B)
+    np.testing.assert_array_equal(kg, ke)
+    np.testing.assert_array_equal(bg, be)
+    np.testing.assert_array_equal(an[0].cpu().numpy(), an[1].cpu().numpy())
+    np.testing.assert_array_equal(out[0].cpu().numpy(), out[1].cpu().numpy())
+    xg = graph.predict_host(f.cpu().numpy(), conf=0.1)  # host entry point: own staging buffers, captured at the first call
+    xg2 = graph.predict_host(f.cpu().numpy(), conf=0.1)
+    np.testing.assert_array_equal(xg[0], xg2[0])
+    np.testing.assert_array_equal(xg[0], out[1].cpu().numpy())
+    graph.close(), eager.close()
+
+
 def test_dynamic_batch_on_a_latency_handle(hip_lib):
     size, B = 128, 8
     _, det, _ = _handle(size, "f16x3")
