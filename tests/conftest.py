@@ -20,7 +20,7 @@ os.environ.setdefault("WTK_LATENCY_PLAN", "0")
 # removes the variable where it tests that rule
 os.environ.setdefault("WTK_NO_SK_MIXED", "1")
 os.environ.setdefault("WTK_SMALL_NARROW", "0")
-# a SIGSEGV inside the library or the HIP runtime prints its native frames before Python's faulthandler prints the Python stack (csrc/wtk_api.hip)
+# a SIGSEGV inside the library or the HIP runtime prints its native frames before Python's faulthandler prints the Python stack (csrc/wtk_plan.hip)
 os.environ.setdefault("WTK_SEGV_BACKTRACE", "1")
 
 

@@ -38,7 +38,7 @@ def _run(cmd: list) -> None:
 
 def build(verbose: bool = False) -> str:
     os.makedirs(OUT, exist_ok=True)
-    headers = [os.path.join(CSRC, "wtk_kernels.h"), os.path.join(ROOT, "include", "wtk_hip.h")]
+    headers = [os.path.join(CSRC, "wtk_kernels.h"), os.path.join(CSRC, "wtk_internal.h"), os.path.join(ROOT, "include", "wtk_hip.h")]
     jobs, objs = [], []
     for src in _sources():
         obj = os.path.join(OUT, src.replace(".hip", ".o"))

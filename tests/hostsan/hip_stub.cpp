@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE (tests/hostsan): a host-only stand-in for libamdhip64 — the "no-op launch layer" behind which the HOST side of libwtk_hip.so
-// (planning, weight packing, launchers, the stream / event / graph lifetime protocol of csrc/wtk_api.hip) runs in the build container under
+// (planning, weight packing, launchers, the stream / event / graph lifetime protocol of csrc/wtk_plan.hip / wtk_run.hip) runs in the build container under
 // AddressSanitizer + UndefinedBehaviorSanitizer.  Nothing here is shipped or measured; no kernel runs.
 //
 // What it models, and what it reports as a violation (stderr line + counter read by the driver through stub_violations()):

@@ -196,7 +196,7 @@ def test_walking_all_atoms_in_one_block_equals_one_block_per_atom(hip_lib, dtype
 @pytest.mark.parametrize("size,B", [(384, 1), (384, 15), (640, 2), (128, 3)])
 def test_grouped_level_launches_equal_one_launch_per_conv(hip_lib, dtype, size, B, monkeypatch):
     """Round 6: a latency-plan handle launches the split-K convs of one dependency level (a Detect tower's box and class convs, a PAN layer next to the
-    tower of the feature map before it) as ONE grid on the caller's stream (csrc/wtk_api.hip: sk_schedule, conv_sk.hip: launch_conv_sk_group).  Grouping
+    tower of the feature map before it) as ONE grid on the caller's stream (csrc/wtk_plan.hip: sk_schedule, conv_sk.hip: launch_conv_sk_group).  Grouping
     picks one tile per launch and a form per member — neither enters the arithmetic — so EVERY conv tensor and every row must equal the
     one-launch-per-conv handle (WTK_SK_GROUP=0) bit for bit."""
     frames = fr.diverse_frames(max(B, 4), size, seed=77 + size)[:B]
@@ -300,7 +300,7 @@ def test_replayed_capture_for_caller_buffers_equals_eager(hip_lib, monkeypatch):
 def test_opt_in_forked_capture_on_a_large_handle_equals_eager(hip_lib, monkeypatch):
     """Replayed captures are opt-in since round 6 (WTK_GRAPH=1).  A handle of more than 16 frames keeps its P3 / P4 towers on the process-wide side streams,
     so its capture FORKS (the form round 5 replayed by default): captured the second time an argument set is met, replayed afterwards — rows and head
-    logits must equal the eager handle's, and the handle must come apart cleanly (execs before events before streams: csrc/wtk_api.hip)."""
+    logits must equal the eager handle's, and the handle must come apart cleanly (execs before events before streams: csrc/wtk_plan.hip)."""
     size, B = 256, 8
     w = ys.synthetic_weights("s", 1, seed=0)
     depth, width, maxch = ys.SCALES["s"]
@@ -414,7 +414,7 @@ def test_controller_raises_on_overflow(hip_lib, tmp_path):
 @pytest.mark.parametrize("dtype", ["f16x3", "fp32"])
 def test_small_throughput_handle_runs_its_smallest_maps_on_the_split_k_kernel(hip_lib, dtype, monkeypatch):
     """A throughput-plan handle of max_batch <= 16 (the controller's cycle batch: 9 / 15 frames at imgsz 384) runs the layers whose whole batch is at most
-    4 096 output pixels — the 12 x 12 maps — on conv_sk_kernel (csrc/wtk_api.hip: sk_mixed).  Same bars as every reference-precision path: logits 2e-3,
+    4 096 output pixels — the 12 x 12 maps — on conv_sk_kernel (csrc/wtk_plan.hip: sk_mixed).  Same bars as every reference-precision path: logits 2e-3,
     boxes 2e-2 px, survivors equal to the restatement's; a frame's logits do not depend on its batch; and the plain throughput handle
     (WTK_NO_SK_MIXED=1, WTK_SMALL_NARROW=0) picks the same survivors."""
     size, B = 384, 15

@@ -5,7 +5,7 @@ stubs) and links it against tests/hostsan/hip_stub.cpp — a no-op launch layer 
 every launch's argument struct against the live allocations — and tests/hostsan/driver.cpp, which drives the C ABI over the GPU suite's shape matrix
 (scales n / s / m, 32 x 32 ... 640 x 640 here, 1280 x 1280 and B = 256 in `full` mode; every dtype, both plans, every entry point, handles created and
 destroyed out of phase, two host threads).  What it pins: planning, weight packing, launcher geometry, allocation sizes against kernel extents, and the
-stream / event / graph lifetime protocol of csrc/wtk_api.hip (the call of yolo_controller.py:64-90, 96-98 that must never die)."""
+stream / event / graph lifetime protocol of csrc/wtk_plan.hip / wtk_run.hip (the call of yolo_controller.py:64-90, 96-98 that must never die)."""
 import os
 import sys
 

@@ -8,8 +8,8 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwtk_hip.so")
-SOURCES = ["wtk_api.hip", "conv_igemm.hip", "conv_sk.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "front_fused_split.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
-HEADERS = ["wtk_kernels.h", os.path.join("..", "..", "include", "wtk_hip.h")]
+SOURCES = ["wtk_api.hip", "wtk_plan.hip", "wtk_run.hip", "wtk_hybrid.hip", "conv_igemm.hip", "conv_sk.hip", "conv1x1_wide.hip", "conv3x3_halo.hip", "conv3x3_c32.hip", "front_fused.hip", "front_fused_split.hip", "c2f_fused.hip", "stem_pool.hip", "head.hip", "mlp.hip", "track_ops.hip", "comm.hip"]
+HEADERS = ["wtk_kernels.h", "wtk_internal.h", os.path.join("..", "..", "include", "wtk_hip.h")]
 
 
 def _hipcc() -> str:
@@ -45,13 +45,13 @@ def needs_build() -> bool:
 
 
 def source_sha() -> str:
-    """sha256[:16] over the kernel sources of libwtk_hip.so (csrc/*.hip + csrc/wtk_kernels.h; the public C header only declares
+    """sha256[:16] over the kernel sources of libwtk_hip.so (csrc/*.hip + csrc/wtk_kernels.h + csrc/wtk_internal.h; the public C header only declares
     entry points and is left out): the key that ties a committed rocprofv3 artefact under profiles/ to the build it was
     collected on (bench.py only quotes such a file when the key matches)."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(SOURCES + ["wtk_kernels.h"]):
+    for f in sorted(SOURCES + ["wtk_kernels.h", "wtk_internal.h"]):
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]

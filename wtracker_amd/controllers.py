@@ -393,7 +393,7 @@ class _YoloModel:
             width, depth, maxch = yolo_spec.scale_params(self.cfg.scale)
             # sizes: a latency-plan handle under plan "auto" only ever sees calls of up to LATENCY_MAX_BATCH frames (its split-K slabs are sized by the
             # capacity: 4, not 16); a throughput-plan handle for the reference's own calls (<= 16 frames) is sized for 16 — the library runs the
-            # 12 x 12-map layers of such a handle on its split-K kernel (csrc/wtk_api.hip: sk_mixed); plan "latency" keeps both calls of a cycle on one
+            # 12 x 12-map layers of such a handle on its split-K kernel (csrc/wtk_plan.hip: sk_mixed); plan "latency" keeps both calls of a cycle on one
             # handle of 16
             if plan == "latency" and self.cfg.plan == "auto":
                 cap = self.LATENCY_MAX_BATCH

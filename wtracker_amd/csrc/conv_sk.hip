@@ -22,7 +22,7 @@
 // combining block (buffer_inv sc1 + vmcnt(0): ~1.5 us on each of the ~33 split layers of a forward, +10 %) would buy nothing that test can see.
 //
 // Grouped launches (round 6).  A launch carries up to kSkGroupMax convs that do not depend on each other — one dependency LEVEL of the latency plan
-// (csrc/wtk_api.hip: sk_schedule) — as one grid on the caller's stream: a block finds its conv by its index (SkGroupArgs::first).  One tile per launch,
+// (csrc/wtk_plan.hip: sk_schedule) — as one grid on the caller's stream: a block finds its conv by its index (SkGroupArgs::first).  One tile per launch,
 // a form per member, both chosen by the cost model; neither enters the arithmetic.
 //
 // Determinism and batch invariance.  K is cut into ATOMS — fixed per layer and HANDLE, never per call (conv_sk_slices: <= 12 steps: one atom; else atoms
@@ -398,7 +398,7 @@ __device__ __forceinline__ void sk_body(const SkArgs &a, const unsigned bid, cha
 }
 
 // A launch carries up to kSkGroupMax convs that do not depend on each other (one dependency LEVEL of the latency plan: a Detect tower's box and class
-// convs, a PAN layer next to the tower of the feature map before it — csrc/wtk_api.hip: sk_schedule): the grid is the concatenation of the members'
+// convs, a PAN layer next to the tower of the feature map before it — csrc/wtk_plan.hip: sk_schedule): the grid is the concatenation of the members'
 // grids, a block finds its member by its index.  One stream, one dispatch per level — what round 5 spread over three streams and 61 dispatches.
 template <bool SPLIT, int BM, int BN, int WAVES_P, int WAVES_C, int NS>
 __global__ __launch_bounds__(64 * WAVES_P *WAVES_C, 1) void conv_sk_kernel(const SkGroupArgs g) {

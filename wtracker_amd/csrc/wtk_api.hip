@@ -1,10 +1,6 @@
-// C ABI of libwtk_hip.so (see include/wtk_hip.h): handle management, YOLOv8 graph planning
-// (channel-slice views instead of concat/upsample tensors), weight packing and kernel launches.
-#include <execinfo.h>
-#include <signal.h>
-#include <unistd.h>
-#include "../../include/wtk_hip.h"
-#include "wtk_kernels.h"
+// C ABI of libwtk_hip.so (see include/wtk_hip.h), part 1: errors and versions, the ResMLP, the batched per-cycle predictors, the second-look
+// helpers and the view crop.  The detector handle lives in wtk_plan.hip / wtk_run.hip, the hybrid object in wtk_hybrid.hip (wtk_internal.h).
+#include "wtk_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -23,20 +19,14 @@ using namespace wtk;
 // errors
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int fail(const std::string &msg) {
+int wtk::fail(const std::string &msg) {
     g_err = msg;
     return 1;
 }
-static int fail_hip(const char *what, hipError_t e) {
+int wtk::fail_hip(const char *what, hipError_t e) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     return 1;
 }
-#define HIP_TRY(expr)                                                                                                          \
-    do {                                                                                                                       \
-        hipError_t _e = (expr);                                                                                                \
-        if (_e != hipSuccess) return fail_hip(#expr, _e);                                                                      \
-    } while (0)
-
 int wtk_set_error(const std::string &msg) { return fail(msg); } // for the other translation units (comm.hip)
 extern "C" const char *wtk_last_error(void) { return g_err.c_str(); }
 extern "C" int wtk_abi_version(void) { return WTK_ABI_VERSION; }
@@ -49,20 +39,11 @@ extern "C" int wtk_device_count(void) {
     return n;
 }
 
-#ifdef WTK_WS64_STAMPS // diagnostic builds: per-wave interval stamps of the kernel under study (tools/gpu_sessions/ws64_stamps.py)
-static unsigned long long *g_dbg_stamps = nullptr;
-constexpr size_t kDbgStampBytes = 1 << 20;
-extern "C" int wtk_debug_stamps(unsigned long long *host, size_t n_words) {
-    if (!g_dbg_stamps || n_words * 8 > kDbgStampBytes) return 1;
-    if (hipDeviceSynchronize() != hipSuccess) return 1;
-    return hipMemcpy(host, g_dbg_stamps, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
 
 // Kernel attributes (dynamic LDS above 64 KiB) are per device: initialise them once for every device a handle is created on.
 static unsigned long long g_attr_done = 0; // bit d = device d initialised (guarded by g_attr_mu: handles may be created from several host threads)
 static std::mutex g_attr_mu;
-static int ensure_attributes(int device) {
+int wtk::ensure_attributes(int device) {
     if (device < 0 || device >= 64) return fail("device id out of range");
     std::lock_guard<std::mutex> lk(g_attr_mu);
     if (g_attr_done & (1ull << device)) return 0;
@@ -70,40 +51,6 @@ static int ensure_attributes(int device) {
     HIP_TRY(pool_init_attributes());
     g_attr_done |= 1ull << device;
     return 0;
-}
-
-// Stream entry points launch on the handle's device whatever the caller's current device is, and leave the caller's
-// current device as they found it (PyTorch tracks the same thread-local HIP state).
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    hipError_t err = hipSuccess;
-    explicit DeviceGuard(int device) {
-        err = hipGetDevice(&prev);
-        if (err == hipSuccess && prev != device) {
-            err = hipSetDevice(device);
-            switched = err == hipSuccess;
-        }
-    }
-    ~DeviceGuard() {
-        if (switched) (void)hipSetDevice(prev);
-    }
-};
-#define DEVICE_GUARD(h)                                                                                                        \
-    DeviceGuard _guard((h)->device);                                                                                           \
-    if (_guard.err != hipSuccess) return fail_hip("selecting the handle's device", _guard.err)
-
-static uint16_t f32_to_f16_bits(float f) {
-    _Float16 h = (_Float16)f; // round-to-nearest-even, host compiler builtin
-    uint16_t b;
-    std::memcpy(&b, &h, 2);
-    return b;
-}
-
-static float f16_bits_to_f32(uint16_t b) {
-    _Float16 h;
-    std::memcpy(&h, &b, 2);
-    return (float)h;
 }
 
 // =============================================================================================
@@ -385,2114 +332,3 @@ extern "C" int wtk_crop_views(const uint8_t *frames_dev, int32_t N, int32_t H, i
     return 0;
 }
 
-// =============================================================================================
-// YOLOv8
-// =============================================================================================
-namespace {
-
-struct ConvSpec {
-    std::string name;
-    int cout, cin, k, stride, act;
-};
-
-struct ModelDims {
-    int c[5];  // channel widths of P1..P5
-    int n[4];  // C2f repeats of layers 2,4,6,8
-    int hb, hc; // Detect hidden widths (box tower, cls tower)
-    int nc;
-};
-
-static int make_divisible8(double x) { return (int)(std::ceil(x / 8.0) * 8.0); }
-
-static ModelDims model_dims(float width, float depth, int max_ch, int nc) {
-    ModelDims d;
-    const int base[5] = {64, 128, 256, 512, 1024};
-    for (int i = 0; i < 5; ++i) d.c[i] = make_divisible8(std::min(base[i], max_ch) * (double)width);
-    const int nb[4] = {3, 6, 6, 3};
-    for (int i = 0; i < 4; ++i) d.n[i] = std::max((int)std::lround(nb[i] * (double)depth), 1);
-    d.hb = std::max(std::max(16, d.c[2] / 4), 64);
-    d.hc = std::max(d.c[2], std::min(nc, 100));
-    d.nc = nc;
-    return d;
-}
-
-static void c2f_specs(std::vector<ConvSpec> &v, const std::string &p, int c1, int c2, int n) {
-    const int c = c2 / 2;
-    v.push_back({p + ".cv1", 2 * c, c1, 1, 1, 1});
-    v.push_back({p + ".cv2", c2, (2 + n) * c, 1, 1, 1});
-    for (int i = 0; i < n; ++i) {
-        v.push_back({p + ".m." + std::to_string(i) + ".cv1", c, c, 3, 1, 1});
-        v.push_back({p + ".m." + std::to_string(i) + ".cv2", c, c, 3, 1, 1});
-    }
-}
-
-// Fused convs in ultralytics module order
-static std::vector<ConvSpec> conv_specs(const ModelDims &d) {
-    std::vector<ConvSpec> v;
-    const int *c = d.c;
-    v.push_back({"model.0", c[0], 3, 3, 2, 1});
-    v.push_back({"model.1", c[1], c[0], 3, 2, 1});
-    c2f_specs(v, "model.2", c[1], c[1], d.n[0]);
-    v.push_back({"model.3", c[2], c[1], 3, 2, 1});
-    c2f_specs(v, "model.4", c[2], c[2], d.n[1]);
-    v.push_back({"model.5", c[3], c[2], 3, 2, 1});
-    c2f_specs(v, "model.6", c[3], c[3], d.n[2]);
-    v.push_back({"model.7", c[4], c[3], 3, 2, 1});
-    c2f_specs(v, "model.8", c[4], c[4], d.n[3]);
-    v.push_back({"model.9.cv1", c[4] / 2, c[4], 1, 1, 1});
-    v.push_back({"model.9.cv2", c[4], c[4] * 2, 1, 1, 1});
-    c2f_specs(v, "model.12", c[4] + c[3], c[3], d.n[3]);
-    c2f_specs(v, "model.15", c[3] + c[2], c[2], d.n[3]);
-    v.push_back({"model.16", c[2], c[2], 3, 2, 1});
-    c2f_specs(v, "model.18", c[2] + c[3], c[3], d.n[3]);
-    v.push_back({"model.19", c[3], c[3], 3, 2, 1});
-    c2f_specs(v, "model.21", c[3] + c[4], c[4], d.n[3]);
-    const int ch[3] = {c[2], c[3], c[4]};
-    for (int i = 0; i < 3; ++i) {
-        const std::string p = "model.22.cv2." + std::to_string(i);
-        v.push_back({p + ".0", d.hb, ch[i], 3, 1, 1});
-        v.push_back({p + ".1", d.hb, d.hb, 3, 1, 1});
-        v.push_back({p + ".2", 64, d.hb, 1, 1, 0});
-    }
-    for (int i = 0; i < 3; ++i) {
-        const std::string p = "model.22.cv3." + std::to_string(i);
-        v.push_back({p + ".0", d.hc, ch[i], 3, 1, 1});
-        v.push_back({p + ".1", d.hc, d.hc, 3, 1, 1});
-        v.push_back({p + ".2", d.nc, d.hc, 1, 1, 0});
-    }
-    return v;
-}
-
-static int find_spec(const std::vector<ConvSpec> &v, const std::string &name) {
-    for (size_t i = 0; i < v.size(); ++i)
-        if (v[i].name == name) return (int)i;
-    return -1;
-}
-
-struct Buf {
-    size_t elems_per_image = 0; // h*w*C
-    int h = 0, w = 0, C = 0;
-    int f32 = 0; // 1: stored as fp32 whatever the handle's dtype (the Detect outputs: head logits are never rounded to fp16)
-    void *ptr = nullptr;
-};
-
-enum OpKind { OP_STEM, OP_CONV, OP_POOL };
-
-struct Op {
-    OpKind kind;
-    // conv
-    int in_buf = -1, in_coff = 0, cin = 0;
-    int out_buf = -1, out_coff = 0;
-    int out2_buf = -1, out2_coff = 0;
-    int res_buf = -1, res_coff = 0;
-    int tail_op = -1; // index of a 1x1 op (64 -> 64, no activation) computed in this op's epilogue (conv3x3_halo fused tail)
-    int folded = 0;   // 1: this op runs inside another op's kernel
-    int in2_buf = -1, in2_coff = 0, in2_split = 0; // half-resolution source of the first in2_split input channels (ConvArgs::in2)
-    int cout = 0, cout_pad = 0, k = 1, stride = 1, act = 1;
-    int cfg = 0;
-    int K = 0, Kpad = 0;
-    int tile_w = 0;
-    int halo = 0; // 1: conv3x3_halo kernel, 2: conv3x3_c32 kernel
-    int side = 0;        // 1: runs on the handle's side stream (Detect towers of P3 / P4)
-    int wait_feat = -1;  // side ops: feature event (0: P3 ready, 1: P4 ready) to wait for before the first one
-    int signal_feat = -1; // main ops: record this feature event after the op
-    void *w = nullptr; // packed device weights
-    float *bias = nullptr;
-    double macs_per_image = 0;
-    int spec = -1; // index of the (first) conv blob this op computes, for wtk_yolo_debug_tensor
-    int sk = 0;                  // latency plan: this conv runs on conv_sk_kernel (split-K implicit GEMM, conv_sk.hip)
-    int sk_atoms = 0;            // ... with this many K atoms (conv_sk_slices(nk), or conv_sk_plan_atoms on a small throughput-plan handle)
-    float *sk_partial = nullptr; // ... and this is its slab scratch ([slices][max_batch * ho * wo][cout_pad] fp32; null: one slice)
-    unsigned *sk_tickets = nullptr; // ... and the arrival counters of its tiles (zero between launches; null: one slice, or WTK_SK_FINISH=1)
-};
-
-} // namespace
-
-struct wtk_yolo {
-    int device = 0;
-    int is_f16 = 1;
-    int esize = 2;
-    // WTK_F16X3: split-fp16 storage (wtk_kernels.h, kSplitScale).  Planned like the fp32 mode (is_f16 = 0, esize = 4: a split tensor
-    // takes the same 4 bytes per value), launched on the SPLIT instantiations of the fp16 kernels with pseudo-channel arguments.
-    int split = 0;
-    const int *n_dyn = nullptr; // wtk_yolo_set_dynamic_batch: device-side count of the batch rows that matter (<= B of the call)
-    int S_h = 0, S_w = 0, max_batch = 0;
-    ModelDims dims;
-    std::vector<Buf> bufs;
-    std::vector<Op> ops;
-    std::vector<std::pair<void *, size_t>> dev_allocs; // (pointer, bytes) of every dev_alloc
-    int box_buf[3] = {-1, -1, -1}, cls_buf[3] = {-1, -1, -1};
-    int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
-    int cls_ld = 32;
-    double macs_per_frame = 0;
-    int anchors = 0;
-    // staging for the host entry points and for letterboxing
-    uint8_t *frames_dev = nullptr;
-    size_t frames_cap = 0;
-    uint8_t *lb_dev = nullptr;
-    size_t lb_cap = 0;
-    void *zero_page = nullptr;
-    float *o_xywh = nullptr, *o_conf = nullptr;
-    float *o_margin = nullptr; // decision margin of every frame of the last max_det = 1 call (wtk_yolo_last_margins_host / wtk_yolo_margin_buffer)
-    int *o_anchor = nullptr;
-    // scratch of the general NMS (max_det > 1), allocated at its first use
-    float *nms_score = nullptr, *nms_box = nullptr;
-    int *nms_cls = nullptr;
-    // profiling
-    int use_halo = 1;
-    int front_debug = 0; // WTK_FRONT_DEBUG=1: the fused front also writes the model.0 / model.1 tensors (test hook)
-    int use_tail = 1; // WTK_NO_FUSED_TAIL=1: Detect box.2 as its own launch (A/B switch)
-    int use_tail_cls_split = 1; // WTK_NO_SPLIT_CLS_TAIL=1: f16x3 handles launch the class towers' last 1x1 on its own (A/B switch; fp16 handles: WTK_NO_FUSED_TAIL)
-    int halo_small_blocks = 1; // WTK_HALO_SMALL_BLOCKS=0: always 256-pixel blocks (A/B switch)
-    int halo_persist = 1; // WTK_HALO_PERSIST=0: one tile per block (A/B switch)
-    int halo_slabs = 3; // WTK_HALO_SLABS=2: two-slab / vmcnt(0) schedule of conv3x3_halo_kernel (A/B switch)
-    int use_c32s = 1;  // WTK_NO_C32S=1: the 32 -> 32 channel 3x3 layers of a split (f16x3) handle through conv_igemm_kernel (A/B switch)
-    int use_s2win = 1; // WTK_NO_S2WIN=1: strided 3x3 convs through conv_igemm_kernel instead of the parity-plane window kernel (A/B switch)
-    int use_ws64 = 1;  // WTK_NO_WS64=1: 64 -> 64 channel 3x3 layers through conv3x3_halo_kernel instead of the weight-stationary kernel (A/B switch)
-    int use_wide = 1;  // WTK_NO_WIDE_1X1=1: every 1x1 conv through conv_igemm_kernel (A/B switch)
-    int use_c2f = 0;   // ops[3..5] (model.2.m.0.cv1, m.0.cv2, model.2.cv2) run as ONE fused kernel (c2f_fused.hip)
-    int use_front = 0; // ops[0..2] (stem, model.1, model.2.cv1) run as ONE fused kernel (front_fused.hip)
-    int num_cus = 0;
-    // Latency plan (small batches: the reference's own operating point, one B = cycle_frame_num call and one B = 1 call per cycle,
-    // yolo_controller.py:96-98,108-109).  Chosen when the handle is created — max_batch <= 4 and a reference-precision dtype, WTK_LATENCY_PLAN=0/1, or the caller's word (wtk_yolo_create_planned) —
-    // and NOT per call: every conv behind the fused front then runs on conv_sk_kernel whatever the batch of the call, so a frame's logits do not
-    // depend on the batch it arrives in.  The Detect towers' 1x1 tails are launches of their own in this plan.
-    int latency = 0;
-    // latency plan, round 6: the convs of one dependency level run as ONE grouped split-K launch on the caller's stream (sk_schedule).
-    int sk_group = 1;                      // WTK_SK_GROUP=0: one launch per conv, in op order (test hook: the grouped launches must give the same bits)
-    int sk_force_tile = -1, sk_force_form = -1; // WTK_SK_TILE / WTK_SK_FORM, read when the handle is created (test hooks: every tile and form gives the same bits)
-    std::map<long long, SkChoice> sk_choices; // (launch or op, batch) -> what the split-K cost model chose (it runs once per key, not per call)
-    std::vector<std::vector<int>> lat_sched; // launches behind ops[0..2] in order: one op, or up to kSkGroupMax split-K ops that do not depend on each other
-    int small_narrow = 0; // a small handle (max_batch <= 16, f16x3) runs window / implicit-GEMM layers whose grid leaves most CUs idle on 64-cout tiles (WTK_SMALL_NARROW=0: off)
-    int halo_deep = 0;    // f16x3: the 64-cout x 128-pixel window tiles on the six-slab ring (small handles; WTK_HALO_DEEP)
-    int *status_host = nullptr; // pinned, device-visible: sticky run-time flags written by the head kernels (wtk_yolo_status); a slot of the process-wide page
-    int *status_dev = nullptr;  // ... and the device's address of the same word
-    int status_static = 0;      // flags fixed at create time (none today)
-    int profiling = 0;
-    // kernel ids of the profile: 0 stem, 1 conv_igemm, 2 pool, 3 head, 4 conv3x3_halo (+ fused tails), 5 fused front / C2f tail,
-    // 6 conv3x3_c32; the public class 1 ("conv") of wtk_yolo_get_profile is the sum of 1, 4, 5, 6
-    static constexpr int kProfKernels = 7, kProfEvents = 96;
-    hipEvent_t ev[kProfEvents];
-    // concurrency: the P3 / P4 Detect towers run on a side stream next to the PAN path
-    // Side streams of one forward pass (op.side = index, 0 = the caller's stream): 1 / 2 = P3 / P4 Detect towers (they only need t15 / t18).  The pair is
-    // process-wide (ensure_side_streams); wtk_yolo_set_side_streams(1) folds both towers onto stream 1, (0) keeps everything on the caller's stream.
-    static constexpr int kSideStreams = 3;
-    hipStream_t side_stream[kSideStreams] = {};
-    hipEvent_t feat_ev[2] = {nullptr, nullptr}, side_done[kSideStreams] = {};
-    int use_side = 1;
-    int side_streams = 2;
-    // launch-bound regime (small batches): the whole forward is captured once per argument set and replayed
-    struct GraphEntry {
-        const void *frames;
-        int B, H, W, C;
-        float conf;
-        void *o_xywh, *o_conf, *o_anchor;
-        hipGraphExec_t exec;
-        hipEvent_t done = nullptr; // recorded behind every replay: waited for before the exec is destroyed (a replay may still be in flight; the handle's OWN event, because
-                                   // the stream of the last replay is the caller's and may be gone by then)
-        // views form (wtk_yolo_predict_views): the view table's device addresses and the view shape are part of the key
-        const void *idx = nullptr, *pos = nullptr;
-        int vw = 0, vh = 0, nf = 0;
-        bool same_args(const GraphEntry &o) const {
-            return frames == o.frames && B == o.B && H == o.H && W == o.W && C == o.C && conf == o.conf && o_xywh == o.o_xywh && o_conf == o.o_conf &&
-                   o_anchor == o.o_anchor && idx == o.idx && pos == o.pos && vw == o.vw && vh == o.vh && nf == o.nf;
-        }
-    };
-    std::vector<GraphEntry> graphs;
-    std::vector<GraphEntry> seen_once; // caller-buffer argument sets met once (exec == nullptr): captured when they come back
-    int graph_max_batch = 16; // WTK_GRAPH_MAX_BATCH; 0 disables
-    int graph_host = 0;       // WTK_GRAPH=1 / WTK_GRAPH_HOST=1: the *_host entry points replay captures (own staging buffers)
-    int graph_views = 0;      // WTK_GRAPH=1 / WTK_GRAPH_VIEWS=1: caller-buffer argument sets are captured when they come back, then replayed
-    hipStream_t host_stream = nullptr; // stream of the *_host entry points (graph capture needs a non-null stream)
-    int ev_created = 0;
-    double prof_ms[kProfKernels] = {};
-    double prof_flops[kProfKernels] = {};
-    long long prof_launches[kProfKernels] = {};
-};
-
-extern "C" int wtk_yolo_conv_count(float width_mult, float depth_mult, int32_t max_channels, int32_t nc) {
-    if (nc < 1 || width_mult <= 0 || depth_mult <= 0 || max_channels < 8) return -1;
-    return (int)conv_specs(model_dims(width_mult, depth_mult, max_channels, nc)).size();
-}
-
-extern "C" int wtk_yolo_conv_info(float width_mult, float depth_mult, int32_t max_channels, int32_t nc, int32_t index, int32_t *cout,
-                                  int32_t *cin, int32_t *k, int32_t *stride, int32_t *act, char *name_out, size_t name_cap) {
-    if (nc < 1 || width_mult <= 0 || depth_mult <= 0 || max_channels < 8) return fail("wtk_yolo_conv_info: bad model scale");
-    const auto v = conv_specs(model_dims(width_mult, depth_mult, max_channels, nc));
-    if (index < 0 || index >= (int)v.size()) return fail("wtk_yolo_conv_info: index out of range");
-    const ConvSpec &s = v[index];
-    if (cout) *cout = s.cout;
-    if (cin) *cin = s.cin;
-    if (k) *k = s.k;
-    if (stride) *stride = s.stride;
-    if (act) *act = s.act;
-    if (name_out && name_cap) {
-        std::snprintf(name_out, name_cap, "%s", s.name.c_str());
-    }
-    return 0;
-}
-
-// Streams come from a per-process pool and go back to it (never destroyed): the HIP runtime binds a stream to one of its few hardware
-// queues when the stream is created, and after handles have come and gone the streams of a NEW handle can land on the queue of the
-// caller's stream — the towers then run behind the PAN path instead of next to it (the whole benefit of the side streams, 14 %, was
-// lost for the fourth workload of bench.py).  Reused streams keep the queues they got when the process was young.
-// Lifetime protocol (round 6; tests/hostsan models it): a stream enters the pool only after it has drained (hipStreamSynchronize) and is handed
-// out only when hipStreamIsCapturing says "none" — a stream that was the origin or a fork of a capture can never carry a capture state, or work
-// of a destroyed handle, into the next handle.
-namespace {
-std::mutex g_stream_mu;
-std::vector<std::pair<int, hipStream_t>> g_free_streams; // (device, stream)
-int stream_idle(hipStream_t s, const char *what) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    HIP_TRY(hipStreamIsCapturing(s, &cs));
-    if (cs != hipStreamCaptureStatusNone) return fail(std::string("stream protocol violation: ") + what + " is still part of a stream capture");
-    return 0;
-}
-int pooled_stream(int device, hipStream_t *s) {
-    {
-        std::lock_guard<std::mutex> lk(g_stream_mu);
-        for (size_t i = 0; i < g_free_streams.size(); ++i)
-            if (g_free_streams[i].first == device) {
-                *s = g_free_streams[i].second;
-                g_free_streams.erase(g_free_streams.begin() + (long)i);
-                return stream_idle(*s, "a stream handed out by the pool");
-            }
-    }
-    HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    return 0;
-}
-void unpool_stream(int device, hipStream_t s) {
-    (void)hipStreamSynchronize(s); // nothing of the handle that held it is still queued on it (wtk_yolo_destroy has synchronised the device already: this returns at once)
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    g_free_streams.insert(g_free_streams.begin(), {device, s}); // LIFO: the next handle gets the streams of the last one destroyed
-}
-} // namespace
-
-// ABI v3 symbol of the block cache of destroyed handles (an experiment of round 3, removed in round 6: it changed nothing measurable): nothing is cached
-extern "C" int wtk_release_cached_memory(void) { return 0; }
-
-static int dev_alloc(wtk_yolo *h, void **p, size_t bytes) {
-    *p = nullptr;
-    HIP_TRY(hipMalloc(p, bytes));
-    h->dev_allocs.emplace_back(*p, bytes);
-    return 0;
-}
-
-static void dev_release(wtk_yolo *h) {
-    for (auto &a : h->dev_allocs) (void)hipFree(a.first);
-    h->dev_allocs.clear();
-}
-
-static int pick_cfg(int cout, bool k1) {
-    // 8-wave tiles (256x256, 256x128, also with a three-buffer ring) all measured 3..30 % slower than two independent
-    // 4-wave 128x128 blocks per CU (profiles/r01_notes.md) and were removed.
-    if (cout % 128 == 0) return CFG_128x128;
-    if (k1 && cout % 64 == 0) return CFG_128x64; // 48 KB LDS, 123 VGPRs: 3 blocks per CU on the HBM-bound 1x1 layers (+8 %)
-    if (cout % 64 == 0) return CFG_256x64;
-    return CFG_256x32;
-}
-
-// pack [cout][k][k][cin] fp32 -> [cout_pad][Kpad] storage dtype (zero padded) on the device
-// Scaled activation domain (wtk_kernels.h, kActScale): every conv but the stem reads log2(e)-scaled activations; SiLU layers
-// produce scaled outputs.  w_scale = (act ? s : 1) / s, b_scale = act ? s : 1; for a SiLU layer w_scale is exactly 1.
-static int pack_conv(wtk_yolo *h, Op &op, const std::vector<const float *> &w_parts, const std::vector<const float *> &b_parts,
-                     const std::vector<int> &couts) {
-    const int ce = h->is_f16 ? 8 : 4;
-    op.K = op.k * op.k * op.cin;
-    op.Kpad = (op.K + 8 * ce - 1) / (8 * ce) * (8 * ce);
-    if (h->split) op.Kpad = op.K; // cin % 32 == 0 (checked at create): rows of 2 K halves, no K tail
-    const int bn = op.halo == 2 ? 32 : (op.halo ? (h->split ? split_halo_cout_tile(op.cout) : halo_cout_tile(op.cout)) : conv_cfg_bn(op.cfg));
-    op.cout_pad = (op.cout + bn - 1) / bn * bn;
-    std::vector<float> wf((size_t)op.cout_pad * op.Kpad, 0.f), bf(op.cout_pad, 0.f);
-    int row = 0;
-    for (size_t p = 0; p < w_parts.size(); ++p) {
-        for (int o = 0; o < couts[p]; ++o, ++row) {
-            std::memcpy(&wf[(size_t)row * op.Kpad], w_parts[p] + (size_t)o * op.K, sizeof(float) * op.K);
-            bf[row] = b_parts[p][o];
-            if (op.act) {
-                bf[row] = (float)((double)bf[row] * (double)kActScale);
-            } else { // linear layer fed by scaled activations: take the scale out again
-                for (int k = 0; k < op.K; ++k) wf[(size_t)row * op.Kpad + k] = (float)((double)wf[(size_t)row * op.Kpad + k] / (double)kActScale);
-            }
-        }
-    }
-    if (h->is_f16 || h->split) { // range guard of the fp16-storage modes (include/wtk_hip.h: wtk_yolo_status)
-        for (size_t i = 0; i < wf.size(); ++i) {
-            const float m = std::fabs(wf[i]);
-            if (!(m <= 65504.0f))
-                return fail("wtk_yolo_create: a folded weight of conv blob " + std::to_string(op.spec) + " (|w| = " + std::to_string(m) +
-                            " in the library's scaled domain) is outside the fp16 range: this model needs dtype WTK_F32");
-        }
-    }
-    for (float b : bf)
-        if (!std::isfinite(b)) return fail("wtk_yolo_create: a bias of conv blob " + std::to_string(op.spec) + " is not finite");
-    if (dev_alloc(h, (void **)&op.bias, bf.size() * sizeof(float))) return 1;
-    HIP_TRY(hipMemcpy(op.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (h->split) {
-        // [cout_pad][tap][block of 32 channels][hi32 | lo32]: 2 K halves per weight, the k order of a split activation row
-        std::vector<uint16_t> wh(wf.size() * 2);
-        const int taps = op.k * op.k, blocks = op.cin / 32;
-        for (int r = 0; r < op.cout_pad; ++r)
-            for (int t = 0; t < taps; ++t)
-                for (int b = 0; b < blocks; ++b)
-                    for (int c = 0; c < 32; ++c) {
-                        const float x = wf[(size_t)r * op.Kpad + (size_t)t * op.cin + b * 32 + c];
-                        const uint16_t hb = f32_to_f16_bits(x);
-                        const float hi = (float)f16_bits_to_f32(hb);
-                        const size_t o = ((size_t)r * op.Kpad + (size_t)t * op.cin + b * 32) * 2 + c;
-                        wh[o] = hb;
-                        wh[o + 32] = f32_to_f16_bits((x - hi) * kSplitScale);
-                    }
-        if (dev_alloc(h, &op.w, wh.size() * 2)) return 1;
-        HIP_TRY(hipMemcpy(op.w, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
-    } else if (h->is_f16) {
-        std::vector<uint16_t> wh(wf.size());
-        for (size_t i = 0; i < wf.size(); ++i) wh[i] = f32_to_f16_bits(wf[i]);
-        if (dev_alloc(h, &op.w, wh.size() * 2)) return 1;
-        HIP_TRY(hipMemcpy(op.w, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
-    } else {
-        if (dev_alloc(h, &op.w, wf.size() * 4)) return 1;
-        HIP_TRY(hipMemcpy(op.w, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
-    }
-    return 0;
-}
-
-namespace {
-struct Planner {
-    wtk_yolo *h;
-    const std::vector<ConvSpec> &specs;
-    const wtk_conv_blob *blobs;
-    bool failed = false;
-
-    int new_buf(int hh, int ww, int C) {
-        Buf b;
-        b.h = hh;
-        b.w = ww;
-        b.C = C;
-        b.elems_per_image = (size_t)hh * ww * C;
-        h->bufs.push_back(b);
-        return (int)h->bufs.size() - 1;
-    }
-    // generic conv op from one or more blobs (concatenated along cout)
-    void conv(const std::vector<std::string> &names, int in_buf, int in_coff, int out_buf, int out_coff, int out2_buf = -1,
-              int out2_coff = 0, int res_buf = -1, int res_coff = 0, int cout_store_pad = 0, int in2_buf = -1, int in2_coff = 0,
-              int in2_split = 0) {
-        if (failed) return;
-        Op op;
-        op.kind = OP_CONV;
-        std::vector<const float *> wp, bp;
-        std::vector<int> couts;
-        int cout = 0;
-        for (auto &nm : names) {
-            const int i = find_spec(specs, nm);
-            if (i < 0) {
-                failed = true;
-                fail("internal: unknown conv " + nm);
-                return;
-            }
-            const ConvSpec &s = specs[i];
-            if (op.spec < 0) op.spec = i;
-            op.cin = s.cin;
-            op.k = s.k;
-            op.stride = s.stride;
-            op.act = s.act;
-            wp.push_back(blobs[i].weight);
-            bp.push_back(blobs[i].bias);
-            couts.push_back(s.cout);
-            cout += s.cout;
-        }
-        op.cout = std::max(cout, cout_store_pad); // channels actually stored (>= real cout, zero rows beyond)
-        op.cfg = pick_cfg(op.cout, op.k == 1 && op.stride == 1);
-        if (h->split && op.cfg == CFG_256x64) op.cfg = CFG_128x64; // the split 256x64 instantiation spills (two accumulator sets)
-        op.in_buf = in_buf;
-        op.in_coff = in_coff;
-        op.out_buf = out_buf;
-        op.out_coff = out_coff;
-        op.out2_buf = out2_buf;
-        op.out2_coff = out2_coff;
-        op.res_buf = res_buf;
-        op.res_coff = res_coff;
-        op.in2_buf = in2_buf;
-        op.in2_coff = in2_coff;
-        op.in2_split = in2_split;
-        if (in2_buf >= 0) {
-            const Buf &lb = h->bufs[in2_buf];
-            const Buf &hb = h->bufs[in_buf];
-            if (op.cfg != CFG_128x128 || op.k != 1 || lb.h * 2 != hb.h || lb.w * 2 != hb.w || in2_coff + in2_split > lb.C || in2_split > op.cin) {
-                failed = true;
-                fail("internal: two-source conv " + names[0] + " does not fit the 128x128 loader");
-                return;
-            }
-        }
-        const Buf &ib = h->bufs[in_buf];
-        const Buf &ob = h->bufs[out_buf];
-        const int pad = op.k / 2;
-        const int ho = (ib.h + 2 * pad - op.k) / op.stride + 1, wo = (ib.w + 2 * pad - op.k) / op.stride + 1;
-        if (ho != ob.h || wo != ob.w || in_coff + op.cin > ib.C || out_coff + op.cout > ob.C) {
-            failed = true;
-            fail("internal: shape mismatch planning conv " + names[0]);
-            return;
-        }
-        // 2-D pixel tiles where the map is large enough that a linear tile would be a thin strip
-        const int bm = conv_cfg_bm(op.cfg);
-        op.tile_w = 0;
-        if (op.k == 3 && wo >= 64 && wo % 16 == 0 && ho % (bm / 16) == 0) op.tile_w = 16;
-        op.halo = halo_eligible(op.k, op.stride, op.cin, h->is_f16) && h->use_halo ? 1 : 0;
-        if (h->split) op.halo = split_halo_eligible(op.k, op.stride, op.cin, op.cout) && h->use_halo ? 1 : 0;
-        if (!h->split && h->use_halo && c32_eligible(op.k, op.stride, op.cin, op.cout, h->is_f16, out2_buf >= 0)) op.halo = 2;
-        if (h->split && h->use_halo && h->use_c32s && c32_split_eligible(op.k, op.stride, op.cin, op.cout, out2_buf < 0 && in2_buf < 0 && !ob.f32)) op.halo = 2;
-        op.macs_per_image = (double)ho * wo * cout * op.k * op.k * op.cin;
-        if (pack_conv(h, op, wp, bp, couts)) {
-            failed = true;
-            return;
-        }
-        h->ops.push_back(op);
-    }
-    // C2f block: input view -> output view.  Returns nothing; allocates its concat + temp buffers.
-    void c2f(const std::string &p, int in_buf, int in_coff, int c2, int n, bool shortcut, int out_buf, int out_coff, int out2_buf = -1,
-             int out2_coff = 0, int in2_buf = -1, int in2_coff = 0, int in2_split = 0) {
-        if (failed) return;
-        const Buf ib = h->bufs[in_buf];
-        const int c = c2 / 2;
-        const int cat = new_buf(ib.h, ib.w, (2 + n) * c);
-        const int tmp = new_buf(ib.h, ib.w, c);
-        conv({p + ".cv1"}, in_buf, in_coff, cat, 0, -1, 0, -1, 0, 0, in2_buf, in2_coff, in2_split);
-        for (int i = 0; i < n; ++i) {
-            const std::string m = p + ".m." + std::to_string(i);
-            conv({m + ".cv1"}, cat, (1 + i) * c, tmp, 0);
-            conv({m + ".cv2"}, tmp, 0, cat, (2 + i) * c, -1, 0, shortcut ? cat : -1, (1 + i) * c);
-        }
-        conv({p + ".cv2"}, cat, 0, out_buf, out_coff, out2_buf, out2_coff);
-    }
-};
-} // namespace
-
-// WTK_SEGV_BACKTRACE=1 (tests/conftest.py sets it): a SIGSEGV prints the native frames to stderr before the handler that was installed before this
-// library was loaded runs (under pytest: Python's faulthandler, which adds the Python stack and re-raises).  Diagnostic only; off by default.
-namespace {
-struct sigaction g_old_segv;
-void segv_backtrace(int sig, siginfo_t *info, void *ctx) {
-    void *frames[64];
-    const int n = backtrace(frames, 64);
-    static const char msg[] = "\nwtracker_amd: SIGSEGV, native frames:\n";
-    if (write(2, msg, sizeof(msg) - 1) < 0) {}
-    backtrace_symbols_fd(frames, n, 2);
-    if ((g_old_segv.sa_flags & SA_SIGINFO) && g_old_segv.sa_sigaction)
-        g_old_segv.sa_sigaction(sig, info, ctx);
-    else if (!(g_old_segv.sa_flags & SA_SIGINFO) && g_old_segv.sa_handler != SIG_DFL && g_old_segv.sa_handler != SIG_IGN)
-        g_old_segv.sa_handler(sig);
-    signal(sig, SIG_DFL);
-    raise(sig);
-}
-__attribute__((constructor)) void install_segv_backtrace() {
-    const char *e = std::getenv("WTK_SEGV_BACKTRACE");
-    if (!e || e[0] != '1') return;
-    void *warm[4];
-    (void)backtrace(warm, 4); // the first call loads libgcc and allocates: done here, not inside the handler
-    struct sigaction sa;
-    std::memset(&sa, 0, sizeof(sa));
-    sa.sa_sigaction = segv_backtrace;
-    sa.sa_flags = SA_SIGINFO | SA_NODEFER; // (no SA_ONSTACK: nobody installs an alternate stack here)
-    sigemptyset(&sa.sa_mask);
-    (void)sigaction(SIGSEGV, &sa, &g_old_segv);
-}
-} // namespace
-
-// Status words live in ONE pinned, device-mapped page per process, handed out by slot and never freed (a handle is a few hundred allocations already; pinning
-// and unpinning host memory per handle — hundreds of times in a test run — is a driver operation that has no business on that path).
-namespace {
-std::mutex g_status_mu;
-int *g_status_page = nullptr, *g_status_page_dev = nullptr;
-std::vector<int> g_status_free;
-constexpr int kStatusSlots = 4096;
-int acquire_status_word(int **host, int **dev) {
-    std::lock_guard<std::mutex> lk(g_status_mu);
-    if (!g_status_page) {
-        void *hp = nullptr, *dp = nullptr;
-        if (hipHostMalloc(&hp, kStatusSlots * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return 1;
-        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-            (void)hipHostFree(hp);
-            return 1;
-        }
-        g_status_page = reinterpret_cast<int *>(hp), g_status_page_dev = reinterpret_cast<int *>(dp);
-        for (int i = kStatusSlots - 1; i >= 0; --i) g_status_free.push_back(i);
-    }
-    if (g_status_free.empty()) return 1;
-    const int slot = g_status_free.back();
-    g_status_free.pop_back();
-    g_status_page[slot] = 0;
-    *host = g_status_page + slot, *dev = g_status_page_dev + slot;
-    return 0;
-}
-void release_status_word(int *host, int *) {
-    std::lock_guard<std::mutex> lk(g_status_mu);
-    if (g_status_page && host >= g_status_page && host < g_status_page + kStatusSlots) g_status_free.push_back((int)(host - g_status_page));
-}
-} // namespace
-
-static void drop_graphs(wtk_yolo *h);
-
-// Launch schedule of a latency-plan handle.  The forward pass is a DAG: the P3 / P4 Detect towers hang off the PAN path, a tower's box and class branches
-// off its first conv.  Round 5 spread it over three streams (61 dispatches for one frame, ~45 on the critical path, the rest beside it on streams the
-// capture forks into).  Here every op gets its dependency LEVEL — one more than the deepest earlier op it conflicts with (read-after-write,
-// write-after-write, write-after-read, at whole-buffer granularity: conservative) — and the split-K convs of one level become ONE launch
-// (conv_sk.hip: launch_conv_sk_group): 48 dispatches for YOLOv8s, all on the caller's stream, nothing to fork, nothing to join.
-static void sk_schedule(wtk_yolo *h) {
-    h->lat_sched.clear();
-    const size_t n = h->ops.size();
-    if (!h->latency || n <= 3) return;
-    auto reads = [&](const Op &o, std::vector<int> &r) {
-        r.clear();
-        for (int b : {o.in_buf, o.res_buf, o.in2_buf})
-            if (b >= 0) r.push_back(b);
-    };
-    auto writes = [&](const Op &o, std::vector<int> &w) {
-        w.clear();
-        if (o.kind == OP_POOL) w.push_back(o.in_buf); // the pool reads and writes slices of the SPPF concat buffer
-        for (int b : {o.out_buf, o.out2_buf})
-            if (b >= 0) w.push_back(b);
-        if (o.tail_op >= 0 && h->ops[o.tail_op].out_buf >= 0) w.push_back(h->ops[o.tail_op].out_buf);
-    };
-    auto meets = [](const std::vector<int> &a, const std::vector<int> &b) {
-        for (int x : a)
-            for (int y : b)
-                if (x == y) return true;
-        return false;
-    };
-    std::vector<int> level(n, 0), ri, wi, rj, wj;
-    int deepest = 0;
-    for (size_t i = 0; i < n; ++i) {
-        if (h->ops[i].folded) continue;
-        reads(h->ops[i], ri), writes(h->ops[i], wi);
-        for (size_t j = 0; j < i; ++j) {
-            if (h->ops[j].folded) continue;
-            reads(h->ops[j], rj), writes(h->ops[j], wj);
-            if (meets(wj, ri) || meets(wj, wi) || meets(rj, wi)) level[i] = std::max(level[i], level[j] + 1);
-        }
-        deepest = std::max(deepest, level[i]);
-    }
-    for (int lv = 0; lv <= deepest; ++lv) {
-        std::vector<int> group;
-        for (size_t i = 3; i < n; ++i) { // ops[0 .. 2] are the (fused) front's: launched first, as before
-            const Op &o = h->ops[i];
-            if (o.folded || level[i] != lv) continue;
-            if (o.kind == OP_CONV && o.sk) {
-                group.push_back((int)i);
-                if ((int)group.size() == kSkGroupMax) h->lat_sched.push_back(group), group.clear();
-            } else {
-                h->lat_sched.push_back({(int)i});
-            }
-        }
-        if (!group.empty()) h->lat_sched.push_back(group);
-    }
-}
-
-// Order of release (round 6: one protocol, checked by tests/hostsan): (1) the device drains — no kernel, copy or graph replay of this handle is in
-// flight; (2) the graph execs go, BEFORE the events and streams they were captured through; (3) the events; (4) the streams go back to the pool,
-// idle and outside any capture; (5) device memory.
-extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
-    if (!h) return;
-    DeviceGuard guard(h->device); // the synchronise and the releases below are about the HANDLE's device, whatever the caller's current device is
-    (void)hipDeviceSynchronize();
-    drop_graphs(h);
-    for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
-    for (int i = 0; i < 2; ++i)
-        if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
-    for (int i = 0; i < wtk_yolo::kSideStreams; ++i) {
-        if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
-    }
-    if (h->host_stream) unpool_stream(h->device, h->host_stream);
-    dev_release(h);
-    (void)hipFree(h->frames_dev);
-    (void)hipFree(h->lb_dev);
-    (void)hipFree(h->nms_score);
-    (void)hipFree(h->nms_box);
-    (void)hipFree(h->nms_cls);
-    if (h->status_host) release_status_word(h->status_host, h->status_dev);
-    delete h;
-}
-
-extern "C" int wtk_yolo_create(wtk_yolo **out, const wtk_yolo_desc *d) { return wtk_yolo_create_planned(out, d, WTK_PLAN_AUTO); }
-extern "C" int wtk_yolo_plan(wtk_yolo *h) { return h ? (h->latency ? WTK_PLAN_LATENCY : WTK_PLAN_THROUGHPUT) : -1; }
-
-extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, int32_t plan) {
-    if (!out || !d || !d->convs) return fail("wtk_yolo_create: null argument");
-    if (plan != WTK_PLAN_AUTO && plan != WTK_PLAN_THROUGHPUT && plan != WTK_PLAN_LATENCY) return fail("wtk_yolo_create_planned: plan must be WTK_PLAN_AUTO, _THROUGHPUT or _LATENCY");
-    if (plan == WTK_PLAN_LATENCY && d->dtype == WTK_F16) return fail("wtk_yolo_create_planned: the latency plan is built for WTK_F32 and WTK_F16X3 handles");
-    if (d->dtype != WTK_F32 && d->dtype != WTK_F16 && d->dtype != WTK_F16X3) return fail("wtk_yolo_create: dtype must be WTK_F32, WTK_F16 or WTK_F16X3");
-    if (d->imgsz_h <= 0 || d->imgsz_w <= 0 || d->imgsz_h % 32 || d->imgsz_w % 32) return fail("wtk_yolo_create: imgsz must be a positive multiple of 32");
-    if (d->max_batch <= 0) return fail("wtk_yolo_create: max_batch must be positive");
-    // nc <= 32: the class towers' last 1x1 runs inside the 3x3 before it (32 stored couts); 33..80 (a stock 80-class YOLOv8 head): the same conv as a
-    // launch of its own (implicit GEMM over cls_ld = nc rounded up to 8 couts).  The reference trains single_cls (yolo/yolo_train_config.yaml:27).
-    if (d->nc < 1 || d->nc > 80) return fail("wtk_yolo_create: nc must be in [1, 80]");
-    if (wtk_device_count() <= d->device) return fail("wtk_yolo_create: no such HIP device (is a GPU visible?)");
-    const ModelDims dims = model_dims(d->width_mult, d->depth_mult, d->max_channels, d->nc);
-    const std::vector<ConvSpec> specs = conv_specs(dims);
-    if ((int)specs.size() != d->n_convs) return fail("wtk_yolo_create: n_convs does not match the model scale");
-    for (size_t i = 0; i < specs.size(); ++i) {
-        const wtk_conv_blob &b = d->convs[i];
-        const ConvSpec &s = specs[i];
-        if (b.cout != s.cout || b.cin != s.cin || b.k != s.k || b.stride != s.stride || b.act != s.act || !b.weight || !b.bias)
-            return fail("wtk_yolo_create: conv blob " + std::to_string(i) + " (" + s.name + ") does not match the expected shape");
-    }
-    for (int i = 0; i < 5; ++i)
-        if (dims.c[i] % 16 != 0) return fail("wtk_yolo_create: channel widths must be multiples of 16 for this build");
-    if (dims.hb % 16 || dims.hc % 16) return fail("wtk_yolo_create: head widths must be multiples of 16");
-    if (d->dtype == WTK_F16X3) {
-        for (int i = 0; i < 5; ++i)
-            if (dims.c[i] % 64 != 0 && !(i == 0 && dims.c[0] == 32)) return fail("wtk_yolo_create: WTK_F16X3 needs channel widths in multiples of 64 (stem: 32)");
-        if (dims.hb % 32 || dims.hc % 32) return fail("wtk_yolo_create: WTK_F16X3 needs head widths in multiples of 32");
-    }
-    DEVICE_GUARD(d);
-    if (ensure_attributes(d->device)) return 1;
-
-    wtk_yolo *h = new wtk_yolo();
-    h->device = d->device;
-    h->is_f16 = d->dtype == WTK_F16;
-    h->split = d->dtype == WTK_F16X3;
-    h->esize = h->is_f16 ? 2 : 4;
-    h->S_h = d->imgsz_h;
-    h->S_w = d->imgsz_w;
-    h->max_batch = d->max_batch;
-    h->dims = dims;
-    if (const char *e = std::getenv("WTK_NO_HALO")) h->use_halo = !(e[0] == '1');
-    // Side streams are for LARGE batches.  A handle for the reference's own calls (max_batch <= 16: one frame, one cycle batch) runs on the caller's stream
-    // alone: its launches last 5-50 us, and a dependency between two streams costs microseconds when the runtime has put them on different hardware
-    // queues, nothing when they share one — so with side streams the same controller loop ran at 7.6 k or 4.4 k frames/s (throughput plan), 9.0 k or
-    // 11.2 k (deferred log) depending on GPU_MAX_HW_QUEUES and on which streams the process had created before; on one stream it runs at the same rate
-    // in every such environment (profiles/r06_notes.md section 4).  wtk_yolo_set_side_streams(h, 2) turns them on for such a handle explicitly.
-    if (d->max_batch <= 16) h->use_side = 0, h->side_streams = 0;
-    if (const char *e = std::getenv("WTK_NO_SIDE_STREAM")) h->use_side = h->use_side && !(e[0] == '1');
-    if (const char *e = std::getenv("WTK_HALO_SLABS")) h->halo_slabs = e[0] == '2' ? 2 : 3;
-    if (const char *e = std::getenv("WTK_HALO_PERSIST")) h->halo_persist = e[0] != '0';
-    if (const char *e = std::getenv("WTK_HALO_SMALL_BLOCKS")) h->halo_small_blocks = e[0] != '0';
-    if (const char *e = std::getenv("WTK_NO_FUSED_TAIL")) h->use_tail = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_SPLIT_CLS_TAIL")) h->use_tail_cls_split = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_WIDE_1X1")) h->use_wide = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_WS64")) h->use_ws64 = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_S2WIN")) h->use_s2win = e[0] != '1';
-    if (const char *e = std::getenv("WTK_NO_C32S")) h->use_c32s = e[0] != '1';
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, d->device));
-        h->num_cus = prop.multiProcessorCount;
-    }
-    h->latency = d->max_batch <= 4 && !h->is_f16;
-    if (const char *e = std::getenv("WTK_LATENCY_PLAN")) h->latency = e[0] == '1' && !h->is_f16;
-    if (plan != WTK_PLAN_AUTO) h->latency = plan == WTK_PLAN_LATENCY; // the caller's word beats the rule and the environment
-    // Replayed captures (hipGraph) are OPT-IN since round 6: WTK_GRAPH=1 (every form), or WTK_GRAPH_HOST=1 (the *_host entry points) / WTK_GRAPH_VIEWS=1
-    // (caller buffers, captured the second time an argument set is met), read when the handle is created.  Round 5 replayed by default on latency-plan
-    // handles (0.53 against 0.57 ms per single-frame call); a capture of this forward pass FORKS into the side streams, a graph exec instantiated from
-    // a forked capture runs its branches on streams the runtime creates for it, and that machinery is where the two open problems of round 5 lived (an
-    // intermittent host fault in the first capturing call of a handle after > 100 handles in the process, and replays that ran 2-4 x slower for later
-    // handles of a process with eight hardware queues): profiles/r06_notes.md section 1.  The latency plan of round 6 runs on ONE stream in launches
-    // grouped per dependency level (sk_schedule), so eager launches no longer pay for the fork either.
-    {
-        const char *g = std::getenv("WTK_GRAPH");
-        h->graph_host = h->graph_views = g && g[0] == '1';
-    }
-    if (h->latency) h->use_tail = 0;
-    if (const char *e = std::getenv("WTK_GRAPH_MAX_BATCH")) h->graph_max_batch = std::atoi(e);
-    if (const char *e = std::getenv("WTK_GRAPH_HOST")) h->graph_host = e[0] == '1';
-    if (const char *e = std::getenv("WTK_GRAPH_VIEWS")) h->graph_views = e[0] == '1';
-
-    Planner P{h, specs, d->convs};
-    const int *c = dims.c;
-    const int H = h->S_h, W = h->S_w;
-    auto hw = [&](int s, int &hh, int &ww) { hh = H / s, ww = W / s; };
-    int h2, w2, h4, w4, h8, w8, h16, w16, h32, w32;
-    hw(2, h2, w2), hw(4, h4, w4), hw(8, h8, w8), hw(16, h16, w16), hw(32, h32, w32);
-
-    // ---- buffers that hold more than one logical tensor (concat-free FPN/PAN)
-    const int t0 = P.new_buf(h2, w2, c[0]);
-    const int t1 = P.new_buf(h4, w4, c[1]);
-    const int t2 = P.new_buf(h4, w4, c[1]);
-    const int t3 = P.new_buf(h8, w8, c[2]);
-    const int cat14 = P.new_buf(h8, w8, c[3] + c[2]);   // [up(t12) | t4]
-    const int t5 = P.new_buf(h16, w16, c[3]);
-    const int cat11 = P.new_buf(h16, w16, c[4] + c[3]); // [up(t9) | t6]
-    const int t7 = P.new_buf(h32, w32, c[4]);
-    const int t8 = P.new_buf(h32, w32, c[4]);
-    const int sppcat = P.new_buf(h32, w32, 2 * c[4]);   // [x | y1 | y2 | y3], each c4/2
-    const int cat20 = P.new_buf(h32, w32, c[3] + c[4]); // [t19 | t9]
-    const int cat17 = P.new_buf(h16, w16, c[2] + c[3]); // [t16 | t12]
-    const int t15 = P.new_buf(h8, w8, c[2]);
-    const int t18 = P.new_buf(h16, w16, c[3]);
-    const int t21 = P.new_buf(h32, w32, c[4]);
-
-    // ---- backbone
-    {
-        Op op;
-        op.kind = OP_STEM;
-        op.out_buf = t0;
-        op.cout = c[0];
-        op.macs_per_image = (double)h2 * w2 * c[0] * 27;
-        const int i0 = find_spec(specs, "model.0");
-        op.spec = i0;
-        // repack [cout][3][3][3(RGB)] -> K = tap*4 + channel (see stem_mfma_kernel)
-        const float *w0 = d->convs[i0].weight;
-        // split mode: split-fp16 operands like every other conv of the handle (pixels / 255 and the weights as hi + lo pairs)
-        const bool stem_split = h->split;
-        const int taps = (h->is_f16 || stem_split) ? 16 : 9;
-        std::vector<float> wp((size_t)c[0] * taps * 4, 0.f);
-        for (int co = 0; co < c[0]; ++co)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int ch = 0; ch < 3; ++ch) // the stem reads unscaled pixels and produces scaled activations
-                    wp[((size_t)co * taps + tap) * 4 + ch] = (float)((double)w0[((size_t)co * 9 + tap) * 3 + ch] * (double)kActScale);
-        if (h->is_f16 || stem_split)
-            for (float x : wp) {
-                if (!(std::fabs(x) <= 65504.0f)) {
-                    wtk_yolo_destroy(h);
-                    return fail("wtk_yolo_create: a folded weight of conv blob " + std::to_string(i0) + " (model.0) is outside the fp16 range: this model needs dtype WTK_F32");
-                }
-            }
-        std::vector<float> stem_bias(c[0]);
-        for (int co = 0; co < c[0]; ++co) stem_bias[co] = (float)((double)d->convs[i0].bias[co] * (double)kActScale);
-        void *wdev;
-        float *bdev;
-        std::vector<uint16_t> wh;
-        const void *src = wp.data();
-        size_t bytes = wp.size() * 4;
-        if (h->is_f16) {
-            wh.resize(wp.size());
-            for (size_t i = 0; i < wp.size(); ++i) wh[i] = f32_to_f16_bits(wp[i]);
-            src = wh.data();
-            bytes = wh.size() * 2;
-        } else if (stem_split) { // [cout][16][4] hi halves, then [cout][16][4] lo halves
-            wh.resize(2 * wp.size());
-            for (size_t i = 0; i < wp.size(); ++i) {
-                const uint16_t hb = f32_to_f16_bits(wp[i]);
-                wh[i] = hb;
-                wh[wp.size() + i] = f32_to_f16_bits((wp[i] - f16_bits_to_f32(hb)) * kSplitScale);
-            }
-            src = wh.data();
-            bytes = wh.size() * 2;
-        }
-        if (dev_alloc(h, &wdev, bytes) || dev_alloc(h, (void **)&bdev, sizeof(float) * c[0])) {
-            wtk_yolo_destroy(h);
-            return 1;
-        }
-        if (hipMemcpy(wdev, src, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(bdev, stem_bias.data(), sizeof(float) * c[0], hipMemcpyHostToDevice) != hipSuccess) {
-            wtk_yolo_destroy(h);
-            return fail("wtk_yolo_create: stem weight upload failed");
-        }
-        op.w = wdev;
-        op.bias = bdev;
-        h->ops.push_back(op);
-    }
-    P.conv({"model.1"}, t0, 0, t1, 0);
-    P.c2f("model.2", t1, 0, c[1], dims.n[0], true, t2, 0);
-    P.conv({"model.3"}, t2, 0, t3, 0);
-    P.c2f("model.4", t3, 0, c[2], dims.n[1], true, cat14, c[3]);
-    P.conv({"model.5"}, cat14, c[3], t5, 0);
-    P.c2f("model.6", t5, 0, c[3], dims.n[2], true, cat11, c[4]);
-    P.conv({"model.7"}, cat11, c[4], t7, 0);
-    P.c2f("model.8", t7, 0, c[4], dims.n[3], true, t8, 0);
-    // SPPF
-    P.conv({"model.9.cv1"}, t8, 0, sppcat, 0);
-    if (!P.failed) {
-        Op op;
-        op.kind = OP_POOL;
-        op.in_buf = sppcat;
-        op.cin = c[4] / 2;
-        h->ops.push_back(op);
-    }
-    // nn.Upsample(2x nearest) + Concat: the consumer's 1x1 conv reads the half-resolution producer directly (two-source
-    // loader of the 128x128 tile), so the 4x larger upsampled copy is never written.  Narrow scales whose cv1 does not
-    // use that tile (and WTK_MATERIALIZE_UPSAMPLE=1) keep the materialised copy in the concat buffer.
-    bool lazy_up = c[2] % 128 == 0 && c[3] % 128 == 0;
-    if (const char *e = std::getenv("WTK_MATERIALIZE_UPSAMPLE")) lazy_up = lazy_up && e[0] != '1';
-    if (lazy_up) {
-        P.conv({"model.9.cv2"}, sppcat, 0, cat20, c[3]); // t9 -> cat20 slice
-        P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], -1, 0, cat20, c[3], c[4]); // [up(t9) | t6]; t12 -> cat17 slice
-        P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0, -1, 0, cat17, c[2], c[3]);      // [up(t12) | t4]
-    } else {
-        P.conv({"model.9.cv2"}, sppcat, 0, cat20, c[3], cat11, 0); // t9 -> cat20 slice, upsampled copy -> cat11
-        P.c2f("model.12", cat11, 0, c[3], dims.n[3], false, cat17, c[2], cat14, 0); // t12 -> cat17 slice, up -> cat14
-        P.c2f("model.15", cat14, 0, c[2], dims.n[3], false, t15, 0);
-    }
-    if (!P.failed) h->ops.back().signal_feat = 0; // P3 feature map complete
-    P.conv({"model.16"}, t15, 0, cat17, 0);
-    P.c2f("model.18", cat17, 0, c[3], dims.n[3], false, t18, 0);
-    if (!P.failed) h->ops.back().signal_feat = 1; // P4 feature map complete
-    P.conv({"model.19"}, t18, 0, cat20, 0);
-    P.c2f("model.21", cat20, 0, c[4], dims.n[3], false, t21, 0);
-    // ---- Detect: both towers' first 3x3 share one conv (weights concatenated along cout)
-    const int feat[3] = {t15, t18, t21};
-    const int fh[3] = {h8, h16, h32}, fw[3] = {w8, w16, w32};
-    h->cls_ld = (d->nc + 7) / 8 * 8; // class logits are stored in 16-byte groups: nc = 1 costs 16 B per anchor, not 64
-    for (int i = 0; i < 3 && !P.failed; ++i) {
-        const std::string b = "model.22.cv2." + std::to_string(i), cl = "model.22.cv3." + std::to_string(i);
-        const int d1 = P.new_buf(fh[i], fw[i], dims.hb + dims.hc);
-        const int d2b = P.new_buf(fh[i], fw[i], dims.hb);
-        const int d2c = P.new_buf(fh[i], fw[i], dims.hc);
-        h->box_buf[i] = P.new_buf(fh[i], fw[i], 64);
-        h->cls_buf[i] = P.new_buf(fh[i], fw[i], h->cls_ld);
-        h->bufs[h->box_buf[i]].f32 = h->bufs[h->cls_buf[i]].f32 = 1;
-        h->lh[i] = fh[i];
-        h->lw[i] = fw[i];
-        const size_t first_op = h->ops.size();
-        P.conv({b + ".0", cl + ".0"}, feat[i], 0, d1, 0);
-        P.conv({b + ".1"}, d1, 0, d2b, 0);
-        P.conv({cl + ".1"}, d1, dims.hb, d2c, 0);
-        P.conv({b + ".2"}, d2b, 0, h->box_buf[i], 0);
-        P.conv({cl + ".2"}, d2c, 0, h->cls_buf[i], 0, -1, 0, -1, 0, h->cls_ld);
-        if (!P.failed && h->use_tail) { // box tower: the last 1x1 runs in the epilogue of the 3x3 before it (fp16, 64 channels)
-            Op &b1 = h->ops[first_op + 1], &b2 = h->ops[first_op + 3];
-            if ((h->is_f16 || h->split) && b1.halo == 1 && b1.cout == 64 && b1.cout_pad == 64 && b2.k == 1 && b2.cin == 64 && b2.cout == 64 && !b2.act &&
-                b2.in_buf == b1.out_buf && b2.res_buf < 0 && b2.out2_buf < 0 && b1.res_buf < 0 && b1.out2_buf < 0 && h->halo_slabs == 3) {
-                b1.tail_op = (int)first_op + 3;
-                b2.folded = 1;
-            }
-            // class tower: 3x3 (128 -> 128) then 1x1 (128 -> nc, stored as cls_ld = 8, 16, 24 or 32 channels)
-            Op &c1 = h->ops[first_op + 2], &c2 = h->ops[first_op + 4];
-            if ((h->is_f16 || (h->split && h->use_tail_cls_split)) && c1.halo == 1 && c1.cout == 128 && c1.cout_pad == 128 && c2.k == 1 && c2.cin == 128 && c2.cout <= 32 && c2.cout_pad == 32 &&
-                !c2.act && c2.in_buf == c1.out_buf && c2.res_buf < 0 && c2.out2_buf < 0 && c1.res_buf < 0 && c1.out2_buf < 0 && h->halo_slabs == 3 &&
-                c2.cout == h->cls_ld) {
-                c1.tail_op = (int)first_op + 4;
-                c2.folded = 1;
-            }
-        }
-        if (!P.failed && i < 2) { // P3 and P4 towers only need t15 / t18: independent of the rest of the PAN path
-            for (size_t k = first_op; k < h->ops.size(); ++k) h->ops[k].side = i == 1 ? 2 : 1; // P4 tower: side stream 2 (folded onto stream 1 at launch time when the handle runs with one side stream)
-            h->ops[first_op].wait_feat = i;
-        }
-    }
-    // A strided 3x3 conv (128 couts, implicit GEMM, fp16) whose ONLY reader is the 1x1 conv 128 -> 128 right behind it (model.3 ->
-    // model.4.cv1 in YOLOv8s): the 1x1 runs in the 3x3's epilogue, its input never reaches HBM.  WTK_NO_IGEMM_TAIL=1 switches it off.
-    if (!P.failed && h->is_f16 && !(std::getenv("WTK_NO_IGEMM_TAIL") && std::getenv("WTK_NO_IGEMM_TAIL")[0] == '1')) {
-        for (size_t i = 0; i + 1 < h->ops.size(); ++i) {
-            Op &c3 = h->ops[i], &c1 = h->ops[i + 1];
-            if (c3.kind != OP_CONV || c1.kind != OP_CONV || c3.halo || c3.k != 3 || c3.stride != 2 || c3.cfg != CFG_128x128 || c3.cout != 128 || c3.cout_pad != 128 ||
-                !c3.act || c3.res_buf >= 0 || c3.out2_buf >= 0 || c3.in2_buf >= 0 || c3.tail_op >= 0 || c3.folded)
-                continue;
-            if (c1.k != 1 || c1.stride != 1 || c1.cin != 128 || c1.cout != 128 || c1.cout_pad != 128 || c1.in_buf != c3.out_buf || c1.in_coff != c3.out_coff ||
-                c1.res_buf >= 0 || c1.out2_buf >= 0 || c1.in2_buf >= 0 || c1.folded || c1.tail_op >= 0 || h->bufs[c3.out_buf].C != 128)
-                continue;
-            bool other_reader = false;
-            for (size_t j = 0; j < h->ops.size(); ++j) {
-                const Op &o = h->ops[j];
-                if (j != i + 1 && (o.in_buf == c3.out_buf || o.res_buf == c3.out_buf || o.in2_buf == c3.out_buf)) other_reader = true;
-            }
-            if (other_reader) continue;
-            c3.tail_op = (int)i + 1;
-            c1.folded = 1;
-        }
-    }
-    if (P.failed) {
-        wtk_yolo_destroy(h);
-        return 1;
-    }
-    h->anchors = h8 * w8 + h16 * w16 + h32 * w32;
-    for (const Op &op : h->ops) h->macs_per_frame += op.macs_per_image;
-    // Which convs the split-K kernel (conv_sk.hip) takes, and their slab scratch.  Latency plan: everything with rows of 32 input channels.
-    // Throughput plan of a SMALL handle (max_batch <= 16, fp32 / f16x3: what a controller's cycle batch of 9 / 15 frames runs on, yolo_controller.py:108-109):
-    // the layers whose whole batch is at most 4 096 output pixels — the 12 x 12 maps of imgsz 384 — where the window / implicit-GEMM kernels run ~40-block
-    // grids that walk K serially (model.8's bottlenecks 40 us, split over K 24 us: profiles/r05_notes.md section 5); the choice is fixed per handle, so a
-    // frame's result still does not depend on its batch.  WTK_NO_SK_MIXED=1 switches the second rule off (A/B).
-    const bool sk_mixed = !h->latency && !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_NO_SK_MIXED") && std::getenv("WTK_NO_SK_MIXED")[0] == '1');
-    // (f16x3: the 12 x 12 maps of imgsz 384; fp32, whose window kernels are 2.5 x slower per tap, gains on the 24 x 24 maps too — profiles/r05_notes.md section 5)
-    const long long sk_mixed_max_px = std::getenv("WTK_SK_MIXED_MAX_PX") ? std::atoll(std::getenv("WTK_SK_MIXED_MAX_PX")) : (h->split ? 4096 : 10000);
-    h->small_narrow = !h->is_f16 && h->max_batch <= 16 && !(std::getenv("WTK_SMALL_NARROW") && std::getenv("WTK_SMALL_NARROW")[0] == '0');
-    {
-        const int deep = std::getenv("WTK_HALO_DEEP") ? std::atoi(std::getenv("WTK_HALO_DEEP")) : 1;
-        h->halo_deep = h->split && (deep == 2 || (deep == 1 && h->max_batch <= 16));
-    }
-    if (h->latency || sk_mixed) {
-        for (size_t i = 3; i < h->ops.size(); ++i) { // ops[0..2] stay the fused front's
-            Op &op = h->ops[i];
-            if (op.kind != OP_CONV || op.folded || op.tail_op >= 0 || op.out2_buf >= 0 || op.cin % 32 || (op.k != 1 && op.k != 3) || op.cout_pad % 32 || op.cout % 8) continue;
-            if (op.in2_buf >= 0 && (op.k != 1 || op.in2_split % 32)) continue;
-            {
-                const Buf &ibx = h->bufs[op.in_buf]; // conv_sk_kernel addresses a tile's pixels by 32-bit lane offsets from its first image: two images inside 31 bits
-                if (2LL * ibx.h * ibx.w * ibx.C * 4 > 0x7fffffffLL) continue;
-            }
-            if (sk_mixed && (long long)h->max_batch * h->bufs[op.out_buf].h * h->bufs[op.out_buf].w > sk_mixed_max_px) continue;
-            op.sk = 1;
-            const Buf &ob = h->bufs[op.out_buf];
-            // K atoms: the count the launcher's cost model likes best for what this handle is for — a small throughput-plan handle's largest call (a cycle
-            // batch's 12 x 12 maps: eight atoms x 34 tiles are 272 blocks = two rounds on 256 CUs, seven are one round), a latency-plan handle's single frame
-            // (0.529 -> 0.515 ms at 384 x 384) — and the layer's default where the model sees no difference.  Fixed per handle, so a frame's result does not
-            // depend on its batch.  WTK_SK_PLAN_ATOMS=0: the default count everywhere.
-            const int nk_op = op.k * op.k * op.cin / 32;
-            const bool plan_atoms = !(std::getenv("WTK_SK_PLAN_ATOMS") && std::getenv("WTK_SK_PLAN_ATOMS")[0] == '0');
-            const long long plan_px = (long long)(h->latency ? 1 : h->max_batch) * ob.h * ob.w;
-            op.sk_atoms = plan_atoms ? conv_sk_plan_atoms(plan_px, op.cout_pad, nk_op, h->num_cus, h->split) : conv_sk_slices(nk_op);
-            const int S = op.sk_atoms;
-            if (S > 1 && dev_alloc(h, (void **)&op.sk_partial, (size_t)S * h->max_batch * ob.h * ob.w * op.cout_pad * sizeof(float))) {
-                wtk_yolo_destroy(h);
-                return 1;
-            }
-            const bool two_launches = std::getenv("WTK_SK_FINISH") && std::getenv("WTK_SK_FINISH")[0] == '1'; // A/B switch: slabs combined by a second launch
-            if (S > 1 && !two_launches) {
-                const size_t nt = conv_sk_ticket_count((long long)h->max_batch * ob.h * ob.w, op.cout_pad) * sizeof(unsigned);
-                if (dev_alloc(h, (void **)&op.sk_tickets, nt)) {
-                    wtk_yolo_destroy(h);
-                    return 1;
-                }
-                if (hipMemset(op.sk_tickets, 0, nt) != hipSuccess) {
-                    wtk_yolo_destroy(h);
-                    return fail("wtk_yolo_create: hipMemset failed");
-                }
-            }
-        }
-    }
-    if (const char *e = std::getenv("WTK_SK_GROUP")) h->sk_group = e[0] != '0';
-    if (const char *e = std::getenv("WTK_SK_TILE")) h->sk_force_tile = std::atoi(e) >= 0 && std::atoi(e) <= 3 ? std::atoi(e) : -1;
-    if (const char *e = std::getenv("WTK_SK_FORM")) h->sk_force_form = std::atoi(e) == 0 || std::atoi(e) == 1 ? std::atoi(e) : -1;
-    sk_schedule(h);
-    // ops[0..2] are stem, model.1, model.2.cv1 by construction; fuse them when the widths match the kernel
-    {
-        const char *e = std::getenv("WTK_NO_FUSED_FRONT");
-        const bool off = e && e[0] == '1';
-        if (const char *dbg = std::getenv("WTK_FRONT_DEBUG")) h->front_debug = dbg[0] == '1';
-        h->use_front = !off && h->ops.size() > 3 && h->ops[0].kind == OP_STEM && h->ops[1].kind == OP_CONV && h->ops[2].kind == OP_CONV &&
-                       h->ops[1].k == 3 && h->ops[1].stride == 2 && h->ops[2].k == 1 && h->ops[1].act && h->ops[2].act &&
-                       h->ops[2].out2_buf < 0 && h->ops[2].res_buf < 0 &&
-                       (front_fused_eligible(h->is_f16, h->ops[0].cout, h->ops[1].cout, h->ops[2].cout) ||
-                        (h->split && h->ops[1].cin == 32 && front_fused_split_eligible(h->ops[0].cout, h->ops[1].cout, h->ops[2].cout)));
-        // ops[3..5] are the first C2f's bottleneck convs and cv2 (dims.n[0] == 1)
-        const char *e2 = std::getenv("WTK_NO_FUSED_C2F");
-        const bool off2 = e2 && e2[0] == '1';
-        if (!off2 && h->ops.size() > 6 && dims.n[0] == 1) {
-            const Op &m1 = h->ops[3], &m2 = h->ops[4], &cv2 = h->ops[5], &cv1 = h->ops[2];
-            h->use_c2f = m1.kind == OP_CONV && m2.kind == OP_CONV && cv2.kind == OP_CONV && m1.k == 3 && m2.k == 3 && cv2.k == 1 &&
-                         m1.stride == 1 && m2.stride == 1 && m1.act && m2.act && cv2.act && m1.in_buf == cv1.out_buf &&
-                         m2.res_buf == cv1.out_buf && m2.res_coff == m1.in_coff && cv2.in_buf == cv1.out_buf && cv2.in_coff == cv1.out_coff &&
-                         m1.in_coff == cv1.out_coff + 32 && m2.out_coff == cv1.out_coff + 64 && cv2.cin == 96 && m1.Kpad == m2.Kpad &&
-                         cv2.out2_buf < 0 && cv2.res_buf < 0 && m1.cout == 32 && m2.cout == 32 &&
-                         c2f_fused_eligible(h->is_f16, m1.cin, dims.n[0], m2.res_buf >= 0, cv2.cout);
-        }
-    }
-
-    // ---- activation workspace: every tensor gets its own allocation (288 GB HBM: no liveness reuse needed)
-    for (Buf &b : h->bufs) {
-        if (dev_alloc(h, &b.ptr, b.elems_per_image * (size_t)h->max_batch * (b.f32 ? 4 : h->esize))) {
-            wtk_yolo_destroy(h);
-            return 1;
-        }
-    }
-    if (dev_alloc(h, (void **)&h->o_xywh, sizeof(float) * 4 * h->max_batch) || dev_alloc(h, (void **)&h->o_conf, sizeof(float) * h->max_batch) ||
-        dev_alloc(h, (void **)&h->o_anchor, sizeof(int) * h->max_batch) || dev_alloc(h, (void **)&h->o_margin, sizeof(float) * h->max_batch)) {
-        wtk_yolo_destroy(h);
-        return 1;
-    }
-    if (acquire_status_word(&h->status_host, &h->status_dev)) {
-        h->status_host = nullptr;
-        wtk_yolo_destroy(h);
-        return fail("wtk_yolo_create: no pinned status word (hipHostMalloc failed, or more than 4096 live handles)");
-    }
-    if (dev_alloc(h, &h->zero_page, 256)) {
-        wtk_yolo_destroy(h);
-        return 1;
-    }
-    if (hipMemset(h->zero_page, 0, 256) != hipSuccess) {
-        wtk_yolo_destroy(h);
-        return fail("wtk_yolo_create: hipMemset failed");
-    }
-    // streams (side streams, the host entry points' stream) are taken from the process pool at first use: a handle that never runs
-    // with side streams (the hybrid's second look) or never sees a host call does not occupy a hardware queue slot
-    *out = h;
-    return 0;
-}
-
-extern "C" int wtk_yolo_status(wtk_yolo *h, int32_t *flags, int32_t clear) {
-    if (!h || !flags) return fail("wtk_yolo_status: null argument");
-    *flags = h->status_static | (h->status_host ? __atomic_load_n(h->status_host, __ATOMIC_RELAXED) : 0);
-    if (clear && h->status_host) __atomic_store_n(h->status_host, 0, __ATOMIC_RELAXED);
-    return 0;
-}
-
-extern "C" int wtk_yolo_workload(wtk_yolo *h, double *macs_per_frame, int32_t *anchors) {
-    if (!h) return fail("wtk_yolo_workload: null handle");
-    if (macs_per_frame) *macs_per_frame = h->macs_per_frame;
-    if (anchors) *anchors = h->anchors;
-    return 0;
-}
-
-extern "C" int wtk_yolo_set_profiling(wtk_yolo *h, int32_t enabled) {
-    if (!h) return fail("wtk_yolo_set_profiling: null handle");
-    if (enabled && !h->ev_created) {
-        for (int i = 0; i < wtk_yolo::kProfEvents; ++i) {
-            HIP_TRY(hipEventCreate(&h->ev[i]));
-            h->ev_created = i + 1;
-        }
-    }
-    h->profiling = enabled ? 1 : 0;
-    for (int i = 0; i < wtk_yolo::kProfKernels; ++i) h->prof_ms[i] = 0, h->prof_flops[i] = 0, h->prof_launches[i] = 0;
-    return 0;
-}
-
-extern "C" int wtk_yolo_get_kernel_profile(wtk_yolo *h, int32_t kernel_id, double *total_ms, int64_t *launches, double *flops) {
-    if (!h || kernel_id < 0 || kernel_id >= wtk_yolo::kProfKernels) return fail("wtk_yolo_get_kernel_profile: bad argument");
-    if (total_ms) *total_ms = h->prof_ms[kernel_id];
-    if (launches) *launches = h->prof_launches[kernel_id];
-    if (flops) *flops = h->prof_flops[kernel_id];
-    return 0;
-}
-
-extern "C" int wtk_yolo_get_profile(wtk_yolo *h, int32_t kernel_class, double *total_ms, int64_t *launches) {
-    if (!h || kernel_class < 0 || kernel_class > 3) return fail("wtk_yolo_get_profile: bad argument");
-    double ms = h->prof_ms[kernel_class];
-    long long n = h->prof_launches[kernel_class];
-    if (kernel_class == 1)
-        for (int k = 4; k < wtk_yolo::kProfKernels; ++k) ms += h->prof_ms[k], n += h->prof_launches[k];
-    if (total_ms) *total_ms = ms;
-    if (launches) *launches = n;
-    return 0;
-}
-
-// ultralytics LetterBox geometry (auto=False: pad to exactly imgsz) + scale_boxes inverse
-static void letterbox_geom(int H, int W, int Sh, int Sw, int &new_h, int &new_w, int &top, int &left, float &gain, float &pad_x, float &pad_y) {
-    const double r = std::min((double)Sh / H, (double)Sw / W);
-    new_w = (int)std::nearbyint(W * r);
-    new_h = (int)std::nearbyint(H * r);
-    const double dw = (Sw - new_w) / 2.0, dh = (Sh - new_h) / 2.0;
-    top = (int)std::nearbyint(dh - 0.1);
-    left = (int)std::nearbyint(dw - 0.1);
-    // scale_boxes recomputes gain/pad from the two shapes
-    gain = (float)std::min((double)Sh / H, (double)Sw / W);
-    pad_x = (float)std::nearbyint((Sw - W * (double)gain) / 2.0 - 0.1);
-    pad_y = (float)std::nearbyint((Sh - H * (double)gain) / 2.0 - 0.1);
-}
-
-// outputs of the general NMS path (max_det >= 1 rows per image)
-struct NmsOut {
-    float iou;
-    int max_det;
-    int *out_cls, *out_count;
-};
-static int run_head(wtk_yolo *h, int B, int H, int W, float conf, float *out_xywh, float *out_conf, int *out_anchor, hipStream_t st,
-                    const NmsOut *nms = nullptr) {
-    HeadArgs a;
-    std::memset(&a, 0, sizeof(a));
-    for (int i = 0; i < 3; ++i) {
-        a.box[i] = h->bufs[h->box_buf[i]].ptr;
-        a.cls[i] = h->bufs[h->cls_buf[i]].ptr;
-        a.lh[i] = h->lh[i];
-        a.lw[i] = h->lw[i];
-    }
-    a.cls_ld = h->cls_ld;
-    a.nc = h->dims.nc;
-    a.N = B;
-    a.conf = conf;
-    int nh, nw, top, left;
-    letterbox_geom(H, W, h->S_h, h->S_w, nh, nw, top, left, a.gain, a.pad_x, a.pad_y);
-    a.img_w = (float)W;
-    a.img_h = (float)H;
-    a.out_xywh = out_xywh;
-    a.out_conf = out_conf;
-    a.out_anchor = out_anchor;
-    a.out_margin = h->o_margin;
-    a.status = h->status_dev;
-    a.conf_logit = conf > 0.f && conf < 1.f ? std::log(conf / (1.f - conf)) : (conf <= 0.f ? -INFINITY : INFINITY);
-    if (nms) {
-        NmsArgs q;
-        q.h = a;
-        q.iou = nms->iou, q.max_det = nms->max_det;
-        q.scratch_score = h->nms_score, q.scratch_cls = h->nms_cls, q.scratch_box = h->nms_box;
-        q.out_xywh = out_xywh, q.out_conf = out_conf, q.out_anchor = out_anchor, q.out_cls = nms->out_cls, q.out_count = nms->out_count;
-        HIP_TRY(launch_head_nms(q, 0, st)); // the Detect outputs are fp32 tensors in both modes
-        return 0;
-    }
-    HIP_TRY(launch_head(a, 0, st)); // the Detect outputs are fp32 tensors in both modes
-    return 0;
-}
-
-static int ensure_nms_scratch(wtk_yolo *h, hipStream_t st) {
-    if (h->nms_score) return 0;
-    HIP_TRY(hipStreamSynchronize(st));
-    const size_t n = (size_t)h->max_batch * h->anchors;
-    HIP_TRY(hipMalloc(&h->nms_score, n * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->nms_cls, n * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->nms_box, n * 4 * sizeof(float)));
-    return 0;
-}
-
-// Enqueue one forward pass (letterbox, stem, convs, pool, head) on `st`.  No allocation, no synchronisation
-// (profiling mode excepted): safe inside stream capture.
-// The pair of side streams is shared by every handle of the process on a device (ensure_side_streams).  Handles driven from different host
-// threads (ctypes releases the GIL) must not interleave on it: a stream capture in one thread (the graph path of wtk_yolo_predict pulls the side
-// streams into a hipStreamCaptureModeThreadLocal capture through the event waits) would swallow or reject the other thread's launches.  Every
-// enqueue that touches the shared pair, and the whole capture bracket, holds this lock; a single-threaded caller (the bench, the controllers)
-// never contends on it.
-static std::recursive_mutex g_side_mu;
-
-// side streams and their events, taken at the first forward pass that uses them
-static int ensure_side_streams(wtk_yolo *h) {
-    // ONE pair of side streams per process and device, shared by every handle and never destroyed.  The HIP runtime multiplexes streams onto its
-    // hardware queues (four by default); with two lanes (two caller streams) a pair per handle made six streams, and which of them shared a queue
-    // depended on the order in which streams had been created in the process: the same workload ran at 24.5 .. 27 k frames/s (fp16) or 14.8 .. 17.7 k
-    // (hybrid) depending on what had run before it (tools/gpu_sessions/order_probe.py).  Two callers + one shared pair = four streams: every stream
-    // has a queue of its own, and the rate no longer depends on the history of the process.  The towers of different handles then run one after the
-    // other on a side stream; lanes are out of phase, nothing is lost (26.8 k / 17.6 k).
-    for (int i = 1; i <= 2; ++i) {
-        if (!h->side_stream[i]) {
-            static std::mutex mu;
-            static std::vector<std::pair<int, hipStream_t>> g_shared[2]; // per slot: (device, stream)
-            std::lock_guard<std::mutex> lk(mu);
-            for (auto &e : g_shared[i - 1])
-                if (e.first == h->device) h->side_stream[i] = e.second;
-            if (!h->side_stream[i]) {
-                HIP_TRY(hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
-                g_shared[i - 1].emplace_back(h->device, h->side_stream[i]);
-            }
-        }
-        if (!h->side_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming));
-    }
-    for (int i = 0; i < 2; ++i)
-        if (!h->feat_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->feat_ev[i], hipEventDisableTiming));
-    return 0;
-}
-
-// `vs` != nullptr: the batch rows are camera views of full frames (wtk_yolo_predict_views) — crop + letterbox in one kernel.
-struct ViewSrc {
-    const int32_t *pos_xy, *frame_index;
-    int view_w, view_h, n_frames;
-};
-static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
-                        float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr, const NmsOut *nms = nullptr) {
-    const uint8_t *net_in = frames_dev;
-    if (vs) {
-        ViewLetterboxArgs va;
-        va.frames = frames_dev, va.frame_index = vs->frame_index, va.pos_xy = vs->pos_xy, va.dst = h->lb_dev;
-        va.N = B, va.H = H, va.W = W, va.C = C;
-        va.F = vs->n_frames;
-        va.view_w = vs->view_w, va.view_h = vs->view_h;
-        va.rows = vs->view_w, va.cols = vs->view_h; // frame[y : y + w, x : x + h], view_controller.py:171
-        va.Sh = h->S_h, va.Sw = h->S_w;
-        float g, px, py;
-        letterbox_geom(va.rows, va.cols, h->S_h, h->S_w, va.new_h, va.new_w, va.top, va.left, g, px, py);
-        HIP_TRY(launch_view_letterbox(va, st));
-        net_in = h->lb_dev;
-        H = va.rows, W = va.cols; // from here on the "image" is the view: scale_boxes maps back to view pixels
-    } else if (H != h->S_h || W != h->S_w) {
-        LetterboxArgs la;
-        la.src = frames_dev;
-        la.dst = h->lb_dev;
-        la.N = B, la.H = H, la.W = W, la.C = C;
-        la.Sh = h->S_h, la.Sw = h->S_w;
-        float g, px, py;
-        letterbox_geom(H, W, h->S_h, h->S_w, la.new_h, la.new_w, la.top, la.left, g, px, py);
-        HIP_TRY(launch_letterbox(la, st));
-        net_in = h->lb_dev;
-    }
-
-    int cur_class = -1, nev = 0;
-    int ev_class[wtk_yolo::kProfEvents];
-    auto mark = [&](int cls) -> int {
-        if (!h->profiling || cls == cur_class) return 0;
-        if (nev >= wtk_yolo::kProfEvents - 1) return 0;
-        HIP_TRY(hipEventRecord(h->ev[nev], st));
-        ev_class[nev] = cls;
-        ++nev;
-        cur_class = cls;
-        return 0;
-    };
-    long long launches[wtk_yolo::kProfKernels] = {};
-    double flops[wtk_yolo::kProfKernels] = {};
-    auto op_flops = [&](const Op &o) { return 2.0 * B * o.macs_per_image; }; // algorithmic: 2 x output pixels x cout x (cin x k x k)
-
-    // Two lanes: the caller's stream runs backbone + PAN + the P5 tower; the P3 / P4 Detect towers run on
-    // the side stream as soon as their feature map is complete and fill the tails of the small PAN kernels.
-    // Profiling keeps everything on one stream so the per-class event brackets stay meaningful.
-    // latency-plan handles (round 6): everything on the caller's stream, independent convs grouped per dependency level into one launch each
-    const bool grouped = h->latency && h->sk_group && !h->lat_sched.empty();
-    if (!grouped && h->use_side && h->side_streams > 0 && !h->profiling && ensure_side_streams(h)) return 1;
-    const bool two_lanes = !grouped && h->use_side && h->side_streams > 0 && h->side_stream[1] && !h->profiling;
-    std::unique_lock<std::recursive_mutex> side_lock;
-    if (two_lanes) side_lock = std::unique_lock<std::recursive_mutex>(g_side_mu);
-    unsigned side_used = 0; // bit i: side_stream[i] carries work of this pass
-    hipStream_t main_st = st;
-    size_t first_op = 0;
-    if (h->use_front && reinterpret_cast<uintptr_t>(net_in) % 4 == 0) {
-        if (mark(5)) return 1;
-        const Op &o0 = h->ops[0], &o1 = h->ops[1], &o2 = h->ops[2];
-        FrontArgs f;
-        std::memset(&f, 0, sizeof(f));
-        f.frames = net_in;
-        f.N = B, f.H = h->S_h, f.W = h->S_w, f.C = C;
-        f.w0 = o0.w, f.b0 = o0.bias;
-        f.w1 = o1.w, f.b1 = o1.bias, f.Kpad1 = o1.Kpad;
-        f.w2 = o2.w, f.b2 = o2.bias, f.Kpad2 = o2.Kpad;
-        f.out = h->bufs[o2.out_buf].ptr;
-        f.out_ld = h->bufs[o2.out_buf].C;
-        f.out_coff = o2.out_coff;
-        if (h->front_debug) f.dbg_t0 = h->bufs[o0.out_buf].ptr, f.dbg_t1 = h->bufs[o1.out_buf].ptr;
-        if (h->split) { // pseudo-channels (see the conv path below)
-            f.Kpad1 *= 2, f.Kpad2 *= 2, f.out_ld *= 2, f.out_coff *= 2;
-            f.n_dyn = h->n_dyn;
-            f.stem_split = 1;
-            HIP_TRY(launch_front_fused_split(f, h->num_cus, st));
-        } else
-            HIP_TRY(launch_front_fused(f, h->num_cus, st));
-        ++launches[5];
-        flops[5] += op_flops(o0) + op_flops(o1) + op_flops(o2);
-        first_op = 3;
-    }
-    // the conv of `op` as the implicit-GEMM / split-K launchers take it (split handles: pseudo-channel arguments)
-    auto conv_args = [&](const Op &op) -> ConvArgs {
-        const Buf &ib = h->bufs[op.in_buf];
-        const Buf &ob = h->bufs[op.out_buf];
-        ConvArgs a;
-        std::memset(&a, 0, sizeof(a));
-        a.in = ib.ptr;
-        a.in_ld = ib.C;
-        a.in_coff = op.in_coff;
-        a.N = B, a.H = ib.h, a.W = ib.w, a.Cin = op.cin;
-        a.Ho = ob.h, a.Wo = ob.w, a.Cout = op.cout;
-        a.CoutPad = op.cout_pad;
-        a.KH = a.KW = op.k;
-        a.stride = op.stride;
-        a.pad = op.k / 2;
-        a.w = op.w;
-        a.bias = op.bias;
-        a.out = ob.ptr;
-        a.out_ld = ob.C;
-        a.out_coff = op.out_coff;
-        a.out_f32 = ob.f32;
-        a.n_dyn = h->n_dyn;
-        if (op.out2_buf >= 0) {
-            a.out2 = h->bufs[op.out2_buf].ptr;
-            a.out2_ld = h->bufs[op.out2_buf].C;
-            a.out2_coff = op.out2_coff;
-        }
-        if (op.in2_buf >= 0) {
-            a.in2 = h->bufs[op.in2_buf].ptr;
-            a.in2_ld = h->bufs[op.in2_buf].C;
-            a.in2_coff = op.in2_coff;
-            a.in2_split = op.in2_split;
-        }
-        if (op.res_buf >= 0) {
-            a.res = h->bufs[op.res_buf].ptr;
-            a.res_ld = h->bufs[op.res_buf].C;
-            a.res_coff = op.res_coff;
-        }
-        a.act = op.act;
-        a.K = op.K;
-        a.Kpad = op.Kpad;
-        a.M = (long long)B * ob.h * ob.w;
-        a.tile_w = op.tile_w;
-        a.zeros = h->zero_page;
-        if (op.tile_w) {
-            const int th = conv_cfg_bm(op.cfg) / op.tile_w;
-            a.tiles_x = (ob.w + op.tile_w - 1) / op.tile_w;
-            a.tiles_y = (ob.h + th - 1) / th;
-        }
-        if (h->split) {
-            // pseudo-channels: every channel count / offset of a split tensor doubles (an fp32 output keeps its real layout)
-            a.in_ld *= 2, a.in_coff *= 2, a.Cin *= 2, a.K *= 2, a.Kpad *= 2;
-            a.in2_ld *= 2, a.in2_coff *= 2, a.in2_split *= 2;
-            a.res_ld *= 2, a.res_coff *= 2, a.out2_ld *= 2, a.out2_coff *= 2;
-            if (!a.out_f32) a.out_ld *= 2, a.out_coff *= 2;
-        }
-        return a;
-    };
-    auto run_op = [&](size_t oi) -> int {
-        const Op &op = h->ops[oi];
-        if (h->use_c2f && (oi == 3 || oi == 4)) return 0; // folded into the fused C2f tail launched at op 5
-        if (op.folded) return 0;                          // runs in the epilogue of the op that names it as tail_op
-        if (h->use_c2f && oi == 5) {
-            if (mark(5)) return 1;
-            const Op &m1 = h->ops[3], &m2 = h->ops[4];
-            const Buf &cb = h->bufs[op.in_buf];
-            C2fArgs c;
-            std::memset(&c, 0, sizeof(c));
-            c.cat = cb.ptr, c.cat_ld = cb.C, c.a_coff = op.in_coff, c.b_coff = m1.in_coff;
-            c.N = B, c.H = cb.h, c.W = cb.w;
-            c.w_m1 = m1.w, c.b_m1 = m1.bias, c.w_m2 = m2.w, c.b_m2 = m2.bias, c.Kpad_m = m1.Kpad;
-            c.w_cv2 = op.w, c.b_cv2 = op.bias, c.Kpad_cv2 = op.Kpad;
-            c.out = h->bufs[op.out_buf].ptr, c.out_ld = h->bufs[op.out_buf].C, c.out_coff = op.out_coff;
-            c.zeros = h->zero_page;
-            HIP_TRY(launch_c2f_fused(c, h->num_cus, main_st));
-            ++launches[5];
-            flops[5] += op_flops(m1) + op_flops(m2) + op_flops(op);
-            return 0;
-        }
-        st = main_st;
-        if (two_lanes && op.side) {
-            const int sidx = std::min(op.side, h->side_streams); // wtk_yolo_set_side_streams(1): both towers on side stream 1
-            st = h->side_stream[sidx];
-            if (op.wait_feat >= 0) HIP_TRY(hipStreamWaitEvent(st, h->feat_ev[op.wait_feat], 0));
-            side_used |= 1u << sidx;
-        }
-        if (op.kind == OP_STEM) {
-            if (mark(0)) return 1;
-            StemArgs a;
-            a.frames = net_in;
-            a.N = B, a.H = h->S_h, a.W = h->S_w, a.C = C;
-            a.w = op.w;
-            a.bias = op.bias;
-            a.out = h->bufs[op.out_buf].ptr;
-            a.Cout = op.cout;
-            a.Ho = h->S_h / 2, a.Wo = h->S_w / 2;
-            a.out_split = h->split; // split store
-            a.in_split = h->split;  // split operands
-            a.n_dyn = h->n_dyn;
-            HIP_TRY(launch_stem(a, h->is_f16, st));
-            ++launches[0];
-            flops[0] += op_flops(op);
-        } else if (op.kind == OP_POOL) {
-            if (mark(2)) return 1;
-            const Buf &b = h->bufs[op.in_buf];
-            PoolArgs a;
-            a.buf = b.ptr;
-            a.N = B, a.H = b.h, a.W = b.w, a.c = op.cin;
-            a.split = h->split;
-            HIP_TRY(launch_sppf_pool(a, h->is_f16, st));
-            ++launches[2];
-        } else {
-            const int kid = op.sk ? 1 : (op.halo == 2 ? 6 : (op.halo ? 4 : 1));
-            if (mark(kid)) return 1;
-            const Buf &ib = h->bufs[op.in_buf];
-            const Buf &ob = h->bufs[op.out_buf];
-            ConvArgs a = conv_args(op);
-            if (op.sk) {
-                a.tile_w = 0;
-                if (!conv_sk_eligible(a, h->split)) return fail("internal: conv " + std::to_string(oi) + " of the latency plan does not fit conv_sk_kernel");
-                const SkMember one{a, op.sk_atoms, op.sk_partial, op.sk_tickets};
-                HIP_TRY(launch_conv_sk_group(&one, 1, h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, st, &h->sk_choices[((long long)(oi + 100000) << 24) | (long long)B]));
-            } else if (h->split && !op.halo && h->use_s2win && ib.h == 2 * ob.h && ib.w == 2 * ob.w &&
-                split_s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0 && !ob.f32)) {
-                // strided 3x3, split operands: the parity-plane window kernel on pseudo-channels
-                HaloArgs g;
-                std::memset(&g, 0, sizeof(g));
-                g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
-                g.N = B, g.H = ob.h, g.W = ob.w, g.Cin = a.Cin;
-                g.Cout = op.cout, g.CoutPad = op.cout_pad;
-                g.w = op.w, g.bias = op.bias;
-                g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
-                g.act = op.act, g.Kpad = a.Kpad;
-                g.n_dyn = h->n_dyn;
-                g.S = ob.w, g.pitch = ob.w + 1, g.strips = 1;
-                g.bm = 256;
-                g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 255) / 256);
-                if (2LL * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus) {
-                    g.bm = 128;
-                    g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 127) / 128);
-                }
-                g.zeros = h->zero_page;
-                HIP_TRY(launch_conv3x3_s2_split(g, st));
-            } else if (h->split && !op.halo) {
-                int cfg = op.cfg;
-                // a small handle's 128 x 128-tile layer whose grid leaves a third of the CUs idle: 64-cout tiles, twice the blocks (same K order: same bits)
-                if (h->small_narrow && h->split && cfg == CFG_128x128 && !a.in2 && !a.tile_w &&
-                    3 * ((a.M + 127) / 128) * (a.CoutPad / 128) <= 2LL * h->num_cus)
-                    cfg = CFG_128x64;
-                HIP_TRY(launch_conv_split(a, cfg, st));
-            } else if (op.halo) {
-                HaloArgs g;
-                std::memset(&g, 0, sizeof(g));
-                g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
-                g.N = B, g.H = ib.h, g.W = ib.w, g.Cin = op.cin;
-                g.Cout = op.cout, g.CoutPad = op.cout_pad;
-                g.w = op.w, g.bias = op.bias;
-                g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
-                g.out2 = a.out2, g.out2_ld = a.out2_ld, g.out2_coff = a.out2_coff;
-                g.res = a.res, g.res_ld = a.res_ld, g.res_coff = a.res_coff;
-                g.act = op.act, g.Kpad = op.Kpad;
-                g.n_dyn = h->n_dyn;
-                g.slabs = h->halo_slabs;
-                if (h->split) g.Cin = a.Cin, g.Kpad = a.Kpad, g.slabs = 3; // pseudo-channels
-                if (op.tail_op >= 0) {
-                    const Op &t = h->ops[op.tail_op];
-                    g.tail_w = t.w, g.tail_bias = t.bias, g.tail_kpad = t.Kpad;
-                    g.tail_out = h->bufs[t.out_buf].ptr, g.tail_ld = h->bufs[t.out_buf].C, g.tail_coff = t.out_coff;
-                    g.tail_cout = t.cout;
-                    g.tail_f32 = h->bufs[t.out_buf].f32;
-                    if (h->split) { // pseudo-channels for the split weights (and for a split output; the fp32 head logits keep their real layout)
-                        g.tail_kpad *= 2;
-                        if (!g.tail_f32) g.tail_ld *= 2, g.tail_coff *= 2;
-                    }
-                }
-                g.persist_cus = h->halo_persist ? h->num_cus : 0;
-                const int rows_max = (op.halo == 2 && h->split) ? c32_split_rows_max() : (op.halo == 2 || h->split) ? kHaloRowsMax : halo_rows_max(op.cout, h->halo_slabs);
-                bool ws64 = false;
-                if (op.halo == 1 && h->use_ws64 && h->halo_slabs == 3 &&
-                    ws64_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, h->is_f16, op.out2_buf >= 0, op.tail_op >= 0)) {
-                    halo_geometry_stacked(B, ib.h, ib.w, ws64_rows_max(), &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
-                    // worth it when every group of a persistent block gets at least two tiles (weights are staged once per block)
-                    ws64 = (long long)g.strips * g.blocks_per_strip >= 4LL * h->num_cus;
-                }
-                if (ws64) {
-                    g.zeros = h->zero_page;
-                    g.bm = 0; // (the weave schedules of round 3 lost: the round-2 schedule)
-#ifdef WTK_WS64_STAMPS
-                    if (std::getenv("WTK_WS64_STAMPS")) {
-                        if (!g_dbg_stamps) HIP_TRY(hipMalloc(&g_dbg_stamps, kDbgStampBytes));
-                        g.dbg_stamps = g_dbg_stamps;
-                    }
-#endif
-                    HIP_TRY(launch_conv3x3_ws64(g, h->num_cus, st));
-                } else if (op.halo == 2) {
-                    halo_geometry(ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
-                } else {
-                    halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip);
-                    if (h->halo_slabs == 3 || h->split) {
-                        // small maps: halve the blocks when 256-pixel blocks leave at least half of the CUs without work
-                        const long long tiles = (long long)g.strips * g.blocks_per_strip * (op.cout_pad / (h->split ? split_halo_cout_tile(op.cout) : halo_cout_tile(op.cout)));
-                        if (h->halo_small_blocks && 2 * tiles <= h->num_cus) {
-                            g.bm = 128;
-                            halo_geometry_stacked(B, ib.h, ib.w, rows_max, &g.S, &g.pitch, &g.strips, &g.blocks_per_strip, 128);
-                            // still under half of the CUs with 128-pixel blocks (a small handle's cycle batch on the 24 x 24 maps): 64-cout tiles as well —
-                            // each block then walks the same taps over half the couts
-                            if (h->small_narrow && h->split && op.tail_op < 0 && op.cout_pad % 128 == 0 &&
-                                2LL * g.strips * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus)
-                                g.narrow = 1;
-                        }
-                    }
-                }
-                // fp32 handles: the exact-fp32 matrix instructions make these layers arithmetic bound, so a grid on under three quarters of the CUs (a small
-                // handle's 48 x 48 maps: 141-150 blocks of 128 / 192 couts) is cut into 64-cout tiles (Detect P3 first convs 205 us, class tower 139 us before)
-                if (h->small_narrow && !h->split && !ws64 && op.halo == 1 && op.tail_op < 0 && op.cout_pad % 64 == 0 && halo_cout_tile(op.cout) != 64 &&
-                    4LL * g.strips * g.blocks_per_strip * (op.cout_pad / halo_cout_tile(op.cout)) <= 3LL * h->num_cus)
-                    g.narrow = 1;
-                // Small f16x3 handles: the 64-cout window tiles on the six-slab ring with fragment prefetch (conv3x3_halo.hip; bit-identical to the
-                // three-slab kernel).  A cycle batch's 24 x 24 layers 19.4 -> 15.9 us each; the 256-pixel tiles and the large handles measure the
-                // same either way (profiles/r05_notes.md section 7), so those keep the three-slab kernel.  WTK_HALO_DEEP: 0 off, 1 small handles
-                // (default), 2 every handle; read when the handle is created.
-                if (h->halo_deep && op.halo == 1 && !ws64) g.deep = 1;
-                g.zeros = h->zero_page;
-                if (ws64) {
-                } else if (h->split && op.halo == 2)
-                    HIP_TRY(launch_conv3x3_c32_split(g, st));
-                else if (h->split)
-                    HIP_TRY(launch_conv3x3_halo_split(g, st));
-                else if (op.halo == 2)
-                    HIP_TRY(launch_conv3x3_c32(g, st));
-                else
-                    HIP_TRY(launch_conv3x3_halo(g, h->is_f16, st));
-            } else if (h->use_s2win && op.tail_op < 0 &&
-                       s2win_eligible(op.k, op.stride, op.cin, op.cout, op.cout_pad, h->is_f16, ob.w, op.res_buf < 0 && op.out2_buf < 0 && op.in2_buf < 0) &&
-                       ib.h == 2 * ob.h && ib.w == 2 * ob.w) {
-                // strided 3x3: parity-plane window kernel; the geometry lives on the OUTPUT map (stacked images, one strip)
-                HaloArgs g;
-                std::memset(&g, 0, sizeof(g));
-                g.in = a.in, g.in_ld = a.in_ld, g.in_coff = a.in_coff;
-                g.N = B, g.H = ob.h, g.W = ob.w, g.Cin = op.cin;
-                g.Cout = op.cout, g.CoutPad = op.cout_pad;
-                g.w = op.w, g.bias = op.bias;
-                g.out = a.out, g.out_ld = a.out_ld, g.out_coff = a.out_coff;
-                g.act = op.act, g.Kpad = op.Kpad;
-                g.n_dyn = h->n_dyn;
-                g.S = ob.w, g.pitch = ob.w + 1, g.strips = 1;
-                g.bm = 256;
-                g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 255) / 256);
-                if (2LL * g.blocks_per_strip * (op.cout_pad / 128) <= h->num_cus) { // small maps: half-size blocks fill the chip
-                    g.bm = 128;
-                    g.blocks_per_strip = (int)(((long long)B * (ob.h + 1) * g.pitch + 127) / 128);
-                }
-                g.zeros = h->zero_page;
-                HIP_TRY(launch_conv3x3_s2(g, st));
-            } else if (op.tail_op >= 0) { // implicit GEMM with the 1x1 behind it fused into its epilogue
-                const Op &t = h->ops[op.tail_op];
-                a.tail_w = t.w, a.tail_bias = t.bias, a.tail_kpad = t.Kpad, a.tail_act = t.act;
-                a.tail_out = h->bufs[t.out_buf].ptr, a.tail_ld = h->bufs[t.out_buf].C, a.tail_coff = t.out_coff;
-                HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
-            } else if (h->use_wide && conv1x1_wide_eligible(a, h->is_f16) && a.CoutPad >= 256 && ((a.M + 255) / 256) * (a.CoutPad / 128) >= 384) {
-                HIP_TRY(launch_conv1x1_wide(a, st));
-            } else {
-                HIP_TRY(launch_conv(a, op.cfg, h->is_f16, st));
-            }
-            ++launches[kid];
-            flops[kid] += op_flops(op) + (op.tail_op >= 0 ? op_flops(h->ops[op.tail_op]) : 0.0);
-            if (two_lanes && op.signal_feat >= 0) HIP_TRY(hipEventRecord(h->feat_ev[op.signal_feat], main_st));
-        }
-            return 0;
-    };
-    if (grouped) {
-        // latency plan: ONE stream, one launch per dependency level (sk_schedule): ops[0 .. 2] (the front, when it did not run fused) first
-        for (size_t oi = first_op; oi < 3 && oi < h->ops.size(); ++oi)
-            if (run_op(oi)) return 1;
-        for (size_t li = 0; li < h->lat_sched.size(); ++li) {
-            const std::vector<int> &L = h->lat_sched[li];
-            if (L.size() == 1) {
-                if (run_op((size_t)L[0])) return 1;
-                continue;
-            }
-            if (mark(1)) return 1;
-            SkMember m[kSkGroupMax];
-            for (size_t k = 0; k < L.size(); ++k) {
-                const Op &op = h->ops[L[k]];
-                m[k] = SkMember{conv_args(op), op.sk_atoms, op.sk_partial, op.sk_tickets};
-                m[k].a.tile_w = 0;
-                if (!conv_sk_eligible(m[k].a, h->split)) return fail("internal: conv " + std::to_string(L[k]) + " of the latency plan does not fit conv_sk_kernel");
-                flops[1] += op_flops(op);
-            }
-            HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st, &h->sk_choices[((long long)li << 24) | (long long)B]));
-            ++launches[1];
-        }
-    } else {
-        for (size_t oi = first_op; oi < h->ops.size(); ++oi)
-            if (run_op(oi)) return 1;
-    }
-    st = main_st;
-    for (int i = 1; i < wtk_yolo::kSideStreams; ++i)
-        if (side_used & (1u << i)) {
-            HIP_TRY(hipEventRecord(h->side_done[i], h->side_stream[i]));
-            HIP_TRY(hipStreamWaitEvent(main_st, h->side_done[i], 0));
-        }
-    if (mark(3)) return 1;
-    if (run_head(h, B, H, W, conf, out_xywh, out_conf, out_anchor, st, nms)) return 1;
-    ++launches[3];
-    if (h->profiling) {
-        if (nev < wtk_yolo::kProfEvents) {
-            HIP_TRY(hipEventRecord(h->ev[nev], st));
-            ev_class[nev] = -1;
-            ++nev;
-        }
-        HIP_TRY(hipEventSynchronize(h->ev[nev - 1]));
-        for (int i = 0; i + 1 < nev; ++i) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-            h->prof_ms[ev_class[i]] += ms;
-        }
-        for (int i = 0; i < wtk_yolo::kProfKernels; ++i) h->prof_launches[i] += launches[i], h->prof_flops[i] += flops[i];
-    }
-    return 0;
-}
-
-// Captured launches carry the stream layout / dynamic-batch pointer they were captured with: drop them all.  Each exec is destroyed only after its last
-// replay has finished (its own event; no device-wide synchronise: other lanes keep running, and a global-mode capture open in another thread stays
-// legal); argument sets met once are forgotten too.
-static void destroy_graph_entry(wtk_yolo::GraphEntry &g) {
-    if (g.done) {
-        (void)hipEventSynchronize(g.done);
-        (void)hipEventDestroy(g.done);
-    }
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    g.exec = nullptr, g.done = nullptr;
-}
-static void drop_graphs(wtk_yolo *h) {
-    for (auto &g : h->graphs) destroy_graph_entry(g);
-    h->graphs.clear();
-    h->seen_once.clear();
-}
-
-// Replay the captured forward pass of this argument set, or capture it now (the whole launch sequence incl. the side streams).
-static int graph_replay_or_capture(wtk_yolo *h, wtk_yolo::GraphEntry key, hipStream_t st, const ViewSrc *vs) {
-    for (auto &g : h->graphs)
-        if (g.same_args(key)) {
-            HIP_TRY(hipGraphLaunch(g.exec, st));
-            HIP_TRY(hipEventRecord(g.done, st));
-            return 0;
-        }
-    hipGraph_t graph = nullptr;
-    const bool forks = !(h->latency && h->sk_group && !h->lat_sched.empty()) && h->use_side && h->side_streams > 0;
-    if (forks && ensure_side_streams(h)) return 1; // streams and events exist before the capture starts
-    std::unique_lock<std::recursive_mutex> capture_lock(g_side_mu); // no other thread may touch the shared side streams while they are captured
-    // protocol: the origin and the streams the capture will fork into are outside any capture when it begins (a stream left inside one by a failed
-    // bracket, here or in the caller's code, must not be captured again: fail loudly instead)
-    if (stream_idle(st, "the stream a capture is about to begin on")) return 1;
-    for (int i = 1; i < wtk_yolo::kSideStreams; ++i)
-        if (h->side_stream[i] && stream_idle(h->side_stream[i], "a side stream")) return 1;
-    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = yolo_enqueue(h, reinterpret_cast<const uint8_t *>(key.frames), key.B, key.H, key.W, key.C, key.conf, reinterpret_cast<float *>(key.o_xywh),
-                                reinterpret_cast<float *>(key.o_conf), reinterpret_cast<int32_t *>(key.o_anchor), st, vs);
-    const hipError_t ec = hipStreamEndCapture(st, &graph);
-    capture_lock.unlock();
-    if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return 1;
-    }
-    if (ec != hipSuccess) return fail_hip("hipStreamEndCapture", ec);
-    const hipError_t ei = hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) return fail_hip("hipGraphInstantiate", ei);
-    if (hipEventCreateWithFlags(&key.done, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGraphExecDestroy(key.exec);
-        return fail("hipEventCreateWithFlags failed");
-    }
-    if (h->graphs.size() >= 16) { // bounded cache: callers that rotate buffers would otherwise grow it without limit
-        destroy_graph_entry(h->graphs.front());
-        h->graphs.erase(h->graphs.begin());
-    }
-    h->graphs.push_back(key);
-    HIP_TRY(hipGraphLaunch(key.exec, st));
-    HIP_TRY(hipEventRecord(key.done, st));
-    return 0;
-}
-
-extern "C" int wtk_yolo_predict(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
-                                int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
-    (void)iou; // with max_det == 1 the IoU threshold cannot change the survivor
-    if (!h || !frames_dev || !out_xywh) return fail("wtk_yolo_predict: null argument");
-    if (B <= 0) return fail("wtk_yolo_predict: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
-    if (B > h->max_batch) return fail("wtk_yolo_predict: batch exceeds max_batch");
-    if (C != 1 && C != 3) return fail("wtk_yolo_predict: frames must have 1 (gray) or 3 (BGR) channels");
-    if (max_det != 1) return fail("wtk_yolo_predict: max_det must be 1 (yolo_controller.py:76 hard-wires it); wtk_yolo_predict_nms takes max_det > 1");
-    if (H <= 0 || W <= 0) return fail("wtk_yolo_predict: bad frame size");
-    DEVICE_GUARD(h);
-    hipStream_t st = (hipStream_t)stream;
-    if ((H != h->S_h || W != h->S_w) && h->lb_cap == 0) { // letterbox staging image, allocated once
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
-        h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
-    }
-    // Opt-in (WTK_GRAPH / WTK_GRAPH_HOST / WTK_GRAPH_VIEWS, see wtk_yolo_create_planned): replay a captured hipGraph of the forward pass.  The handle's own
-    // staging buffers (the *_host entry points) never change address, so one capture per (B, H, W, C, conf) is replayed forever; a caller's argument set
-    // is captured the second time it is met, so a caller that rotates its buffers never pays for a capture.
-    const bool own_buffers = frames_dev == h->frames_dev && out_xywh == h->o_xywh;
-    const bool use_graph = ((own_buffers && h->graph_host) || (!own_buffers && h->graph_views)) && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
-    if (!use_graph) return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
-    wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
-    if (!own_buffers) {
-        bool known = false;
-        for (auto &g : h->graphs) known = known || g.same_args(key);
-        for (auto &g : h->seen_once) known = known || g.same_args(key);
-        if (!known) {
-            if (h->seen_once.size() >= 16) h->seen_once.erase(h->seen_once.begin());
-            h->seen_once.push_back(key);
-            return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st);
-        }
-    }
-    return graph_replay_or_capture(h, key, st, nullptr);
-}
-
-extern "C" int wtk_yolo_predict_nms(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float iou,
-                                    int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls, int32_t *out_anchor, int32_t *out_count,
-                                    void *stream) {
-    if (!h || !frames_dev || !out_xywh) return fail("wtk_yolo_predict_nms: null argument");
-    if (B <= 0) return fail("wtk_yolo_predict_nms: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
-    if (B > h->max_batch) return fail("wtk_yolo_predict_nms: batch exceeds max_batch");
-    if (C != 1 && C != 3) return fail("wtk_yolo_predict_nms: frames must have 1 (gray) or 3 (BGR) channels");
-    if (max_det < 1 || max_det > 30000) return fail("wtk_yolo_predict_nms: max_det must be in [1, 30000]");
-    if (!(iou >= 0.f && iou <= 1.f)) return fail("wtk_yolo_predict_nms: iou must be in [0, 1]");
-    if (H <= 0 || W <= 0) return fail("wtk_yolo_predict_nms: bad frame size");
-    DEVICE_GUARD(h);
-    hipStream_t st = (hipStream_t)stream;
-    if ((H != h->S_h || W != h->S_w) && h->lb_cap == 0) {
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
-        h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
-    }
-    if (ensure_nms_scratch(h, st)) return 1;
-    const NmsOut nms{iou, max_det, out_cls, out_count};
-    return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, nullptr, &nms);
-}
-
-extern "C" int wtk_yolo_predict_views(wtk_yolo *h, const uint8_t *frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t C,
-                                      const int32_t *frame_index_dev, const int32_t *pos_xy_dev, int32_t B, int32_t view_w, int32_t view_h, float conf,
-                                      float iou, int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
-    (void)iou;
-    if (!h || !frames_dev || !pos_xy_dev || !out_xywh) return fail("wtk_yolo_predict_views: null argument");
-    if (B <= 0) return fail("wtk_yolo_predict_views: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
-    if (B > h->max_batch) return fail("wtk_yolo_predict_views: batch exceeds max_batch");
-    if (C != 1 && C != 3) return fail("wtk_yolo_predict_views: frames must have 1 (gray) or 3 (BGR) channels");
-    if (max_det != 1) return fail("wtk_yolo_predict_views: max_det must be 1 (yolo_controller.py:76 hard-wires it)");
-    if (H <= 0 || W <= 0 || view_w <= 0 || view_h <= 0 || n_frames <= 0) return fail("wtk_yolo_predict_views: bad frame / view size");
-    if (!frame_index_dev && B > n_frames) return fail("wtk_yolo_predict_views: without frame_index the batch rows are frames 0..B-1");
-    DEVICE_GUARD(h);
-    hipStream_t st = (hipStream_t)stream;
-    if (h->lb_cap == 0) { // staging image of the network input, allocated once
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMalloc(&h->lb_dev, (size_t)h->max_batch * h->S_h * h->S_w * 3));
-        h->lb_cap = (size_t)h->max_batch * h->S_h * h->S_w * 3;
-    }
-    const ViewSrc vs{pos_xy_dev, frame_index_dev, view_w, view_h, n_frames};
-    // The reference's operating point is this call at B = 1 and B = one cycle (9 / 15 views), once per cycle each (yolo_controller.py:95-109).  With
-    // WTK_GRAPH_VIEWS=1 a caller that comes back with the SAME device addresses (frames, view table, output rows — HipYoloController keeps them per
-    // batch size) gets the captured forward replayed; an argument set is captured the second time it is met (a caller that rotates its buffers never
-    // pays for a capture).  OFF by default: measured in round 4 (bench.py `closed_loop`, 384 x 384 views) the replay changes a B = 1 call from 1.13 to
-    // 1.12 ms and a B = 15 call from 1.38 to 1.35 ms — these calls are bound by the ~60 dependent kernels' own latencies (18 us each on grids of a few
-    // blocks), not by the host's launch rate — while a replay costs its fixed 10-16 us.
-    const bool use_graph = h->graph_views && st != nullptr && !h->profiling && h->graph_max_batch > 0 && B <= h->graph_max_batch;
-    if (use_graph) {
-        wtk_yolo::GraphEntry key{frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, nullptr};
-        key.idx = frame_index_dev, key.pos = pos_xy_dev, key.vw = view_w, key.vh = view_h, key.nf = n_frames;
-        bool known = false;
-        for (auto &g : h->graphs) known = known || g.same_args(key);
-        for (auto &g : h->seen_once) known = known || g.same_args(key);
-        if (known) return graph_replay_or_capture(h, key, st, &vs);
-        if (h->seen_once.size() >= 16) h->seen_once.erase(h->seen_once.begin());
-        h->seen_once.push_back(key);
-    }
-    return yolo_enqueue(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, &vs);
-}
-
-extern "C" int wtk_yolo_predict_host(wtk_yolo *h, const uint8_t *frames_host, int32_t B, int32_t H, int32_t W, int32_t C, float conf,
-                                     float iou, int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_anchor) {
-    if (!h || !frames_host || !out_xywh) return fail("wtk_yolo_predict_host: null argument");
-    if (B <= 0) return fail("wtk_yolo_predict_host: empty batch (the reference asserts len(frames) > 0, yolo_controller.py:65)");
-    if (B > h->max_batch) return fail("wtk_yolo_predict_host: batch exceeds max_batch");
-    if (H <= 0 || W <= 0 || (C != 1 && C != 3)) return fail("wtk_yolo_predict_host: bad frame shape");
-    DEVICE_GUARD(h);
-    const size_t need = (size_t)B * H * W * C;
-    if (need > h->frames_cap) {
-        (void)hipFree(h->frames_dev);
-        h->frames_dev = nullptr;
-        h->frames_cap = 0;
-        const size_t cap = std::max(need, (size_t)h->max_batch * H * W * C);
-        HIP_TRY(hipMalloc(&h->frames_dev, cap));
-        h->frames_cap = cap;
-    }
-    if (!h->host_stream && pooled_stream(h->device, &h->host_stream)) return 1;
-    hipStream_t st = h->host_stream;
-    HIP_TRY(hipMemcpyAsync(h->frames_dev, frames_host, need, hipMemcpyHostToDevice, st));
-    if (wtk_yolo_predict(h, h->frames_dev, B, H, W, C, conf, iou, max_det, h->o_xywh, h->o_conf, h->o_anchor, st)) return 1;
-    HIP_TRY(hipMemcpyAsync(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost, st));
-    if (out_conf) HIP_TRY(hipMemcpyAsync(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost, st));
-    if (out_anchor) HIP_TRY(hipMemcpyAsync(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return 0;
-}
-
-extern "C" int wtk_yolo_set_side_streams(wtk_yolo *h, int32_t n) {
-    if (!h || n < 0 || n > 2) return fail("wtk_yolo_set_side_streams: n must be 0, 1 or 2");
-    DEVICE_GUARD(h);
-    drop_graphs(h); // captured launches (host stream or a caller's) carry the old stream layout
-    h->side_streams = n;
-    h->use_side = n > 0;
-    return 0;
-}
-
-extern "C" int wtk_yolo_set_dynamic_batch(wtk_yolo *h, const int32_t *n_dev) {
-    if (!h) return fail("wtk_yolo_set_dynamic_batch: null handle");
-    h->n_dyn = n_dev;
-    if (!h->graphs.empty() || !h->seen_once.empty()) { // captured launches carry the old pointer
-        DEVICE_GUARD(h);
-        drop_graphs(h);
-    }
-    return 0;
-}
-
-extern "C" int wtk_yolo_margin_buffer(wtk_yolo *h, const float **margins_dev) {
-    if (!h || !margins_dev) return fail("wtk_yolo_margin_buffer: null argument");
-    *margins_dev = h->o_margin;
-    return 0;
-}
-
-extern "C" int wtk_yolo_last_margins_host(wtk_yolo *h, int32_t B, float *margins_host) {
-    if (!h || !margins_host || B <= 0 || B > h->max_batch) return fail("wtk_yolo_last_margins_host: bad argument");
-    DEVICE_GUARD(h);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(margins_host, h->o_margin, sizeof(float) * B, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-static void to_f32(const void *src, float *dst, size_t n, int is_f16) {
-    if (!is_f16) {
-        std::memcpy(dst, src, n * 4);
-        return;
-    }
-    const _Float16 *s = reinterpret_cast<const _Float16 *>(src);
-    for (size_t i = 0; i < n; ++i) dst[i] = (float)s[i];
-}
-
-extern "C" int wtk_yolo_debug_head(wtk_yolo *h, int32_t level, int32_t B, float *box_host, float *cls_host) {
-    if (!h || level < 0 || level > 2 || B <= 0 || B > h->max_batch) return fail("wtk_yolo_debug_head: bad argument");
-    DEVICE_GUARD(h);
-    HIP_TRY(hipDeviceSynchronize());
-    const size_t A = (size_t)h->lh[level] * h->lw[level];
-    if (box_host) {
-        const size_t n = (size_t)B * A * 64;
-        HIP_TRY(hipMemcpy(box_host, h->bufs[h->box_buf[level]].ptr, n * 4, hipMemcpyDeviceToHost)); // fp32 in both modes
-    }
-    if (cls_host) {
-        const size_t n = (size_t)B * A * h->cls_ld;
-        std::vector<float> full(n);
-        HIP_TRY(hipMemcpy(full.data(), h->bufs[h->cls_buf[level]].ptr, n * 4, hipMemcpyDeviceToHost)); // fp32 in both modes
-        for (size_t i = 0; i < (size_t)B * A; ++i)
-            for (int k = 0; k < h->dims.nc; ++k) cls_host[i * h->dims.nc + k] = full[i * h->cls_ld + k];
-    }
-    return 0;
-}
-
-extern "C" int wtk_yolo_debug_tensor(wtk_yolo *h, int32_t conv_index, int32_t B, float *out_host, size_t out_cap, int32_t *shape_hwc) {
-    if (!h || B <= 0 || B > h->max_batch) return fail("wtk_yolo_debug_tensor: bad argument");
-    const Op *op = nullptr;
-    for (const Op &o : h->ops)
-        if (o.spec == conv_index && o.out_buf >= 0) op = &o;
-    if (!op) return fail("wtk_yolo_debug_tensor: no op computes conv " + std::to_string(conv_index));
-    const Buf &b = h->bufs[op->out_buf];
-    if (shape_hwc) shape_hwc[0] = b.h, shape_hwc[1] = b.w, shape_hwc[2] = op->cout;
-    if (!out_host) return 0;
-    const size_t px = (size_t)B * b.h * b.w;
-    if (out_cap < px * op->cout) return fail("wtk_yolo_debug_tensor: output buffer too small");
-    DEVICE_GUARD(h);
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<char> tmp(px * b.C * (b.f32 ? 4 : h->esize));
-    HIP_TRY(hipMemcpy(tmp.data(), b.ptr, tmp.size(), hipMemcpyDeviceToHost));
-    std::vector<float> full(px * b.C);
-    if (h->split && !b.f32) {
-        const _Float16 *sp = reinterpret_cast<const _Float16 *>(tmp.data());
-        for (size_t i = 0; i < px; ++i)
-            for (int c = 0; c < b.C; ++c) {
-                const size_t o = i * 2 * b.C + 64 * (c >> 5) + (c & 31);
-                full[i * b.C + c] = (float)sp[o] + (float)sp[o + 32] * kSplitInv;
-            }
-    } else {
-        to_f32(tmp.data(), full.data(), full.size(), b.f32 ? 0 : h->is_f16);
-    }
-    const float unscale = op->act ? 1.0f / kActScale : 1.0f; // SiLU outputs are stored log2(e)-scaled
-    for (size_t i = 0; i < px; ++i)
-        for (int k = 0; k < op->cout; ++k) out_host[i * op->cout + k] = full[i * b.C + op->out_coff + k] * unscale;
-    return 0;
-}
-
-static int upload_head_logits(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B);
-
-extern "C" int wtk_yolo_decode_nms_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf, float iou,
-                                        int32_t max_det, float *out_xywh, float *out_conf, int32_t *out_cls, int32_t *out_anchor, int32_t *out_count) {
-    if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch || max_det < 1) return fail("wtk_yolo_decode_nms_host: bad argument");
-    DEVICE_GUARD(h);
-    HIP_TRY(hipDeviceSynchronize());
-    if (upload_head_logits(h, box_host, cls_host, B)) return 1;
-    if (ensure_nms_scratch(h, nullptr)) return 1;
-    const size_t rows = (size_t)B * max_det;
-    float *d_xywh = nullptr, *d_conf = nullptr;
-    int *d_cls = nullptr, *d_anchor = nullptr, *d_count = nullptr;
-    hipError_t e = hipSuccess;
-    if ((e = hipMalloc(&d_xywh, rows * 16)) != hipSuccess || (e = hipMalloc(&d_conf, rows * 4)) != hipSuccess || (e = hipMalloc(&d_cls, rows * 4)) != hipSuccess ||
-        (e = hipMalloc(&d_anchor, rows * 4)) != hipSuccess || (e = hipMalloc(&d_count, (size_t)B * 4)) != hipSuccess) {
-        (void)hipFree(d_xywh), (void)hipFree(d_conf), (void)hipFree(d_cls), (void)hipFree(d_anchor), (void)hipFree(d_count);
-        return fail_hip("wtk_yolo_decode_nms_host: hipMalloc", e);
-    }
-    const NmsOut nms{iou, max_det, d_cls, d_count};
-    int rc = run_head(h, B, H, W, conf, d_xywh, d_conf, d_anchor, nullptr, &nms);
-    if (!rc) {
-        if ((e = hipMemcpy(out_xywh, d_xywh, rows * 16, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("wtk_yolo_decode_nms_host: copy", e);
-        if (!rc && out_conf && (e = hipMemcpy(out_conf, d_conf, rows * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
-        if (!rc && out_cls && (e = hipMemcpy(out_cls, d_cls, rows * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
-        if (!rc && out_anchor && (e = hipMemcpy(out_anchor, d_anchor, rows * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
-        if (!rc && out_count && (e = hipMemcpy(out_count, d_count, (size_t)B * 4, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail_hip("copy", e);
-    }
-    (void)hipFree(d_xywh), (void)hipFree(d_conf), (void)hipFree(d_cls), (void)hipFree(d_anchor), (void)hipFree(d_count);
-    return rc;
-}
-
-extern "C" int wtk_yolo_decode_host(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B, int32_t H, int32_t W, float conf,
-                                    float *out_xywh, float *out_conf, int32_t *out_anchor) {
-    if (!h || !box_host || !cls_host || !out_xywh || B <= 0 || B > h->max_batch) return fail("wtk_yolo_decode_host: bad argument");
-    DEVICE_GUARD(h);
-    HIP_TRY(hipDeviceSynchronize());
-    if (upload_head_logits(h, box_host, cls_host, B)) return 1;
-    if (run_head(h, B, H, W, conf, h->o_xywh, h->o_conf, h->o_anchor, nullptr)) return 1;
-    HIP_TRY(hipMemcpy(out_xywh, h->o_xywh, sizeof(float) * 4 * B, hipMemcpyDeviceToHost));
-    if (out_conf) HIP_TRY(hipMemcpy(out_conf, h->o_conf, sizeof(float) * B, hipMemcpyDeviceToHost));
-    if (out_anchor) HIP_TRY(hipMemcpy(out_anchor, h->o_anchor, sizeof(int) * B, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-// scatter concatenated [B][A][.] fp32 logits into the per-level head buffers (storage dtype): the test hook behind the two
-// decode entry points
-static int upload_head_logits(wtk_yolo *h, const float *box_host, const float *cls_host, int32_t B) {
-    // scatter the concatenated [B][A][.] logits into the per-level head buffers (storage dtype)
-    const int A = h->anchors;
-    size_t a0 = 0;
-    for (int l = 0; l < 3; ++l) {
-        const size_t Al = (size_t)h->lh[l] * h->lw[l];
-        std::vector<float> bx((size_t)B * Al * 64), cl((size_t)B * Al * h->cls_ld, 0.f);
-        for (int n = 0; n < B; ++n)
-            for (size_t j = 0; j < Al; ++j) {
-                std::memcpy(&bx[((size_t)n * Al + j) * 64], &box_host[((size_t)n * A + a0 + j) * 64], 64 * sizeof(float));
-                for (int k = 0; k < h->dims.nc; ++k) cl[((size_t)n * Al + j) * h->cls_ld + k] = cls_host[((size_t)n * A + a0 + j) * h->dims.nc + k];
-            }
-        HIP_TRY(hipMemcpy(h->bufs[h->box_buf[l]].ptr, bx.data(), bx.size() * 4, hipMemcpyHostToDevice)); // fp32 in both modes
-        HIP_TRY(hipMemcpy(h->bufs[h->cls_buf[l]].ptr, cl.data(), cl.size() * 4, hipMemcpyHostToDevice));
-        a0 += Al;
-    }
-    return 0;
-}
-
-// =============================================================================================
-// Hybrid detector (include/wtk_hip.h, wtk_hybrid_*): a fast handle on every frame + a full-precision handle on the frames whose
-// decision margin is below a threshold, composed from the entry points above.  Host code only: every device step is one of the
-// library's own launches on the caller's stream.
-// =============================================================================================
-struct wtk_hybrid {
-    wtk_yolo *fast = nullptr, *exact = nullptr;
-    int device = 0;
-    float margin = 0.f;
-    int k = 0, defer = 1;
-    // device scratch: rows of the second look, slot list, counters
-    int32_t *slots = nullptr, *n_weak = nullptr, *overflow = nullptr, *replaced = nullptr, *anchor = nullptr;
-    float *xywh = nullptr, *conf = nullptr;
-    int32_t *pos_full = nullptr; // [k][2] view centre that makes a "view" the whole frame (immediate mode gathers weak frames through the views path)
-    int pos_h = -1, pos_w = -1;
-    int32_t *idx_tmp = nullptr, *pos_tmp = nullptr; // weak rows' (frame, view centre) of wtk_hybrid_predict_views
-    // deferred mode: queue of frame copies + output-row addresses
-    uint8_t *q_frames = nullptr;
-    int q_H = 0, q_W = 0, q_C = 0;
-    void **q_ptrs[3] = {nullptr, nullptr, nullptr};
-    int32_t *pos_scratch = nullptr;
-    int calls = 0;
-    float conf_thr = 0.1f;
-    bool held = false; // wtk_hybrid_hold: the full-precision handle is the caller's for a while
-    std::vector<void *> allocs;
-};
-
-static int hybrid_alloc(wtk_hybrid *h, void **p, size_t bytes) {
-    HIP_TRY(hipMalloc(p, bytes));
-    h->allocs.push_back(*p);
-    HIP_TRY(hipMemset(*p, 0, bytes));
-    return 0;
-}
-
-extern "C" void wtk_hybrid_destroy(wtk_hybrid *h) {
-    if (!h) return;
-    DeviceGuard guard(h->device);
-    (void)hipDeviceSynchronize();
-    if (h->exact) (void)wtk_yolo_set_dynamic_batch(h->exact, nullptr);
-    for (void *p : h->allocs) (void)hipFree(p);
-    if (h->q_frames) (void)hipFree(h->q_frames);
-    delete h;
-}
-
-extern "C" int wtk_hybrid_create(wtk_hybrid **out, wtk_yolo *fast, wtk_yolo *exact, float margin, int32_t k, int32_t defer) {
-    if (!out || !fast || !exact) return fail("wtk_hybrid_create: null argument");
-    if (fast == exact) return fail("wtk_hybrid_create: the fast and the full-precision handle must be two handles");
-    if (fast->device != exact->device) return fail("wtk_hybrid_create: both handles must live on the same device");
-    if (fast->S_h != exact->S_h || fast->S_w != exact->S_w || fast->anchors != exact->anchors)
-        return fail("wtk_hybrid_create: both handles must be the same model at the same network size");
-    if (exact->n_dyn) return fail("wtk_hybrid_create: the full-precision handle already takes its batch size from device memory (another hybrid object owns it, or wtk_yolo_set_dynamic_batch was called)");
-    if (defer < 1) return fail("wtk_hybrid_create: defer >= 1");
-    if (k == 0) k = defer > 1 ? exact->max_batch : std::min(fast->max_batch, exact->max_batch);
-    if (k < 1 || k > exact->max_batch) return fail("wtk_hybrid_create: 1 <= k <= max_batch of the full-precision handle");
-    if (!(margin >= 0.f)) return fail("wtk_hybrid_create: margin must be a non-negative number");
-    DEVICE_GUARD(fast);
-    wtk_hybrid *h = new wtk_hybrid();
-    h->fast = fast, h->exact = exact, h->device = fast->device, h->margin = margin, h->k = k, h->defer = defer;
-    const size_t K = (size_t)k;
-    int rc = hybrid_alloc(h, (void **)&h->slots, K * 4) || hybrid_alloc(h, (void **)&h->n_weak, 4) || hybrid_alloc(h, (void **)&h->overflow, 4) ||
-             hybrid_alloc(h, (void **)&h->replaced, 4) || hybrid_alloc(h, (void **)&h->xywh, K * 16) || hybrid_alloc(h, (void **)&h->conf, K * 4) ||
-             hybrid_alloc(h, (void **)&h->anchor, K * 4) || hybrid_alloc(h, (void **)&h->pos_full, K * 8) || hybrid_alloc(h, (void **)&h->idx_tmp, K * 4) ||
-             hybrid_alloc(h, (void **)&h->pos_tmp, K * 8);
-    if (!rc && defer > 1) {
-        for (int i = 0; i < 3 && !rc; ++i) rc = hybrid_alloc(h, (void **)&h->q_ptrs[i], K * sizeof(void *));
-        if (!rc) rc = hybrid_alloc(h, (void **)&h->pos_scratch, (size_t)std::max(fast->max_batch, 1) * 4);
-    }
-    if (rc) {
-        h->exact = nullptr; // nothing set on it yet
-        wtk_hybrid_destroy(h);
-        return 1;
-    }
-    if (wtk_yolo_set_dynamic_batch(exact, h->n_weak)) { // the second look costs what the weak rows cost
-        h->exact = nullptr;
-        wtk_hybrid_destroy(h);
-        return 1;
-    }
-    *out = h;
-    return 0;
-}
-
-extern "C" int wtk_hybrid_set_margin(wtk_hybrid *h, float margin) {
-    if (!h || !(margin >= 0.f)) return fail("wtk_hybrid_set_margin: bad argument");
-    h->margin = margin;
-    return 0;
-}
-
-extern "C" int wtk_hybrid_config(wtk_hybrid *h, int32_t *k, int32_t *defer, float *margin) {
-    if (!h) return fail("wtk_hybrid_config: null handle");
-    if (k) *k = h->k;
-    if (defer) *defer = h->defer;
-    if (margin) *margin = h->margin;
-    return 0;
-}
-
-extern "C" int wtk_hybrid_hold(wtk_hybrid *h, int32_t hold) {
-    if (!h) return fail("wtk_hybrid_hold: null handle");
-    if (h->defer > 1 && h->calls > 0) return fail("wtk_hybrid_hold: rows are pending (wtk_hybrid_flush first)");
-    if (wtk_yolo_set_dynamic_batch(h->exact, hold ? nullptr : h->n_weak)) return 1;
-    h->held = hold != 0;
-    return 0;
-}
-
-extern "C" int wtk_hybrid_pending(wtk_hybrid *h) { return h ? (h->defer > 1 ? h->calls : 0) : -1; }
-
-extern "C" int wtk_hybrid_flush(wtk_hybrid *h, void *stream) {
-    if (!h) return fail("wtk_hybrid_flush: null handle");
-    if (h->held) return fail("wtk_hybrid_flush: the full-precision handle is held by the caller (wtk_hybrid_hold)");
-    DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
-    if (h->defer <= 1 || !h->q_frames || h->calls == 0) return 0;
-    // the full-precision handle runs over the queue with its device-side dynamic batch = the queue's length; rows go back to the addresses queued with them
-    if (wtk_yolo_predict(h->exact, h->q_frames, h->k, h->q_H, h->q_W, h->q_C, h->conf_thr, 0.7f, 1, h->xywh, h->conf, h->anchor, stream)) return 1;
-    if (wtk_recheck_scatter(h->n_weak, h->k, h->xywh, h->conf, h->anchor, h->q_ptrs[0], h->q_ptrs[1], h->q_ptrs[2], h->replaced, stream)) return 1;
-    h->calls = 0;
-    return 0;
-}
-
-// the slot list of the immediate forms: the (up to kk) weakest rows of the fast pass just enqueued
-static int hybrid_select(wtk_hybrid *h, int B, int kk, void *stream) {
-    return wtk_recheck_select_counted(h->fast->o_margin, B, kk, h->margin, h->slots, h->n_weak, h->overflow, stream);
-}
-
-extern "C" int wtk_hybrid_predict(wtk_hybrid *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
-                                  float *out_conf, int32_t *out_anchor, void *stream) {
-    if (!h) return fail("wtk_hybrid_predict: null handle");
-    if (h->held) return fail("wtk_hybrid_predict: the full-precision handle is held by the caller (wtk_hybrid_hold)");
-    DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
-    const long long fb = (long long)H * W * C;
-    if (h->defer > 1) {
-        // every precondition of the deferred form is checked BEFORE the fast pass is enqueued: a call that fails must not have
-        // written fp16 rows that then never get their second look and are not counted in `overflow` either
-        if (!frames_dev || !out_xywh) return fail("wtk_hybrid_predict: null argument");
-        if (B <= 0 || B > 1024 || B > h->fast->max_batch) return fail("wtk_hybrid_predict (defer > 1): need 1 <= B <= min(1024, max_batch of the fast handle)");
-        if (fb <= 0 || fb % 16 || reinterpret_cast<uintptr_t>(frames_dev) % 16)
-            return fail("wtk_hybrid_predict (defer > 1): frames must be 16-byte aligned and a multiple of 16 bytes each");
-        if (reinterpret_cast<uintptr_t>(out_xywh) % 16) return fail("wtk_hybrid_predict (defer > 1): xywh rows must be 16-byte aligned");
-        // ... including the fast pass's own argument checks: a call it would reject must not fix the queue's frame shape for the object's life
-        if ((C != 1 && C != 3) || H <= 0 || W <= 0) return fail("wtk_hybrid_predict: frames must be H x W x 1 (gray) or H x W x 3 (BGR)");
-        if (h->q_frames && (h->q_H != H || h->q_W != W || h->q_C != C))
-            return fail("wtk_hybrid_predict (defer > 1): every call must bring frames of the same shape");
-        if (!h->q_frames) { // the queue's frame copies: allocated at the first call, for its frame shape
-            HIP_TRY(hipMalloc((void **)&h->q_frames, (size_t)h->k * (size_t)fb));
-            h->q_H = H, h->q_W = W, h->q_C = C;
-        }
-    }
-    if (wtk_yolo_predict(h->fast, frames_dev, B, H, W, C, conf, 0.7f, 1, out_xywh, out_conf, out_anchor, stream)) return 1;
-    if (h->defer > 1) {
-        if (wtk_recheck_enqueue(h->fast->o_margin, B, h->margin, frames_dev, fb, h->q_frames, h->k, h->n_weak, h->q_ptrs[0], h->q_ptrs[1], h->q_ptrs[2], out_xywh,
-                                out_conf, out_anchor, h->pos_scratch, h->overflow, stream))
-            return 1;
-        ++h->calls;
-        h->conf_thr = conf;
-        if (h->calls % h->defer == 0) return wtk_hybrid_flush(h, stream);
-        return 0;
-    }
-    const int kk = std::min(h->k, (int)B);
-    if (hybrid_select(h, B, kk, stream)) return 1;
-    if (h->pos_h != H || h->pos_w != W) {
-        // wtk_yolo_predict_views cuts frame[y0 : y0 + view_w, x0 : x0 + view_h] with (x0, y0) = pos - (view_w / 2, view_h / 2)
-        // (view_controller.py:158-172): the view (H, W) centred at (H / 2, W / 2) is the frame itself
-        std::vector<int32_t> p((size_t)h->k * 2);
-        for (int i = 0; i < h->k; ++i) p[2 * i] = H / 2, p[2 * i + 1] = W / 2;
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); // a pass enqueued earlier may still read the old centres
-        HIP_TRY(hipMemcpy(h->pos_full, p.data(), p.size() * 4, hipMemcpyHostToDevice));
-        h->pos_h = H, h->pos_w = W;
-    }
-    if (wtk_yolo_predict_views(h->exact, frames_dev, B, H, W, C, h->slots, h->pos_full, kk, H, W, conf, 0.7f, 1, h->xywh, h->conf, h->anchor, stream)) return 1;
-    return wtk_recheck_merge(h->fast->o_margin, h->slots, B, kk, h->margin, h->xywh, h->conf, h->anchor, out_xywh, out_conf, out_anchor, h->replaced, stream);
-}
-
-extern "C" int wtk_hybrid_predict_views(wtk_hybrid *h, const uint8_t *frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t C,
-                                        const int32_t *frame_index_dev, const int32_t *pos_xy_dev, int32_t B, int32_t view_w, int32_t view_h, float conf,
-                                        float *out_xywh, float *out_conf, int32_t *out_anchor, void *stream) {
-    if (!h) return fail("wtk_hybrid_predict_views: null handle");
-    if (h->defer > 1) return fail("wtk_hybrid_predict_views: the views entry point has no deferred form (create the object with defer = 1)");
-    if (h->held) return fail("wtk_hybrid_predict_views: the full-precision handle is held by the caller (wtk_hybrid_hold)");
-    DEVICE_GUARD(h); // the recheck launches below go to the CURRENT device
-    if (wtk_yolo_predict_views(h->fast, frames_dev, n_frames, H, W, C, frame_index_dev, pos_xy_dev, B, view_w, view_h, conf, 0.7f, 1, out_xywh, out_conf,
-                               out_anchor, stream))
-        return 1;
-    const int kk = std::min(h->k, (int)B);
-    if (hybrid_select(h, B, kk, stream)) return 1;
-    HIP_TRY(launch_recheck_gather_views(h->slots, kk, frame_index_dev, pos_xy_dev, h->idx_tmp, h->pos_tmp, (hipStream_t)stream));
-    if (wtk_yolo_predict_views(h->exact, frames_dev, n_frames, H, W, C, h->idx_tmp, h->pos_tmp, kk, view_w, view_h, conf, 0.7f, 1, h->xywh, h->conf, h->anchor,
-                               stream))
-        return 1;
-    return wtk_recheck_merge(h->fast->o_margin, h->slots, B, kk, h->margin, h->xywh, h->conf, h->anchor, out_xywh, out_conf, out_anchor, h->replaced, stream);
-}
-
-extern "C" int wtk_hybrid_counters(wtk_hybrid *h, int64_t *rows_replaced, int64_t *rows_overflowed) {
-    if (!h) return fail("wtk_hybrid_counters: null handle");
-    DEVICE_GUARD(h);
-    HIP_TRY(hipDeviceSynchronize());
-    int32_t r = 0, o = 0;
-    HIP_TRY(hipMemcpy(&r, h->replaced, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&o, h->overflow, 4, hipMemcpyDeviceToHost));
-    if (rows_replaced) *rows_replaced = r;
-    if (rows_overflowed) *rows_overflowed = o;
-    return 0;
-}

@@ -209,7 +209,7 @@ size_t conv_sk_partial_bytes(const ConvArgs &a, int split, int atoms = 0); // sc
 // tickets: conv_sk_ticket_count(a) zero-initialised counters of this op (the last block of a tile combines the slabs in-kernel), or null (second launch: sk_finish_kernel)
 size_t conv_sk_ticket_count(long long M, int cout_pad);
 hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t stream); // atoms = 0: conv_sk_slices(nk)
-// ... and up to kSkGroupMax such convs that do not depend on each other as ONE launch (the latency plan's dependency levels, csrc/wtk_api.hip: sk_schedule).
+// ... and up to kSkGroupMax such convs that do not depend on each other as ONE launch (the latency plan's dependency levels, csrc/wtk_plan.hip: sk_schedule).
 // force_tile 0..3 / force_form 0 (one block per atom), 1 (one block walks all atoms): test hooks, -1 = the cost model decides.  Bit-identical to n launches.
 constexpr int kSkGroupMax = 4;
 struct SkMember {
