@@ -335,6 +335,35 @@ static void hybrid_and_misc() {
     }
 }
 
+// The latency plan's launch schedule (csrc/wtk_plan.hip: sk_schedule): one frame of YOLOv8s is 48 dependency levels — the fused front, 45 levels of split-K
+// convs (a Detect tower's box and class convs, a PAN layer and the tower of the feature map before it share a level), the pool, the head — on ONE stream.
+static void schedule_shape() {
+    std::fprintf(stderr, "[hostsan] latency-plan schedule\n");
+    const Model m = make_model(kScales[1], 1, 9);
+    void *st = nullptr;
+    hipStreamCreateWithFlags(&st, 1);
+    wtk_yolo *h = create(m, 384, 384, 4, WTK_F16X3, WTK_PLAN_LATENCY);
+    if (!h) return;
+    DevBufs d;
+    d.alloc((size_t)4 * 384 * 384, 4, 1);
+    const int streams_before = stub_live_streams();
+    auto count = [&](const char *k) { return stub_kernel_launches(k); };
+    const unsigned long long sk0 = count("conv_sk_kernel"), fr0 = count("front_fused"), po0 = count("sppf_pool"), he0 = count("head_select"), all0 = count(nullptr), fin0 = count("sk_finish");
+    CHECK(wtk_yolo_predict(h, (const uint8_t *)d.frames, 1, 384, 384, 1, 0.1f, 0.7f, 1, (float *)d.xywh, (float *)d.conf, (int32_t *)d.anchor, st) == 0, "predict");
+    const unsigned long long sk = count("conv_sk_kernel") - sk0, fin = count("sk_finish") - fin0, all = count(nullptr) - all0;
+    const bool grouped = !(std::getenv("WTK_SK_GROUP") && std::getenv("WTK_SK_GROUP")[0] == '0');
+    if (grouped) {
+        CHECK(sk == 45, "%llu grouped split-K launches per frame, expected 45 levels", sk);
+        CHECK(all == 48 + fin, "%llu launches per frame, expected 48 levels + %llu second-launch combinations", all, fin);
+    } else {
+        CHECK(sk == 57, "%llu split-K launches per frame without grouping, expected one per conv op behind the front (57: 63 convs, 3 in the front, 3 x 2 Detect first convs as 3 ops)", sk);
+    }
+    CHECK(count("front_fused") - fr0 == 1 && count("sppf_pool") - po0 == 1 && count("head_select") - he0 == 1, "front / pool / head once each");
+    CHECK(stub_live_streams() == streams_before, "a latency-plan forward created %d stream(s): it must run on the caller's stream alone", stub_live_streams() - streams_before);
+    wtk_yolo_destroy(h);
+    d.release();
+}
+
 // two host threads, a handle each, both capturing through the process-wide pair of side streams (ctypes releases the GIL: TrackPipeline lanes)
 static void two_threads() {
     std::fprintf(stderr, "[hostsan] two host threads\n");
@@ -465,6 +494,7 @@ int main(int argc, char **argv) {
     }
     run_matrix("shape matrix", cases, 3);
     hybrid_and_misc();
+    schedule_shape();
     two_threads();
     const int v = stub_violations();
     std::fprintf(stderr, "[hostsan] kernels launched: %llu (conv_sk %llu, window %llu, igemm %llu, front %llu, head %llu); peak device memory %.1f GB; violations %d; driver failures %d\n",

@@ -34,7 +34,8 @@ def test_launch_layer_flags_deliberate_violations():
     {"WTK_GRAPH": "1"},  # replayed captures on (host entry points and caller buffers), forked through the shared side streams
     # the GPU suite's environment (tests/conftest.py) + captures: the configuration of both round-5 crashes
     {"WTK_LATENCY_PLAN": "0", "WTK_NO_SK_MIXED": "1", "WTK_SMALL_NARROW": "0", "WTK_GRAPH": "1"},
-], ids=["default", "graphs", "suite-env-graphs"])
+    {"WTK_SK_GROUP": "0"},  # the latency plan as one launch per conv (the bit-identity reference of the grouped launches)
+], ids=["default", "graphs", "suite-env-graphs", "ungrouped"])
 def test_host_side_is_clean_over_the_shape_matrix(env):
     r = hostsan.run("quick", env)
     _ok(r)
