@@ -619,6 +619,40 @@ def test_fused_view_crop_letterbox_matches_oracle_views(hip_lib, frame_shape, ca
         det.predict_views(torch.from_numpy(frames).cuda(), len(frames), H, W, C, None, torch.from_numpy(pos).cuda(), 9, cam[0], cam[1], out)
 
 
+def test_views_call_is_ordered_behind_writes_pending_on_the_callers_stream(hip_lib, tmp_path):
+    """A caller may refill `device_frames` in place between cycles: its writes sit on ITS current stream, the controller launches on a stream of its own.
+    The call is ordered behind the caller's stream whenever that stream has work pending (an idle stream is not waited for: nothing to be ordered
+    behind).  Here the refill is queued behind ~20 ms of matmuls on the current stream and the views call follows at once: the rows must be those of
+    the NEW frames."""
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig
+
+    w = ys.synthetic_weights("n", 1, seed=0)
+    path = str(tmp_path / "n.wtk")
+    ys.save_weights(path, w, "n", 1)
+    old, _ = fr.synthetic_frames(6, 256, seed=8)
+    new, _ = fr.synthetic_frames(6, 256, seed=9)
+    ec = ExperimentConfig("synthetic", 6, 60, (256, 256), 32, (128, 128))
+    tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.5, 0.5))
+    cfg = YoloConfig(model_path=path, device="cuda", pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="fp32", scale="n", max_batch=16)
+    entries = [(i, 100 + 9 * i, 120 + 5 * i, (128, 128)) for i in range(6)]
+    want_new = HipYoloController(tc, cfg, device_frames=torch.from_numpy(new).cuda()).predict_views(entries)
+    want_old = HipYoloController(tc, cfg, device_frames=torch.from_numpy(old).cuda()).predict_views(entries)
+    assert not np.array_equal(np.nan_to_num(want_new), np.nan_to_num(want_old))
+    dev = torch.from_numpy(old).cuda()
+    ctrl = HipYoloController(tc, cfg, device_frames=dev)
+    np.testing.assert_array_equal(ctrl.predict_views(entries), want_old)  # (buffers, streams and handles exist now: the next call starts at once)
+    fresh = torch.from_numpy(new).cuda()
+    a = torch.randn((4096, 4096), device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(40):  # keeps the current stream busy for tens of milliseconds ...
+        a = a @ a * 1e-3
+    dev.copy_(fresh)  # ... with the refill queued behind it
+    got = ctrl.predict_views(entries)
+    np.testing.assert_array_equal(got, want_new)
+    del a
+
+
 def test_converted_unfused_checkpoint_runs_on_device(hip_lib, tmp_path):
     """SURVEY.md §8 f3 end to end: a synthetic UN-FUSED ultralytics-style state dict (Conv2d + BatchNorm2d eps 1e-3 per Conv,
     plain Conv2d + bias for the Detect outputs, OIHW) -> tools/convert_ultralytics.py -> WTKYOLO1 file -> YoloConfig /

@@ -514,9 +514,13 @@ class HipYoloController(SimController):
             # the handle's sticky status word now holds THAT call's flags: they go into its token before this call can raise its own (a flag is
             # reported by the call that caused it, whichever lane collects first)
             busy["flags"] = det.status(clear=True)
-        # EVERY call is ordered behind the caller's current stream (an event wait, microseconds): a caller that refills or extends `device_frames` in
-        # place between cycles has its writes on that stream, and the crop / letterbox kernel must not read frames that are still being written
-        stream.wait_stream(torch.cuda.current_stream(dev))
+        # EVERY call is ordered behind the caller's current stream: a caller that refills or extends `device_frames` in place between cycles has its
+        # writes on that stream, and the crop / letterbox kernel must not read frames that are still being written.  The order costs an event record +
+        # wait (~90 us of host time in front of the first launch when the current stream is the legacy default stream: cProfile, round 6) only when
+        # that stream HAS work pending — an idle stream (hipStreamQuery: microseconds) has nothing to be ordered behind.
+        cur = torch.cuda.current_stream(dev)
+        if os.environ.get("WTK_CTRL_ALWAYS_WAIT") == "1" or not cur.query():
+            stream.wait_stream(cur)
         bufs = self._view_bufs.get((lane, n))
         if bufs is None:
             bufs = self._view_bufs[(lane, n)] = dict(meta=torch.empty((3 * n,), dtype=torch.int32, device=dev), host=torch.empty((3 * n,), dtype=torch.int32).pin_memory(),
