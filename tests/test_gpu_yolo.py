@@ -653,6 +653,33 @@ def test_views_call_is_ordered_behind_writes_pending_on_the_callers_stream(hip_l
     del a
 
 
+def test_a_handle_replaced_by_a_larger_one_stays_valid_for_the_call_still_in_flight(hip_lib, tmp_path):
+    """a call launched on lane 1 (the deferred cycle batch) names its detector handle in its token.  When a later, larger call makes the
+    controller replace that handle (capacity 16 -> 64), the device drains first and the old handle stays readable until its tokens are collected:
+    the token's rows are the rows an undisturbed call returns."""
+    from wtracker_amd.controllers import HipYoloController, YoloConfig
+    from wtracker_amd.sim import ExperimentConfig, TimingConfig
+
+    w = ys.synthetic_weights("n", 1, seed=0)
+    path = str(tmp_path / "n.wtk")
+    ys.save_weights(path, w, "n", 1)
+    frames, _ = fr.synthetic_frames(48, 256, seed=21)
+    dev = torch.from_numpy(frames).cuda()
+    ec = ExperimentConfig("synthetic", 48, 60, (256, 256), 32, (128, 128))
+    tc = TimingConfig(ec, 100, 40, 50, (4, 4), (0.5, 0.5))
+    cfg = YoloConfig(model_path=path, device="cuda", pred_kwargs={"imgsz": 128, "conf": 0.1}, dtype="fp32", scale="n", max_batch=64)
+    ent = lambda n: [(i, 100 + 3 * i, 120 + 2 * i, (128, 128)) for i in range(n)]
+    want15 = HipYoloController(tc, cfg, device_frames=dev).predict_views(ent(15))
+    cfg.model = None
+    ctrl = HipYoloController(tc, cfg, device_frames=dev)
+    token = ctrl.launch_views(ent(15), lane=1)  # throughput-plan handle of 16 frames
+    small = token["det"]
+    got40 = ctrl.predict_views(ent(40))  # same key, larger batch: the 16-frame handle is replaced by one of 64
+    assert ctrl._model.detector((128, 128), 15) is not small and small in ctrl._model._retired
+    np.testing.assert_array_equal(ctrl.collect_views(token), want15)
+    np.testing.assert_array_equal(got40[:15], want15)  # (batch invariance across the two handles of one plan: same kernels, same K order)
+
+
 def test_converted_unfused_checkpoint_runs_on_device(hip_lib, tmp_path):
     """SURVEY.md §8 f3 end to end: a synthetic UN-FUSED ultralytics-style state dict (Conv2d + BatchNorm2d eps 1e-3 per Conv,
     plain Conv2d + bias for the Detect outputs, OIHW) -> tools/convert_ultralytics.py -> WTKYOLO1 file -> YoloConfig /
