@@ -332,6 +332,43 @@ def test_opt_in_forked_capture_on_a_large_handle_equals_eager(hip_lib, monkeypat
     graph.close(), eager.close()
 
 
+def test_two_host_threads_a_handle_each(hip_lib):
+    """README, "Threads": handles driven from different host threads (ctypes releases the GIL) are safe.  Two threads, a handle each — one latency-plan
+    handle (one stream, grouped launches), one handle of 32 frames (side streams, shared process-wide, under the library's lock) — run interleaved
+    calls; every call's rows and head logits equal the ones the same handle produced alone."""
+    import threading
+
+    size = 256
+    frames = fr.diverse_frames(8, size, seed=31)
+    w = ys.synthetic_weights("s", 1, seed=0)
+    depth, width, maxch = ys.SCALES["s"]
+    dets = [hip.HipYolo(w, (size, size), 4, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch, plan="latency"),
+            hip.HipYolo(w, (size, size), 32, dtype="f16x3", nc=1, width=width, depth=depth, max_channels=maxch, plan="throughput")]
+    batches = [[frames[i % 8 : i % 8 + 1] for i in range(12)], [frames[: 1 + i % 8] for i in range(12)]]
+    alone = [[d.predict_host(b, conf=0.1) for b in bs] for d, bs in zip(dets, batches)]
+    got, errs = [[], []], []
+
+    def work(k):
+        try:
+            for b in batches[k]:
+                got[k].append(dets[k].predict_host(b, conf=0.1))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for k in range(2):
+        assert len(got[k]) == len(alone[k])
+        for (xa, ca, aa), (xg, cg, ag) in zip(alone[k], got[k]):
+            np.testing.assert_array_equal(ag, aa)
+            np.testing.assert_array_equal(xg, xa)
+            np.testing.assert_array_equal(cg, ca)
+    for d in dets:
+        d.close()
+
+
 def test_dynamic_batch_on_a_latency_handle(hip_lib):
     size, B = 128, 8
     _, det, _ = _handle(size, "f16x3")
