@@ -141,6 +141,8 @@ void wtk_yolo_destroy(wtk_yolo *h);
  *   WTK_PLAN_AUTO        (= wtk_yolo_create) latency when max_batch <= 4 and the dtype allows it, else throughput (measured on MI355X at imgsz 384:
  *                        B = 1 0.51 ms against 0.67-1.00 ms on the throughput plan, B = 15 1.5 ms against 1.1 ms — the cross-over lies near B = 6); the
  *                        environment variable WTK_LATENCY_PLAN=0 / 1 overrides AUTO only.
+ * The first eager call of a latency-plan handle at a batch size also TIMES its launch choices (every grouped launch's tile / form candidates, inside the real
+ * forward pass: ~0.1 s once; WTK_SK_AUTOTUNE=0 keeps the cost model's); the choice changes no result bit.
  * Launches are eager.  Replaying a captured hipGraph of the forward pass is opt-in (environment WTK_GRAPH=1, read when the handle is created): the
  * throughput plan's capture forks into the library's side streams, and the runtime's handling of such graphs is where round 5's two open problems
  * lived (profiles/r06_notes.md section 1).

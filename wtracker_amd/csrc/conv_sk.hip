@@ -726,6 +726,52 @@ hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus
     return sk_launch_chosen(g, m, n, ch.tile, ch.S, split, st);
 }
 
+// Every (tile, forms) a launch of these members can run as — out[0] = the cost model's choice, then the others — for the handle's autotune pass
+// (csrc/wtk_run.hip: sk_autotune): the model is calibrated on a few layers, the timer is not.  Test hooks and chip-filling members leave the one choice.
+int conv_sk_enumerate(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, SkChoice *out, int cap) {
+    if (n < 1 || n > kSkGroupMax || cap < 1) return 0;
+    SkGroupArgs g;
+    SkShape shapes[kSkGroupMax];
+    bool big = false;
+    for (int i = 0; i < n; ++i) {
+        if (sk_fill(g.p[i], m[i], split) != hipSuccess) return 0;
+        shapes[i] = {g.p[i].M, g.p[i].CoutPad, g.p[i].nk, g.p[i].NA};
+        big = big || shapes[i].M > 16384;
+    }
+    SkChoice &c0 = out[0];
+    c0 = SkChoice();
+    c0.est_us = sk_choose(shapes, n, num_cus, split, force_tile, force_form, &c0.tile, c0.S);
+    c0.valid = 1;
+    if (big) { // (launch_conv_sk_group's rule: the members' own launches)
+        c0.separate = n > 1;
+        for (int i = 0; i < n; ++i) {
+            int s1[kSkGroupMax];
+            (void)sk_choose(&shapes[i], 1, num_cus, split, force_tile, force_form, &c0.m_tile[i], s1);
+            c0.m_S[i] = s1[0];
+        }
+        return 1;
+    }
+    int cnt = 1;
+    if (force_tile >= 0 || force_form >= 0) return cnt;
+    for (int ti = 0; ti < 4; ++ti) {
+        bool fits = true;
+        for (int i = 0; i < n; ++i) fits = fits && shapes[i].cout_pad % kSkTiles[ti].bn == 0;
+        if (!fits) continue;
+        for (int combo = 0; combo < (1 << n) && cnt < cap; ++combo) {
+            SkChoice c;
+            c.valid = 1, c.tile = ti;
+            bool ok = true, same = ti == c0.tile;
+            for (int i = 0; i < n; ++i) {
+                c.S[i] = (combo >> i) & 1 ? 1 : shapes[i].NA;
+                if (shapes[i].NA == 1 && ((combo >> i) & 1) == 0) ok = false; // (one atom: both forms are the same launch)
+                same = same && c.S[i] == c0.S[i];
+            }
+            if (ok && !same) out[cnt++] = c;
+        }
+    }
+    return cnt;
+}
+
 hipError_t launch_conv_sk(const ConvArgs &a, int split, int atoms, float *partial, unsigned *tickets, int num_cus, hipStream_t st) {
     const SkMember m{a, atoms, partial, tickets};
     return launch_conv_sk_group(&m, 1, split, num_cus, -1, -1, st, nullptr);

@@ -170,6 +170,15 @@ struct wtk_yolo {
     int sk_group = 1;                      // WTK_SK_GROUP=0: one launch per conv, in op order (test hook: the grouped launches must give the same bits)
     int sk_force_tile = -1, sk_force_form = -1; // WTK_SK_TILE / WTK_SK_FORM, read when the handle is created (test hooks: every tile and form gives the same bits)
     std::map<long long, wtk::SkChoice> sk_choices; // (launch or op, batch) -> what the split-K cost model chose (it runs once per key, not per call)
+    // autotune of the latency plan (wtk_run.hip: sk_autotune): the first eager call at a batch size times every (tile, forms) candidate of every launch inside the
+    // real forward pass and keeps the fastest; neither enters the arithmetic.  WTK_SK_AUTOTUNE=0: the cost model's choice.
+    int sk_autotune = 1;
+    int tune_pass = -1;                                     // >= 0: a timing pass is being enqueued (candidate = pass % candidates of the launch)
+    std::map<long long, std::vector<wtk::SkChoice>> sk_cands; // (launch, batch) -> candidates, [0] = the cost model's
+    std::map<long long, std::vector<float>> tune_ms;         // ... and the best time seen of each
+    std::vector<hipEvent_t> tune_ev;                        // two per launch of lat_sched
+    std::vector<long long> tune_key;                        // key of the launch timed through tune_ev[2 i], [2 i + 1] in this pass (-1: none)
+    std::vector<int> sk_tuned;                              // batch sizes that have been tuned
     std::vector<std::vector<int>> lat_sched; // launches behind ops[0..2] in order: one op, or up to kSkGroupMax split-K ops that do not depend on each other
     int small_narrow = 0; // a small handle (max_batch <= 16, f16x3) runs window / implicit-GEMM layers whose grid leaves most CUs idle on 64-cout tiles (WTK_SMALL_NARROW=0: off)
     int halo_deep = 0;    // f16x3: the 64-cout x 128-pixel window tiles on the six-slab ring (small handles; WTK_HALO_DEEP)

@@ -228,6 +228,8 @@ struct SkChoice {
     double est_us = 0.0;
 };
 hipError_t launch_conv_sk_group(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, hipStream_t stream, struct SkChoice *choice);
+constexpr int kSkMaxCandidates = 4 * (1 << kSkGroupMax); // tiles x forms of a launch
+int conv_sk_enumerate(const SkMember *m, int n, int split, int num_cus, int force_tile, int force_form, SkChoice *out, int cap);
 // the kernel's view of one conv and of a grouped launch (here, not in conv_sk.hip, so that the host-side launch checker of tests/hostsan can read them)
 struct SkArgs {
     const char *in;  // input tensor (slice view): byte pitch per pixel, byte offset of the first channel

@@ -466,6 +466,7 @@ extern "C" void wtk_yolo_destroy(wtk_yolo *h) {
     (void)hipDeviceSynchronize();
     drop_graphs(h);
     for (int i = 0; i < h->ev_created; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->tune_ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i)
         if (h->feat_ev[i]) (void)hipEventDestroy(h->feat_ev[i]);
     for (int i = 0; i < wtk_yolo::kSideStreams; ++i) {
@@ -809,6 +810,7 @@ extern "C" int wtk_yolo_create_planned(wtk_yolo **out, const wtk_yolo_desc *d, i
         }
     }
     if (const char *e = std::getenv("WTK_SK_GROUP")) h->sk_group = e[0] != '0';
+    if (const char *e = std::getenv("WTK_SK_AUTOTUNE")) h->sk_autotune = e[0] != '0';
     if (const char *e = std::getenv("WTK_SK_TILE")) h->sk_force_tile = std::atoi(e) >= 0 && std::atoi(e) <= 3 ? std::atoi(e) : -1;
     if (const char *e = std::getenv("WTK_SK_FORM")) h->sk_force_form = std::atoi(e) == 0 || std::atoi(e) == 1 ? std::atoi(e) : -1;
     sk_schedule(h);

@@ -127,8 +127,8 @@ struct ViewSrc {
     const int32_t *pos_xy, *frame_index;
     int view_w, view_h, n_frames;
 };
-static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
-                        float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr, const NmsOut *nms = nullptr) {
+static int yolo_enqueue_pass(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh,
+                             float *out_conf, int32_t *out_anchor, hipStream_t st, const ViewSrc *vs, const NmsOut *nms) {
     const uint8_t *net_in = frames_dev;
     if (vs) {
         ViewLetterboxArgs va;
@@ -483,7 +483,7 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
             if (run_op(oi)) return 1;
         for (size_t li = 0; li < h->lat_sched.size(); ++li) {
             const std::vector<int> &L = h->lat_sched[li];
-            if (L.size() == 1) {
+            if (!(h->ops[L[0]].kind == OP_CONV && h->ops[L[0]].sk)) { // (the pool, or a conv that does not fit the split-K kernel: one op, its own launch)
                 if (run_op((size_t)L[0])) return 1;
                 continue;
             }
@@ -496,7 +496,23 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
                 if (!conv_sk_eligible(m[k].a, h->split)) return fail("internal: conv " + std::to_string(L[k]) + " of the latency plan does not fit conv_sk_kernel");
                 flops[1] += op_flops(op);
             }
-            HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st, &h->sk_choices[((long long)li << 24) | (long long)B]));
+            const long long key = ((long long)li << 24) | (long long)B;
+            if (h->tune_pass >= 0) { // a timing pass of sk_autotune: this launch as its candidate number (pass mod candidates), between two events
+                std::vector<SkChoice> &cands = h->sk_cands[key];
+                if (cands.empty()) {
+                    cands.resize(kSkMaxCandidates);
+                    cands.resize((size_t)std::max(conv_sk_enumerate(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, cands.data(), kSkMaxCandidates), 0));
+                    if (cands.empty()) return fail("internal: no launch candidate for level " + std::to_string(li));
+                    h->tune_ms[key].assign(cands.size(), 1e30f);
+                }
+                SkChoice c = cands[(size_t)h->tune_pass % cands.size()];
+                HIP_TRY(hipEventRecord(h->tune_ev[2 * li], main_st));
+                HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st, &c));
+                HIP_TRY(hipEventRecord(h->tune_ev[2 * li + 1], main_st));
+                h->tune_key[li] = key;
+            } else {
+                HIP_TRY(launch_conv_sk_group(m, (int)L.size(), h->split, h->num_cus, h->sk_force_tile, h->sk_force_form, main_st, &h->sk_choices[key]));
+            }
             ++launches[1];
         }
     } else {
@@ -527,6 +543,69 @@ static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32
         for (int i = 0; i < wtk_yolo::kProfKernels; ++i) h->prof_launches[i] += launches[i], h->prof_flops[i] += flops[i];
     }
     return 0;
+}
+
+// Autotune of a latency-plan handle: the first EAGER forward pass at a batch size is preceded by timing passes — the same forward pass (real frames, real
+// activations), every grouped launch between two events, launch i running its candidate number (pass mod candidates_i) — and every launch keeps the
+// (tile, forms) that took the least time.  The cost model that otherwise decides is calibrated on a few layers of one network at one size; the choice
+// enters no arithmetic (tests/test_gpu_latency.py: every tile and form gives the same bits), so timing noise can cost microseconds, never results.
+static int sk_autotune(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh, float *out_conf,
+                       int32_t *out_anchor, hipStream_t st, const ViewSrc *vs, const NmsOut *nms) {
+    const size_t n = h->lat_sched.size();
+    while (h->tune_ev.size() < 2 * n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->tune_ev.push_back(e);
+    }
+    h->tune_key.assign(n, -1);
+    constexpr int kReps = 3;
+    size_t most = 1;
+    int rc = 0;
+    for (size_t pass = 0; pass < most * kReps && !rc; ++pass) {
+        h->tune_pass = (int)pass;
+        rc = yolo_enqueue_pass(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, vs, nms);
+        h->tune_pass = -1;
+        if (rc) break;
+        if (hipStreamSynchronize(st) != hipSuccess) {
+            rc = fail("sk_autotune: hipStreamSynchronize failed");
+            break;
+        }
+        for (size_t li = 0; li < n; ++li) {
+            const long long key = h->tune_key[li];
+            if (key < 0) continue;
+            const std::vector<SkChoice> &cands = h->sk_cands[key];
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->tune_ev[2 * li], h->tune_ev[2 * li + 1]) != hipSuccess) continue;
+            float &best = h->tune_ms[key][pass % cands.size()];
+            best = std::min(best, ms);
+            most = std::max(most, cands.size());
+        }
+    }
+    if (rc) return rc;
+    for (size_t li = 0; li < n; ++li) {
+        const long long key = h->tune_key[li];
+        if (key < 0) continue;
+        const std::vector<SkChoice> &cands = h->sk_cands[key];
+        const std::vector<float> &ms = h->tune_ms[key];
+        size_t b = 0;
+        for (size_t i = 1; i < cands.size(); ++i)
+            if (ms[i] < ms[b] * 0.97f) b = i; // (the model's choice unless another is clearly faster)
+        h->sk_choices[key] = cands[b];
+    }
+    h->sk_tuned.push_back(B);
+    return 0;
+}
+
+static int yolo_enqueue(wtk_yolo *h, const uint8_t *frames_dev, int32_t B, int32_t H, int32_t W, int32_t C, float conf, float *out_xywh, float *out_conf,
+                        int32_t *out_anchor, hipStream_t st, const ViewSrc *vs = nullptr, const NmsOut *nms = nullptr) {
+    if (h->latency && h->sk_group && h->sk_autotune && !h->lat_sched.empty() && !h->profiling && h->tune_pass < 0 &&
+        std::find(h->sk_tuned.begin(), h->sk_tuned.end(), (int)B) == h->sk_tuned.end()) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) { // (a capture cannot be timed: it keeps the cost model's choices)
+            if (sk_autotune(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, vs, nms)) return 1;
+        }
+    }
+    return yolo_enqueue_pass(h, frames_dev, B, H, W, C, conf, out_xywh, out_conf, out_anchor, st, vs, nms);
 }
 
 // Captured launches carry the stream layout / dynamic-batch pointer they were captured with: drop them all.  Each exec is destroyed only after its last
