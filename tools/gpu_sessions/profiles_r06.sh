@@ -28,5 +28,9 @@ ls $R/gpurun_out | grep r6pf_ | head -40
 # 6. BASELINE config 5's per-GPU shape (1280 x 1280, fp16, batch 256): the bench line and its MFMA-busy PMC pass
 cd $R && timeout -k 10 500 python3 bench.py --size 1280 --batch 256 --dtype fp16 --steps 4 --warmup 1 --repeats 3 --no-fp32 --cpu-frames 0 --no-closed-loop --no-latency > gpurun_out/r6pf_bench_1280_b256.out 2> gpurun_out/r6pf_bench_1280_b256.err; echo "1280 bench rc $?"; tail -c 600 gpurun_out/r6pf_bench_1280_b256.out
 cd /tmp && WTK_NO_SIDE_STREAM=1 timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/r6pf_mfma_1280 -o p -- python3 $R/bench.py --size 1280 --batch 256 --dtype fp16 --steps 1 --warmup 1 --repeats 1 --lanes 1 --no-profile --no-fp32 --cpu-frames 0 --no-check --no-closed-loop --no-latency > $R/gpurun_out/r6pf_mfma_1280.log 2>&1 || echo "mfma 1280 failed"
-# 7. the default bench line on the same box
-cd $R && timeout -k 10 600 python3 bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err; echo "default bench rc $?"; tail -c 400 gpurun_out/bench_default.log
+# 7. the artefacts are rebuilt ON the box (so that the bench line that follows quotes this session's PMC files: provenance = these sources), then the default
+#    bench line, then the artefacts again (with the line) into gpurun_out/profiles_r06/ for the way back
+cd $R && bash tools/refresh_profiles_r06.sh > gpurun_out/r6pf_refresh.log 2>&1; echo "refresh rc $?"
+timeout -k 10 600 python3 bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err; echo "default bench rc $?"; tail -c 400 gpurun_out/bench_default.log
+bash tools/refresh_profiles_r06.sh >> gpurun_out/r6pf_refresh.log 2>&1
+mkdir -p gpurun_out/profiles_r06 && cp profiles/r06_* gpurun_out/profiles_r06/ && ls gpurun_out/profiles_r06 | wc -l
