@@ -1616,18 +1616,9 @@ hipError_t launch_ws64(HaloArgs a, int num_cus, hipStream_t stream) {
     const long long want = (tiles + 1) / 2;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     a.grid = (int)grid;
-    // woven epilogue: needs SiLU (the woven pieces have no activation switch) and 32-bit store offsets; a.bm carries the number of woven pixel tiles
-    // (0: the round-2 schedule) outside the ablation builds
-    const bool can_weave = a.act && (long long)a.N * a.H * a.W * a.out_ld * 2 < 0xe0000000LL; // (kOutRange of the kernel)
-#ifdef WTK_WS64_STAMPS
-    const int nwv = 0;
-#else
-    const int nwv = can_weave ? a.bm : 0;
-#endif
-    if (nwv == 1) hipLaunchKernelGGL(conv3x3_ws64_kernel<1>, dim3(grid), dim3(512), 0, stream, a);
-    else if (nwv == 2) hipLaunchKernelGGL(conv3x3_ws64_kernel<2>, dim3(grid), dim3(512), 0, stream, a);
-    else if (nwv == 3) hipLaunchKernelGGL(conv3x3_ws64_kernel<3>, dim3(grid), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(conv3x3_ws64_kernel<0>, dim3(grid), dim3(512), 0, stream, a);
+    // (the woven-epilogue schedules of round 3 — NWV = 1 .. 3 pixel tiles of a wave's four riding on the next multiply phase — measured no gain and are no
+    // longer instantiated: NWV = 0 is round 2's schedule)
+    hipLaunchKernelGGL(conv3x3_ws64_kernel<0>, dim3(grid), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1946,7 +1937,7 @@ int split_halo_cout_tile(int cout_stored) { return cout_stored % 128 == 0 ? 128 
 
 // Every channel count / offset of `a` but Cout / CoutPad in pseudo-channels (2 x real); three weight slabs, one tile per block
 hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
-    const int bn = ((a.narrow || a.two_per_cu) && !a.tail_w) ? 64 : split_halo_cout_tile(a.Cout);
+    const int bn = (a.narrow && !a.tail_w) ? 64 : split_halo_cout_tile(a.Cout);
     if (a.Cin % 64 != 0 || a.CoutPad % bn != 0 || a.Cout != a.CoutPad || a.slabs == 2) return hipErrorInvalidValue;
     // fused 1x1 tail: 64 -> 64 couts (box towers), split weights [64][tail_kpad = 128 pseudo-channels]; 128 -> <= 32 stored couts with fp32 output
     // (class towers), split weights [32][tail_kpad = 256 pseudo-channels]
@@ -1961,10 +1952,6 @@ hipError_t launch_conv3x3_halo_split(const HaloArgs &a, hipStream_t stream) {
     if ((long long)a.blocks_per_strip * bm < (long long)a.N * (a.H + 1) * a.pitch) return hipErrorInvalidValue;
     if (a.res && (a.res_ld % 64 || a.res_coff % 64)) return hipErrorInvalidValue;
     if (a.out2 && (a.out2_ld % 64 || a.out2_coff % 64)) return hipErrorInvalidValue;
-    if (a.two_per_cu && !a.tail_w) { // 64 couts x 128 pixels, one window buffer, 78 KB of LDS and <= 128 VGPRs: two blocks per CU
-        if (bm != 128) return hipErrorInvalidValue;
-        return launch_h<_Float16, 64, 1, 4, 3, kHaloRowsMax, 128, false, true>(a, stream);
-    }
     if (bn == 128 && a.tail_w) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);
     if (bn == 128) return bm == 128 ? launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 128, false, true>(a, stream) : launch_h<_Float16, 128, 2, 2, 3, kHaloRowsMax, 256, false, true>(a, stream);
     if (a.tail_w) return bm == 128 ? launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 128, true, true>(a, stream) : launch_h<_Float16, 64, 2, 2, 3, kHaloRowsMax, 256, true, true>(a, stream);

@@ -301,7 +301,6 @@ struct HaloArgs {
     int bm;          // flat output pixels per block of conv3x3_halo_kernel: 0 / 256 (default) or 128
     int persist_cus; // > 0: CU count; use the persistent form of the three-slab kernel where it exists (128 / 192-cout tiles, even chunk count)
     int slabs; // conv3x3_halo: 3 (default, also 0) = three weight slabs + counted vmcnt; 2 = two slabs, vmcnt(0) per tap
-    int two_per_cu; // split window kernel: 1 = 64 couts x 128 pixels with ONE window buffer (78 KB, <= 128 VGPRs): two blocks per CU (bm must be 128)
     int deep;       // split window kernel, 64-cout x 128-pixel tiles without a fused tail: 1 = six-slab weight ring + fragment prefetch (156 KB of LDS)
     int narrow; // split window kernel: 1 = 64-cout tiles for a layer of 128-multiple couts (twice the blocks; for grids that leave most CUs idle)
     int grid; // blocks of the launch (filled by the launchers: reading gridDim.x costs the set-up one more scalar-load round trip)
